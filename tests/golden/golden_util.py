@@ -1,0 +1,36 @@
+"""Helpers shared by make_golden.py (fixture writer) and the tests (fixture readers)."""
+import numpy as np
+import torch
+
+
+def seeded_uniform(shape, seed):
+    """U(-1, 1) tensor from an explicit CPU generator: the synthetic-tile distribution of SURVEY 8(d)
+    (matches the [-1, 1] range of deepliif/data/__init__.py:133-138 transform)."""
+    return torch.rand(tuple(shape), generator=torch.Generator().manual_seed(int(seed))) * 2 - 1
+
+
+def digest(t, nproj=4, seed=4242):
+    """[numel, l2 norm, sum, <t, r_0>, ..., <t, r_3>] with r_i seeded N(0,1) vectors -- a compact stand-in for a
+    large tensor: any elementwise discrepancy shows up in the random projections."""
+    flat = torch.as_tensor(t).detach().reshape(-1).double().cpu()
+    g = torch.Generator().manual_seed(seed)
+    vals = [float(flat.numel()), float(flat.norm()), float(flat.sum())]
+    for _ in range(nproj):
+        r = torch.randn(flat.numel(), generator=g, dtype=torch.float64)
+        vals.append(float((flat * r).sum()))
+    return np.array(vals, dtype=np.float64)
+
+
+def digest_close(actual, expected, rtol):
+    """Compare a tensor (or its digest) with a stored digest: the projections of N(0,1) vectors have standard
+    deviation = l2 norm, so differences are measured relative to the norm."""
+    a = actual if isinstance(actual, np.ndarray) and actual.ndim == 1 and actual.shape == expected.shape else digest(actual)
+    if a[0] != expected[0]:
+        return False, f'numel {a[0]} != {expected[0]}'
+    scale = max(expected[1], 1e-30)
+    err = np.abs(a[1:] - expected[1:]).max() / scale
+    # sum can be large relative to the norm: normalise by sqrt(numel) * norm as an upper bound
+    err_sum = abs(a[2] - expected[2]) / (scale * np.sqrt(expected[0]))
+    err_other = np.abs(np.delete(a, [0, 2]) - np.delete(expected, [0, 2])).max() / scale
+    worst = max(err_sum, err_other)
+    return worst <= rtol, f'digest rel err {worst:.3e} (tol {rtol:.1e})'
