@@ -1,0 +1,110 @@
+"""ctypes binding of libdeepliif_hip.so (include/deepliif_hip.h).
+
+The library is the product: importing this module without the built .so raises, there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdeepliif_hip.so')
+
+DL_F32, DL_BF16 = 0, 1
+PREC_BF16, PREC_BF16X3 = 1, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+NORM_INSTANCE, NORM_BATCH = 0, 1
+LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1, 2
+MAX_TAPS, MAX_PHASES = 64, 4
+
+i32 = C.c_int32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('N', i32), ('Hi', i32), ('Wi', i32), ('Ci', i32), ('in_pstride', i32),
+                ('Ho', i32), ('Wo', i32), ('Co', i32), ('out_pstride', i32),
+                ('Hq', i32), ('Wq', i32), ('out_step', i32), ('in_step', i32), ('n_phase', i32),
+                ('phase_oh', i32 * MAX_PHASES), ('phase_ow', i32 * MAX_PHASES),
+                ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
+                ('tap_dh', C.c_int8 * MAX_TAPS), ('tap_dw', C.c_int8 * MAX_TAPS),
+                ('pad_mode', i32), ('w_kstride', i32), ('w_rows', i32), ('act', i32),
+                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('N', i32), ('Hp', i32), ('Wp', i32), ('CAp', i32), ('p_pstride', i32),
+                ('Hq', i32), ('Wq', i32), ('CBp', i32), ('q_pstride', i32),
+                ('KH', i32), ('KW', i32), ('step', i32), ('pad', i32), ('pad_mode', i32),
+                ('CA', i32), ('CB', i32), ('dtype', i32), ('prec', i32), ('splitk', i32), ('accumulate', i32),
+                ('q_act', i32), ('p_act', i32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('A', i32), ('B', i32), ('KH', i32), ('KW', i32), ('row_is_a', i32),
+                ('rows_real', i32), ('rows_pad', i32), ('Cc', i32), ('Cc_pad', i32), ('n_phase', i32),
+                ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
+                ('tap_kh', C.c_int8 * MAX_TAPS), ('tap_kw', C.c_int8 * MAX_TAPS), ('kstride', i32)]
+
+
+class NormDesc(C.Structure):
+    _fields_ = [('N', i32), ('H', i32), ('W', i32), ('Cp', i32), ('C', i32),
+                ('y_pstride', i32), ('z_pstride', i32), ('r_pstride', i32),
+                ('dtype', i32), ('scope', i32), ('act', i32), ('eps', C.c_float), ('momentum', C.c_float)]
+
+
+_vp, _f, _i, _i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
+
+# every symbol include/deepliif_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'dl_version': (_i, []),
+    'dl_last_error': (C.c_char_p, []),
+    'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
+    'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
+    'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),
+    'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'dl_act_forward': (_i, [_i, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_act_backward': (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_axpby': (_i, [_i, _f, _vp, _i, _f, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_copy_channels': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _vp]),
+    'dl_channel_sum': (_i, [_i, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp]),
+    'dl_nchw_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    'dl_nhwc_to_nchw': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    'dl_loss_ws_floats': (C.c_size_t, []),
+    'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
+    'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    'dl_probe_mfma16': (_i, [_vp, _vp, _vp, _vp]),
+    'dl_probe_trread': (_i, [_vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HipLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C deepliif_amd/csrc`). deepliif_amd has no CPU / PyTorch fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dl_version() != 100:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 100 (stale build)')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dl_last_error().decode('utf-8', 'replace')
+        raise HipLibraryError(f'{what} failed (rc={rc}): {msg}')

@@ -1,0 +1,114 @@
+// common.h -- shared device helpers for libdeepliif_hip (gfx950 only; wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include "../../include/deepliif_hip.h"
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;     // MFMA A/B fragment (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;      // MFMA 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+void dl_set_error(const char *fmt, ...);
+#define DL_FAIL(...) do { dl_set_error(__VA_ARGS__); return -1; } while (0)
+#define DL_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    dl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return -2; } } while (0)
+
+// ---- bf16 <-> fp32 (round to nearest even; NaN handling not needed on this path)
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(u);
+#else
+    memcpy(&f, &u, 4);
+#endif
+    return f;
+}
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- 8-element vector load/store of an activation row chunk, as fp32 registers
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4 *>(p);
+        const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[8]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&v)[8]) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t *>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(a[i] << 16);
+            v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, const float (&v)[8]) {
+        u32x4_t a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
+        *reinterpret_cast<u32x4_t *>(p) = a;
+    }
+};
+template <typename T> __device__ __forceinline__ float load1(const T *p);
+template <> __device__ __forceinline__ float load1<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void store1(T *p, float v);
+template <> __device__ __forceinline__ void store1<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case DL_ACT_RELU: return v > 0.f ? v : 0.f;
+        case DL_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case DL_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative of the activation expressed through its OUTPUT (relu/lrelu keep the sign; tanh' = 1 - y^2)
+__device__ __forceinline__ float act_grad_from_output(int act, float y) {
+    switch (act) {
+        case DL_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case DL_ACT_LRELU: return y > 0.f ? 1.f : 0.2f;
+        case DL_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// wave64 butterfly sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, private L2s): consecutive logical blocks share an XCD.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

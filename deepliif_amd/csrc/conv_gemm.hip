@@ -1,0 +1,414 @@
+// conv_gemm.hip -- implicit-GEMM gather convolution on MFMA (gfx950), see include/deepliif_hip.h dl_conv_forward.
+//
+// GEMM view (per sub-pixel phase):   D[co][pix] = sum_k W[co][k] * X[pix][k],   k = (tap, ci), ci fastest.
+//   rows  (MFMA A operand) = output channels  -> packed weights, K-contiguous rows
+//   cols  (MFMA B operand) = output pixels    -> gathered NHWC activations, 8 channels (16 B) per load
+// Both LDS tiles are [row][BK] bf16 with the 16-byte chunks of a row XOR-swizzled so that ds_read_b128 fragment reads
+// are bank-conflict free for the gfx950 lane-group servicing order (MI355X_MICROARCH.md, LDS table).
+// The accumulator fragment of mfma_f32_16x16x32_bf16 gives each lane 4 consecutive output channels of one pixel
+// -> one 8-byte (bf16) / 16-byte (fp32) store per fragment.
+// Pipeline: register-staged double buffer (global loads of tile t+1 are issued before the MFMAs of tile t and written
+// to the other LDS buffer after them), one barrier per K step.
+#include "common.h"
+
+struct ConvArgs {
+    const void *in;
+    const bf16_t *w_hi;
+    const bf16_t *w_lo;
+    const float *bias;
+    void *out;
+    float *slab;
+    int N, Hi, Wi, Ci, log2Ci, in_pstride;
+    int Ho, Wo, Co, out_pstride;
+    int Hq, Wq, out_step, in_step;
+    int n_phase, splitk;
+    int phase_oh[DL_MAX_PHASES], phase_ow[DL_MAX_PHASES];
+    int phase_tap_begin[DL_MAX_PHASES + 1];
+    int phase_kbase[DL_MAX_PHASES];
+    int pad_mode, w_kstride, act, in_act, bias_n;
+    int tiles_m, tiles_n, Mtot;
+    int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
+};
+
+template <int CPR> __device__ __forceinline__ int swz_chunk(int row, int c) {
+    if constexpr (CPR == 4) {
+        // f(q) = {0,2,3,1}[q], q = (row >> 2) & 3
+        const int q = (row >> 2) & 3;
+        return c ^ ((0x1320 >> (4 * q)) & 3);
+    } else {
+        return c ^ ((row >> 1) & (CPR - 1));
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+// raw staging registers for one 8-element chunk
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { u32x4_t v; };
+template <> struct Raw8<float> { f32x4_t a, b; };
+
+template <typename T> __device__ __forceinline__ void raw_zero(Raw8<T> &r);
+template <> __device__ __forceinline__ void raw_zero<bf16_t>(Raw8<bf16_t> &r) { r.v = u32x4_t{0, 0, 0, 0}; }
+template <> __device__ __forceinline__ void raw_zero<float>(Raw8<float> &r) { r.a = f32x4_t{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+template <typename T> __device__ __forceinline__ void raw_load(Raw8<T> &r, const T *p);
+template <> __device__ __forceinline__ void raw_load<bf16_t>(Raw8<bf16_t> &r, const bf16_t *p) { r.v = *reinterpret_cast<const u32x4_t *>(p); }
+template <> __device__ __forceinline__ void raw_load<float>(Raw8<float> &r, const float *p) {
+    r.a = *reinterpret_cast<const f32x4_t *>(p);
+    r.b = *reinterpret_cast<const f32x4_t *>(p + 4);
+}
+__device__ __forceinline__ void raw_to_f32(const Raw8<bf16_t> &r, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r.v[i] << 16); f[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void raw_to_f32(const Raw8<float> &r, float (&f)[8]) {
+    f[0] = r.a[0]; f[1] = r.a[1]; f[2] = r.a[2]; f[3] = r.a[3]; f[4] = r.b[0]; f[5] = r.b[1]; f[6] = r.b[2]; f[7] = r.b[3];
+}
+
+// convert a staged chunk to the bf16 hi (and lo) LDS images
+template <typename T, int PREC>
+__device__ __forceinline__ void raw_to_planes(const Raw8<T> &r, int in_act, u32x4_t &hi, u32x4_t &lo) {
+    if constexpr (sizeof(T) == 2 && PREC == 1) {
+        if (in_act == DL_ACT_NONE) { hi = reinterpret_cast<const Raw8<bf16_t> &>(r).v; return; }
+    }
+    float f[8];
+    raw_to_f32(r, f);
+    if (in_act != DL_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = apply_act(in_act, f[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t h0 = f32_to_bf16(f[2 * i]), h1 = f32_to_bf16(f[2 * i + 1]);
+        hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        if constexpr (PREC == 3) {
+            lo[i] = pack2_bf16(f[2 * i] - bf16_to_f32(h0), f[2 * i + 1] - bf16_to_f32(h1));
+        }
+    }
+}
+
+template <typename TIn, typename TOut, int PREC, int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
+    constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row
+    constexpr int X_CH = (BM * CPR + 255) / 256;      // chunks per thread, activation tile
+    constexpr int W_CH = (BN * CPR + 255) / 256;      // chunks per thread, weight tile
+    constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
+    constexpr int NPL = (PREC == 3) ? 2 : 1;
+    constexpr int XT = BM * BK, WT = BN * BK;         // elements per tile plane
+    constexpr int BUF = NPL * (XT + WT);              // elements per pipeline buffer
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert((256 % CPR) == 0, "chunk column is constant per thread");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+    int16_t *tap_lds = reinterpret_cast<int16_t *>(smem + 2 * BUF);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
+    const int phase = blockIdx.y / a.splitk, ks = blockIdx.y % a.splitk;
+    const int tap0 = a.phase_tap_begin[phase];
+    const int ntaps = a.phase_tap_begin[phase + 1] - tap0;
+    const int kbase = a.phase_kbase[phase];
+    const int nk_total = (ntaps * a.Ci + 63) / 64 * 64 / BK;
+    const int nk_per = (nk_total + a.splitk - 1) / a.splitk;
+    const int kt_begin = ks * nk_per;
+    const int kt_end = min(nk_total, kt_begin + nk_per);
+
+    if (tid < DL_MAX_TAPS) tap_lds[tid] = a.taps[tid];
+
+    // ---- per-thread geometry of the activation rows it stages (fixed over the K loop)
+    const int xc = tid % CPR;                         // chunk column (same for all of this thread's rows)
+    int x_hi0[X_CH], x_wi0[X_CH], x_nbase[X_CH];
+    bool x_ok[X_CH];
+    const int HWq = a.Hq * a.Wq;
+#pragma unroll
+    for (int i = 0; i < X_CH; ++i) {
+        const int row = (tid + i * 256) / CPR;
+        const int m = tm * BM + row;
+        x_ok[i] = (row < BM) && (m < a.Mtot);
+        const int mm = x_ok[i] ? m : 0;
+        const int n = mm / HWq, rem = mm - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        x_hi0[i] = hq * a.in_step;
+        x_wi0[i] = wq * a.in_step;
+        x_nbase[i] = n * a.Hi;
+    }
+    const TIn *in = reinterpret_cast<const TIn *>(a.in);
+
+    Raw8<TIn> xr[X_CH];
+    u32x4_t wr[NPL][W_CH];
+
+    auto load_tile = [&](int kt) {
+        // activations
+        const int k0 = kt * BK + xc * 8;
+        const int tl = k0 >> a.log2Ci;
+        const int ci = k0 & (a.Ci - 1);
+        int dh = 0, dw = 0;
+        const bool tap_ok = tl < ntaps;
+        if (tap_ok) {
+            const int16_t t = tap_lds[tap0 + tl];
+            dh = (int)(int8_t)(t & 0xff);
+            dw = (int)(int8_t)((t >> 8) & 0xff);
+        }
+#pragma unroll
+        for (int i = 0; i < X_CH; ++i) {
+            int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
+            bool ok = x_ok[i] && tap_ok;
+            if (a.pad_mode == DL_PAD_REFLECT) {
+                hi = reflect_idx(hi, a.Hi);
+                wi = reflect_idx(wi, a.Wi);
+            } else {
+                ok = ok && ((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi);
+            }
+            if (ok) {
+                const size_t off = ((size_t)(x_nbase[i] + hi) * a.Wi + wi) * (size_t)a.in_pstride + ci;
+                raw_load<TIn>(xr[i], in + off);
+            } else {
+                raw_zero<TIn>(xr[i]);
+            }
+        }
+        // weights (rows padded to the tile, K padded: always in bounds)
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int q = tid + i * 256;
+            if (q < BN * CPR) {
+                const int row = q / CPR, c = q % CPR;
+                const size_t off = (size_t)(tn * BN + row) * a.w_kstride + kbase + kt * BK + c * 8;
+                wr[0][i] = *reinterpret_cast<const u32x4_t *>(a.w_hi + off);
+                if constexpr (PREC == 3) wr[1][i] = *reinterpret_cast<const u32x4_t *>(a.w_lo + off);
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        bf16_t *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < X_CH; ++i) {
+            const int q = tid + i * 256;
+            if (q < BM * CPR) {
+                const int row = q / CPR;
+                u32x4_t hi, lo;
+                raw_to_planes<TIn, PREC>(xr[i], a.in_act, hi, lo);
+                const int e = (row * CPR + swz_chunk<CPR>(row, xc)) * 8;
+                *reinterpret_cast<u32x4_t *>(base + e) = hi;
+                if constexpr (PREC == 3) *reinterpret_cast<u32x4_t *>(base + XT + e) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i) {
+            const int q = tid + i * 256;
+            if (q < BN * CPR) {
+                const int row = q / CPR, c = q % CPR;
+                const int e = (row * CPR + swz_chunk<CPR>(row, c)) * 8;
+                *reinterpret_cast<u32x4_t *>(base + NPL * XT + e) = wr[0][i];
+                if constexpr (PREC == 3) *reinterpret_cast<u32x4_t *>(base + NPL * XT + WT + e) = wr[1][i];
+            }
+        }
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();     // tap table visible
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = (kt + 1 < kt_end);
+        if (more) load_tile(kt + 1);
+
+        const bf16_t *base = smem + cur * BUF;
+        const bf16_t *Xs = base, *Ws = base + NPL * XT;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t wf[NPL][FN], xf[NPL][FM];
+            const int ch = kk * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int row = wn * PN + i * 16 + fr;
+                const int e = (row * CPR + swz_chunk<CPR>(row, ch)) * 8;
+                wf[0][i] = *reinterpret_cast<const bf16x8_t *>(Ws + e);
+                if constexpr (PREC == 3) wf[1][i] = *reinterpret_cast<const bf16x8_t *>(Ws + WT + e);
+            }
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int row = wm * PM + j * 16 + fr;
+                const int e = (row * CPR + swz_chunk<CPR>(row, ch)) * 8;
+                xf[0][j] = *reinterpret_cast<const bf16x8_t *>(Xs + e);
+                if constexpr (PREC == 3) xf[1][j] = *reinterpret_cast<const bf16x8_t *>(Xs + XT + e);
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    if constexpr (PREC == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels co..co+3 of pixel (column fr) for each fragment
+    const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = tm * BM + wm * PM + j * 16 + fr;
+        if (m >= a.Mtot) continue;
+        const int n = m / HWq, rem = m - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int co = tn * BN + wn * PN + i * 16 + fg * 4;
+            if (co >= a.Co) continue;
+            f32x4_t v = acc[i][j];
+            if (a.splitk > 1) {
+                float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
+                }
+                if (a.act != DL_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(a.act, v[r]);
+                }
+                TOut *dst = reinterpret_cast<TOut *>(a.out) + opix * a.out_pstride + co;
+                if constexpr (sizeof(TOut) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    u32x2_t p;
+                    p[0] = pack2_bf16(v[0], v[1]);
+                    p[1] = pack2_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2_t *>(dst) = p;
+                }
+            }
+        }
+    }
+}
+
+// out[p][c] = act(bias[c] + sum_ks slab[ks][p][c]), fixed summation order (deterministic)
+template <typename TOut>
+__global__ void __launch_bounds__(256) conv_slab_reduce_kernel(const float *slab, int splitk, size_t npix, int Co,
+                                                               const float *bias, int bias_n, int act, TOut *out, int out_pstride) {
+    const size_t total = npix * (size_t)(Co / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / (Co / 4);
+        const int c = (int)(i % (Co / 4)) * 4;
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < splitk; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(slab + ((size_t)k * npix + p) * Co + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (bias) {
+            s.x += (c < bias_n) ? bias[c] : 0.f; s.y += (c + 1 < bias_n) ? bias[c + 1] : 0.f;
+            s.z += (c + 2 < bias_n) ? bias[c + 2] : 0.f; s.w += (c + 3 < bias_n) ? bias[c + 3] : 0.f;
+        }
+        s.x = apply_act(act, s.x); s.y = apply_act(act, s.y); s.z = apply_act(act, s.z); s.w = apply_act(act, s.w);
+        TOut *dst = out + p * out_pstride + c;
+        store1<TOut>(dst, s.x); store1<TOut>(dst + 1, s.y); store1<TOut>(dst + 2, s.z); store1<TOut>(dst + 3, s.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host dispatch
+template <typename TIn, typename TOut, int PREC, int BM, int BN, int BK, int WM, int WN>
+static int launch_conv(const ConvArgs &a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.Mtot + BM - 1) / BM;
+    a.tiles_n = (a.Co + BN - 1) / BN;
+    constexpr int NPL = (PREC == 3) ? 2 : 1;
+    constexpr size_t smem = (size_t)2 * NPL * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int16_t);
+    auto kern = conv_gemm_kernel<TIn, TOut, PREC, BM, BN, BK, WM, WN>;
+    static bool attr_set = false;      // benign race: idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_forward: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.n_phase * a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_forward");
+    return 0;
+}
+
+template <typename TIn, typename TOut, int PREC>
+static int dispatch_tile(const ConvArgs &a, hipStream_t stream) {
+    constexpr int BK = (PREC == 3) ? 32 : 64;
+    if (a.Co <= 16) return launch_conv<TIn, TOut, PREC, 256, 16, 32, 4, 1>(a, stream);
+    if (a.Co <= 64) return launch_conv<TIn, TOut, PREC, 128, 64, BK, 2, 2>(a, stream);
+    return launch_conv<TIn, TOut, PREC, 128, 128, BK, 2, 2>(a, stream);
+}
+
+extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
+                               void *out, float *slab, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !in || !w_hi || !out) DL_FAIL("dl_conv_forward: null argument");
+    const int l2 = ilog2_exact(d->Ci);
+    if (l2 < 3) DL_FAIL("dl_conv_forward: Ci=%d must be a power of two >= 8", d->Ci);
+    if (d->Co % 8 || d->Co <= 0) DL_FAIL("dl_conv_forward: Co=%d must be a positive multiple of 8", d->Co);
+    if (d->in_pstride % 8 || d->out_pstride % 4) DL_FAIL("dl_conv_forward: pixel strides must keep 16-byte alignment");
+    if (d->n_phase < 1 || d->n_phase > DL_MAX_PHASES) DL_FAIL("dl_conv_forward: n_phase=%d", d->n_phase);
+    if (d->phase_tap_begin[d->n_phase] > DL_MAX_TAPS) DL_FAIL("dl_conv_forward: too many taps");
+    if (d->prec == DL_PREC_BF16X3 && !w_lo) DL_FAIL("dl_conv_forward: BF16X3 needs the lo weight plane");
+    if (d->prec == DL_PREC_BF16X3 && d->in_dtype != DL_F32) DL_FAIL("dl_conv_forward: BF16X3 needs fp32 activations");
+    if (d->in_dtype != d->out_dtype) DL_FAIL("dl_conv_forward: in/out dtype must match");
+    if (d->splitk < 1 || (d->splitk > 1 && !slab)) DL_FAIL("dl_conv_forward: splitk=%d needs a slab", d->splitk);
+    if (d->pad_mode == DL_PAD_REFLECT && (d->n_phase != 1)) DL_FAIL("dl_conv_forward: reflect padding only for single-phase layers");
+    if ((size_t)d->N * d->Hi * d->Wi * (size_t)d->in_pstride >= ((size_t)1 << 40)) DL_FAIL("dl_conv_forward: tensor too large");
+    for (int p = 0; p < d->n_phase; ++p)
+        if (d->phase_kbase[p] % 64) DL_FAIL("dl_conv_forward: phase_kbase must be a multiple of 64");
+
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w_hi = (const bf16_t *)w_hi; a.w_lo = (const bf16_t *)w_lo; a.bias = bias; a.out = out; a.slab = slab;
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.log2Ci = l2; a.in_pstride = d->in_pstride;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.out_pstride = d->out_pstride;
+    a.Hq = d->Hq; a.Wq = d->Wq; a.out_step = d->out_step; a.in_step = d->in_step;
+    a.n_phase = d->n_phase; a.splitk = d->splitk;
+    for (int p = 0; p < DL_MAX_PHASES; ++p) { a.phase_oh[p] = d->phase_oh[p]; a.phase_ow[p] = d->phase_ow[p]; a.phase_kbase[p] = d->phase_kbase[p]; }
+    for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
+    for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
+    a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n;
+    a.Mtot = d->N * d->Hq * d->Wq;
+
+    int rc;
+    if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
+    else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_tile<float, float, 3>(a, stream);
+    else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_tile<float, float, 1>(a, stream);
+    else DL_FAIL("dl_conv_forward: unsupported dtype/precision combination (%d, %d)", d->in_dtype, d->prec);
+    if (rc) return rc;
+
+    if (d->splitk > 1) {
+        const size_t npix = (size_t)d->N * d->Ho * d->Wo;
+        const size_t total = npix * (size_t)(d->Co / 4);
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        if (d->out_dtype == DL_F32)
+            hipLaunchKernelGGL(conv_slab_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, npix, d->Co,
+                               bias, d->bias_n, d->act, (float *)out, d->out_pstride);
+        else
+            hipLaunchKernelGGL(conv_slab_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, npix, d->Co,
+                               bias, d->bias_n, d->act, (bf16_t *)out, d->out_pstride);
+        DL_CHECK_LAUNCH("dl_conv_forward(reduce)");
+    }
+    return 0;
+}

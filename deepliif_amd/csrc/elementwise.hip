@@ -1,0 +1,306 @@
+// elementwise.hip -- activations, axpby, channel copies (torch.cat / slicing), channel sums (bias gradients), GAN / SmoothL1
+// losses with their gradients, fused Adam, and the hardware probes.  All HBM-bound: 16-byte vector accesses along the NHWC
+// channel axis, grid-stride loops, fixed-order two-stage reductions (deterministic).  See include/deepliif_hip.h.
+#include "common.h"
+
+#define EW_BLOCKS(total) ((int)min((size_t)8192, ((size_t)(total) + 255) / 256))
+
+// ------------------------------------------------------------------------------------------- activations
+template <typename T>
+__global__ void __launch_bounds__(256) act_fwd_kernel(int act, const T *x, int x_ps, T *y, int y_ps, size_t npix, int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cvec;
+        const int c0 = (int)(i % cvec) * 8;
+        float v[8];
+        Vec8<T>::load(x + p * x_ps + c0, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = apply_act(act, v[k]);
+        Vec8<T>::store(y + p * y_ps + c0, v);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(int act, const T *dy, int dy_ps, const T *y, int y_ps, T *dx, int dx_ps, size_t npix,
+                                                      int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cvec;
+        const int c0 = (int)(i % cvec) * 8;
+        float g[8], o[8];
+        Vec8<T>::load(dy + p * dy_ps + c0, g);
+        Vec8<T>::load(y + p * y_ps + c0, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] *= act_grad_from_output(act, o[k]);
+        Vec8<T>::store(dx + p * dx_ps + c0, g);
+    }
+}
+extern "C" int dl_act_forward(int act, int dtype, const void *x, int x_ps, void *y, int y_ps, int64_t npix, int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || Cp % 8 || x_ps % 8 || y_ps % 8) DL_FAIL("dl_act_forward: bad argument");
+    const size_t total = (size_t)npix * (Cp / 8);
+    if (dtype == DL_F32) hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, act, (const float *)x, x_ps, (float *)y, y_ps, (size_t)npix, Cp);
+    else hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, act, (const bf16_t *)x, x_ps, (bf16_t *)y, y_ps, (size_t)npix, Cp);
+    DL_CHECK_LAUNCH("dl_act_forward");
+    return 0;
+}
+extern "C" int dl_act_backward(int act, int dtype, const void *dy, int dy_ps, const void *y, int y_ps, void *dx, int dx_ps, int64_t npix,
+                               int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !y || !dx || Cp % 8 || dy_ps % 8 || y_ps % 8 || dx_ps % 8) DL_FAIL("dl_act_backward: bad argument");
+    const size_t total = (size_t)npix * (Cp / 8);
+    if (dtype == DL_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, act, (const float *)dy, dy_ps, (const float *)y, y_ps, (float *)dx, dx_ps, (size_t)npix, Cp);
+    else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, act, (const bf16_t *)dy, dy_ps, (const bf16_t *)y, y_ps, (bf16_t *)dx, dx_ps, (size_t)npix, Cp);
+    DL_CHECK_LAUNCH("dl_act_backward");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- out = alpha*a + beta*b
+template <typename T>
+__global__ void __launch_bounds__(256) axpby_kernel(float alpha, const T *a, int a_ps, float beta, const T *b, int b_ps, T *out, int o_ps,
+                                                    size_t npix, int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cvec;
+        const int c0 = (int)(i % cvec) * 8;
+        float va[8], vb[8];
+        Vec8<T>::load(a + p * a_ps + c0, va);
+        if (b) {
+            Vec8<T>::load(b + p * b_ps + c0, vb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] = alpha * va[k] + beta * vb[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] = alpha * va[k];
+        }
+        Vec8<T>::store(out + p * o_ps + c0, va);
+    }
+}
+extern "C" int dl_axpby(int dtype, float alpha, const void *a, int a_ps, float beta, const void *b, int b_ps, void *out, int o_ps,
+                        int64_t npix, int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a || !out || Cp % 8 || a_ps % 8 || o_ps % 8 || (b && b_ps % 8)) DL_FAIL("dl_axpby: bad argument");
+    const size_t total = (size_t)npix * (Cp / 8);
+    if (dtype == DL_F32) hipLaunchKernelGGL(axpby_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, alpha, (const float *)a, a_ps, beta, (const float *)b, b_ps, (float *)out, o_ps, (size_t)npix, Cp);
+    else hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, alpha, (const bf16_t *)a, a_ps, beta, (const bf16_t *)b, b_ps, (bf16_t *)out, o_ps, (size_t)npix, Cp);
+    DL_CHECK_LAUNCH("dl_axpby");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- channel copy (cat / slice)
+template <typename T>
+__global__ void __launch_bounds__(256) copy_channels_kernel(const T *src, int s_ps, int s_c0, T *dst, int d_ps, int d_c0, size_t npix, int C,
+                                                            int accumulate) {
+    const size_t total = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i % C);
+        float v = load1<T>(src + p * s_ps + s_c0 + c);
+        T *d = dst + p * d_ps + d_c0 + c;
+        if (accumulate) v += load1<T>(d);
+        store1<T>(d, v);
+    }
+}
+extern "C" int dl_copy_channels(int dtype, const void *src, int s_ps, int s_c0, void *dst, int d_ps, int d_c0, int64_t npix, int C,
+                                int accumulate, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst || C <= 0) DL_FAIL("dl_copy_channels: bad argument");
+    const size_t total = (size_t)npix * C;
+    if (dtype == DL_F32) hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)src, s_ps, s_c0, (float *)dst, d_ps, d_c0, (size_t)npix, C, accumulate);
+    else hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)src, s_ps, s_c0, (bf16_t *)dst, d_ps, d_c0, (size_t)npix, C, accumulate);
+    DL_CHECK_LAUNCH("dl_copy_channels");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- per-channel sum over pixels
+#define CS_BLOCKS 256
+template <typename T>
+__global__ void __launch_bounds__(256) channel_sum_partial_kernel(const T *x, int ps, size_t npix, int Cp, float *part) {
+    __shared__ float red[256 * 9];
+    const int tid = threadIdx.x;
+    const int cvec = Cp / 8;
+    for (int cbase = 0; cbase < cvec; cbase += 256) {
+        const int tpp = min(cvec - cbase, 256), rows = 256 / tpp;
+        const int col = tid % tpp, row = tid / tpp;
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = 0.f;
+        if (row < rows) {
+            for (size_t p = (size_t)blockIdx.x * rows + row; p < npix; p += (size_t)gridDim.x * rows) {
+                float v[8];
+                Vec8<T>::load(x + p * ps + (cbase + col) * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s[k] += v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[tid * 9 + k] = s[k];
+        __syncthreads();
+        if (tid < tpp) {
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = 0.f;
+            for (int r = 0; r < rows; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += red[(r * tpp + tid) * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) part[(size_t)blockIdx.x * Cp + (cbase + tid) * 8 + k] = a[k];
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float *part, int nblocks, int Cp, int C, float *out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)part[(size_t)b * Cp + c];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+extern "C" int dl_channel_sum(int dtype, const void *x, int ps, int64_t npix, int Cp, int C, float *out, int accumulate, float *ws,
+                              void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !out || !ws || Cp % 8 || ps % 8) DL_FAIL("dl_channel_sum: bad argument (ws needs %d*Cp floats)", CS_BLOCKS);
+    if (dtype == DL_F32) hipLaunchKernelGGL(channel_sum_partial_kernel<float>, dim3(CS_BLOCKS), dim3(256), 0, stream, (const float *)x, ps, (size_t)npix, Cp, ws);
+    else hipLaunchKernelGGL(channel_sum_partial_kernel<bf16_t>, dim3(CS_BLOCKS), dim3(256), 0, stream, (const bf16_t *)x, ps, (size_t)npix, Cp, ws);
+    DL_CHECK_LAUNCH("dl_channel_sum(partial)");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, CS_BLOCKS, Cp, C, out, accumulate);
+    DL_CHECK_LAUNCH("dl_channel_sum(final)");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- losses
+#define LOSS_BLOCKS 512
+extern "C" size_t dl_loss_ws_floats(void) { return LOSS_BLOCKS; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) loss_kernel(int kind, const T *x, int x_ps, const T *target, int t_ps, float tconst, size_t npix, int C,
+                                                   float inv_count, T *grad, int g_ps, float gscale, int Cp, float *part) {
+    __shared__ float red[4];
+    const size_t total = npix * C;
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i % C);
+        const float v = load1<T>(x + p * x_ps + c);
+        const float t = target ? load1<T>(target + p * t_ps + c) : tconst;
+        float l, g;
+        if (kind == DL_LOSS_BCE_LOGITS) {
+            // max(v,0) - v*t + log(1 + exp(-|v|));  d/dv = sigmoid(v) - t
+            const float e = expf(-fabsf(v));
+            l = fmaxf(v, 0.f) - v * t + log1pf(e);
+            const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            g = sig - t;
+        } else if (kind == DL_LOSS_MSE) {
+            const float d = v - t;
+            l = d * d;
+            g = 2.f * d;
+        } else {
+            const float d = v - t, ad = fabsf(d);
+            l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+            g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        }
+        acc += l;
+        if (grad) store1<T>(grad + p * g_ps + c, g * gscale * inv_count);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    // zero the padded channels of the gradient so downstream vector kernels see clean padding
+    if (grad && Cp > C) {
+        const size_t totalp = npix * (Cp - C);
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < totalp; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t p = i / (Cp - C);
+            const int c = C + (int)(i % (Cp - C));
+            store1<T>(grad + p * g_ps + c, 0.f);
+        }
+    }
+}
+__global__ void loss_final_kernel(const float *part, int n, float inv_count, float *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)part[i];
+        out[0] = (float)(s * (double)inv_count);
+    }
+}
+extern "C" int dl_loss(int kind, int dtype, const void *x, int x_ps, const void *target, int t_ps, float tconst, int64_t npix, int C, int Cp,
+                       float *loss_out, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !loss_out || !ws || C <= 0 || C > Cp) DL_FAIL("dl_loss: bad argument");
+    if (kind < 0 || kind > 2) DL_FAIL("dl_loss: kind %d", kind);
+    const float inv = 1.0f / (float)((double)npix * C);
+    if (dtype == DL_F32) hipLaunchKernelGGL(loss_kernel<float>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const float *)x, x_ps, (const float *)target, t_ps, tconst, (size_t)npix, C, inv, (float *)grad, g_ps, gscale, Cp, ws);
+    else hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const bf16_t *)x, x_ps, (const bf16_t *)target, t_ps, tconst, (size_t)npix, C, inv, (bf16_t *)grad, g_ps, gscale, Cp, ws);
+    DL_CHECK_LAUNCH("dl_loss");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, LOSS_BLOCKS, inv, loss_out);
+    DL_CHECK_LAUNCH("dl_loss(final)");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- Adam
+__global__ void __launch_bounds__(256) adam_kernel(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float gscale) {
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int step, float grad_scale, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) DL_FAIL("dl_adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(EW_BLOCKS(n)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2,
+                       eps, bc1, sqrtf(bc2), grad_scale);
+    DL_CHECK_LAUNCH("dl_adam_step");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- probes
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// D[16][16] = A[16][32] * B[32][16] with the fragment mapping the GEMM kernels assume
+__global__ void probe_mfma16_kernel(const bf16_t *A, const bf16_t *B, float *D) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    bf16x8_t a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = (short)A[r * 32 + g * 8 + j];          // A[row = r][k = 8g + j]
+        b[j] = (short)B[(g * 8 + j) * 16 + r];        // B[k = 8g + j][col = r]
+    }
+    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) D[(g * 4 + i) * 16 + r] = c[i];   // row = 4g + i, col = r
+}
+extern "C" int dl_probe_mfma16(const uint16_t *a, const uint16_t *b, float *d, void *stream_) {
+    hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a, b, d);
+    DL_CHECK_LAUNCH("dl_probe_mfma16");
+    return 0;
+}
+// src: 64 rows x 16 cols bf16 (row-major).  Lane (m = lane&15, g = lane>>4) issues ds_read_b64_tr_b16 at
+// &tile[4g + (m>>2)][(m&3)*4]; dst[lane][j] receives the four returned elements.
+__global__ void probe_trread_kernel(const bf16_t *src, bf16_t *dst) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 16];
+    for (int i = threadIdx.x; i < 64 * 16; i += 64) tile[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+    const bf16_t *p = tile + (4 * g + (m >> 2)) * 16 + (m & 3) * 4;
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = (bf16_t)v[j];
+}
+extern "C" int dl_probe_trread(const uint16_t *src, uint16_t *dst, void *stream_) {
+    hipLaunchKernelGGL(probe_trread_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, src, dst);
+    DL_CHECK_LAUNCH("dl_probe_trread");
+    return 0;
+}

@@ -1,0 +1,112 @@
+// pack.hip -- parameter packing (fp32 OIHW/IOHW -> K-contiguous bf16 hi/lo GEMM images) and the NCHW<->NHWC boundary
+// converters.  All pure HBM streaming; see include/deepliif_hip.h.
+#include "common.h"
+
+struct PackArgs {
+    const float *src;
+    bf16_t *w_hi, *w_lo;
+    int A, B, KH, KW, row_is_a, rows_real, rows_pad, Cc, Cc_pad, log2Cc, n_phase, kstride;
+    int phase_tap_begin[DL_MAX_PHASES + 1];
+    int phase_kbase[DL_MAX_PHASES];
+    int phase_kend[DL_MAX_PHASES];
+    int8_t tap_kh[DL_MAX_TAPS], tap_kw[DL_MAX_TAPS];
+};
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) {
+    const size_t total = (size_t)a.rows_pad * a.kstride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / a.kstride), k = (int)(i % a.kstride);
+        float v = 0.f;
+        if (row < a.rows_real) {
+            int ph = -1;
+            for (int p = 0; p < a.n_phase; ++p)
+                if (k >= a.phase_kbase[p] && k < a.phase_kend[p]) ph = p;
+            if (ph >= 0) {
+                const int kl = k - a.phase_kbase[ph];
+                const int tl = kl >> a.log2Cc, c = kl & (a.Cc_pad - 1);
+                const int t = a.phase_tap_begin[ph] + tl;
+                if (t < a.phase_tap_begin[ph + 1] && c < a.Cc) {
+                    const int kh = a.tap_kh[t], kw = a.tap_kw[t];
+                    const int ia = a.row_is_a ? row : c, ib = a.row_is_a ? c : row;
+                    v = a.src[(((size_t)ia * a.B + ib) * a.KH + kh) * a.KW + kw];
+                }
+            }
+        }
+        const bf16_t h = f32_to_bf16(v);
+        a.w_hi[i] = h;
+        if (a.w_lo) a.w_lo[i] = f32_to_bf16(v - bf16_to_f32(h));
+    }
+}
+
+extern "C" int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !src || !w_hi) DL_FAIL("dl_pack_weights: null argument");
+    const int l2 = ilog2_exact(d->Cc_pad);
+    if (l2 < 3) DL_FAIL("dl_pack_weights: Cc_pad=%d must be a power of two >= 8", d->Cc_pad);
+    if (d->n_phase < 1 || d->n_phase > DL_MAX_PHASES) DL_FAIL("dl_pack_weights: n_phase=%d", d->n_phase);
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.w_hi = (bf16_t *)w_hi; a.w_lo = (bf16_t *)w_lo;
+    a.A = d->A; a.B = d->B; a.KH = d->KH; a.KW = d->KW; a.row_is_a = d->row_is_a;
+    a.rows_real = d->rows_real; a.rows_pad = d->rows_pad; a.Cc = d->Cc; a.Cc_pad = d->Cc_pad; a.log2Cc = l2;
+    a.n_phase = d->n_phase; a.kstride = d->kstride;
+    for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
+    for (int p = 0; p < d->n_phase; ++p) {
+        a.phase_kbase[p] = d->phase_kbase[p];
+        a.phase_kend[p] = d->phase_kbase[p] + (d->phase_tap_begin[p + 1] - d->phase_tap_begin[p]) * d->Cc_pad;
+        if (a.phase_kend[p] > d->kstride) DL_FAIL("dl_pack_weights: phase %d exceeds kstride", p);
+    }
+    for (int t = 0; t < DL_MAX_TAPS; ++t) { a.tap_kh[t] = d->tap_kh[t]; a.tap_kw[t] = d->tap_kw[t]; }
+    const size_t total = (size_t)d->rows_pad * d->kstride;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    DL_CHECK_LAUNCH("dl_pack_weights");
+    return 0;
+}
+
+// ---- NCHW fp32 -> NHWC (channels [c0, c0+C) of a padded buffer; optional zeroing of channels [c0+C, zero_pad_to))
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float *src, int N, int C, int H, int W, T *dst, int pstride, int c0,
+                                                           int zero_to) {
+    const size_t hw = (size_t)H * W, npix = (size_t)N * hw;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = p / hw, r = p % hw;
+        T *d = dst + p * pstride + c0;
+        for (int c = 0; c < C; ++c) store1<T>(d + c, src[(n * C + c) * hw + r]);
+        for (int c = C; c0 + c < zero_to; ++c) store1<T>(d + c, 0.f);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T *src, int pstride, int c0, float *dst, int N, int C, int H, int W) {
+    const size_t hw = (size_t)H * W, total = (size_t)N * C * hw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i % hw, c = (i / hw) % C, n = i / (hw * C);
+        dst[i] = load1<T>(src + (n * hw + r) * pstride + c0 + c);
+    }
+}
+
+extern "C" int dl_nchw_to_nhwc(const float *src, int N, int C, int H, int W, int dtype, void *dst, int dst_pstride, int dst_c0,
+                               int zero_pad_to, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst) DL_FAIL("dl_nchw_to_nhwc: null argument");
+    const size_t npix = (size_t)N * H * W;
+    const int blocks = (int)min((size_t)4096, (npix + 255) / 256);
+    if (dtype == DL_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, N, C, H, W, (float *)dst, dst_pstride, dst_c0, zero_pad_to);
+    else if (dtype == DL_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, src, N, C, H, W, (bf16_t *)dst, dst_pstride, dst_c0, zero_pad_to);
+    else DL_FAIL("dl_nchw_to_nhwc: dtype %d", dtype);
+    DL_CHECK_LAUNCH("dl_nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int dl_nhwc_to_nchw(int dtype, const void *src, int src_pstride, int src_c0, float *dst, int N, int C, int H, int W,
+                               void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst) DL_FAIL("dl_nhwc_to_nchw: null argument");
+    const size_t total = (size_t)N * C * H * W;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    if (dtype == DL_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)src, src_pstride, src_c0, dst, N, C, H, W);
+    else if (dtype == DL_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t *)src, src_pstride, src_c0, dst, N, C, H, W);
+    else DL_FAIL("dl_nhwc_to_nchw: dtype %d", dtype);
+    DL_CHECK_LAUNCH("dl_nhwc_to_nchw");
+    return 0;
+}

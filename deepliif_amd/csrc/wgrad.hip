@@ -1,0 +1,321 @@
+// wgrad.hip -- weight gradient of Conv2d / ConvTranspose2d on MFMA (gfx950), see include/deepliif_hip.h dl_conv_wgrad.
+//
+// GEMM view:  R[ca][j] = sum_p P[p][ca] * Q[gather(p, tap(j))][cb(j)],   j = tap * CBp + cb,   p = (n, hp, wp).
+// The contraction index is the PIXEL, but both operands are stored pixel-major (NHWC): the 8 consecutive k values an
+// mfma_f32_16x16x32_bf16 lane needs are 8 different pixels of one channel.  The tiles are staged in LDS exactly as they
+// lie in memory ([pixel][channel], rows padded by 32 B against bank conflicts) and the fragments are fetched with
+// gfx950's transposing LDS read ds_read_b64_tr_b16 (two per fragment).  A and B fragments use the same
+// (lane group, element) -> pixel mapping, which is all the MFMA contraction requires.
+// Split-K over pixel ranges writes fp32 slabs; a second kernel combines them in a fixed order (deterministic) and
+// scatters into the parameter-gradient layout [a][b][kh][kw].
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+struct WgradArgs {
+    const void *P;
+    const void *Q;
+    float *slab;
+    int N, Hp, Wp, CAp, p_pstride;
+    int Hq, Wq, CBp, log2CB, q_pstride;
+    int KH, KW, step, pad, pad_mode;
+    int J;              // KH*KW*CBp
+    int Ptot;           // N*Hp*Wp
+    int splitk, pchunk; // pixels per split (multiple of 32)
+    int tiles_a, tiles_j;
+    int dn, dh, dw;     // 32 pixels in mixed radix (Hp*Wp, Wp, 1)
+    int p_act, q_act;
+};
+
+__device__ __forceinline__ int reflect_idx_w(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+template <typename T> struct RawW;
+template <> struct RawW<bf16_t> { u32x4_t v; };
+template <> struct RawW<float> { f32x4_t a, b; };
+
+template <typename T, int PREC>
+__device__ __forceinline__ void raww_to_planes(const RawW<T> &r, int act, u32x4_t &hi, u32x4_t &lo) {
+    float f[8];
+    if constexpr (sizeof(T) == 2) {
+        if (PREC == 1 && act == DL_ACT_NONE) { hi = r.v; return; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r.v[i] << 16); f[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = r.a[i]; f[4 + i] = r.b[i]; }
+    }
+    if (act != DL_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = apply_act(act, f[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t h0 = f32_to_bf16(f[2 * i]), h1 = f32_to_bf16(f[2 * i + 1]);
+        hi[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        if constexpr (PREC == 3) lo[i] = pack2_bf16(f[2 * i] - bf16_to_f32(h0), f[2 * i + 1] - bf16_to_f32(h1));
+    }
+}
+
+template <typename T> __device__ __forceinline__ void raww_load(RawW<T> &r, const T *p);
+template <> __device__ __forceinline__ void raww_load<bf16_t>(RawW<bf16_t> &r, const bf16_t *p) { r.v = *reinterpret_cast<const u32x4_t *>(p); }
+template <> __device__ __forceinline__ void raww_load<float>(RawW<float> &r, const float *p) {
+    r.a = *reinterpret_cast<const f32x4_t *>(p);
+    r.b = *reinterpret_cast<const f32x4_t *>(p + 4);
+}
+template <typename T> __device__ __forceinline__ void raww_zero(RawW<T> &r);
+template <> __device__ __forceinline__ void raww_zero<bf16_t>(RawW<bf16_t> &r) { r.v = u32x4_t{0, 0, 0, 0}; }
+template <> __device__ __forceinline__ void raww_zero<float>(RawW<float> &r) { r.a = f32x4_t{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+
+// transposing fragment fetch: tile is [32 pixels][ROW bf16]; returns for lane (i = lane&15, g = lane>>4) the 8 values
+// tile[8g + 4h + j][c0 + i], h = 0,1, j = 0..3.
+template <int ROW>
+__device__ __forceinline__ bf16x8_t tr_fragment(const bf16_t *tile, int c0, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const bf16_t *p0 = tile + (8 * g + (m >> 2)) * ROW + c0 + (m & 3) * 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(p0 + 4 * ROW));
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// BA: tile rows (channels of P), BJ = 128 columns (tap, cb); waves WA x WJ
+template <typename T, int PREC, int BA, int WA, int WJ>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+    constexpr int BJ = 128, BP = 32;
+    constexpr int PA = BA / WA, PJ = BJ / WJ, FA = PA / 16, FJ = PJ / 16;
+    constexpr int ROWA = BA + 16, ROWJ = BJ + 16;          // padded LDS rows (elements)
+    constexpr int NPL = (PREC == 3) ? 2 : 1;
+    constexpr int TA = BP * ROWA, TJ = BP * ROWJ;          // elements per tile plane
+    constexpr int BUF = NPL * (TA + TJ);
+    constexpr int CPA = BA / 8;                            // chunks per pixel row of P
+    constexpr int P_CH = (BP * CPA + 255) / 256;
+    constexpr int Q_CH = (BP * 16) / 256;                  // = 2
+    static_assert(WA * WJ == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave % WA, wj = wave / WA;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
+    const int ks = blockIdx.y;
+    const int p_begin = ks * a.pchunk;
+    const int p_end = min(a.Ptot, p_begin + a.pchunk);
+    const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const T *P = reinterpret_cast<const T *>(a.P);
+    const T *Q = reinterpret_cast<const T *>(a.Q);
+
+    // ---- Q chunk geometry: column chunk fixed per thread, two pixel rows (tid/16 and 16 + tid/16)
+    const int qcol = tid & 15;
+    const int j0 = tj * BJ + qcol * 8;
+    const int tap = j0 >> a.log2CB;
+    const int cb = j0 & (a.CBp - 1);
+    const bool tap_ok = tap < a.KH * a.KW;
+    const int kh = tap_ok ? tap / a.KW : 0, kw = tap_ok ? tap - (tap / a.KW) * a.KW : 0;
+    int qn[Q_CH], qh[Q_CH], qw[Q_CH];
+    const int HWp = a.Hp * a.Wp;
+#pragma unroll
+    for (int i = 0; i < Q_CH; ++i) {
+        const int p = p_begin + (tid >> 4) + i * 16;
+        qn[i] = p / HWp;
+        const int rem = p - qn[i] * HWp;
+        qh[i] = rem / a.Wp;
+        qw[i] = rem - qh[i] * a.Wp;
+    }
+
+    RawW<T> pr[P_CH], qr[Q_CH];
+
+    auto load_tile = [&](int kt) {
+        const int pbase = p_begin + kt * BP;
+#pragma unroll
+        for (int i = 0; i < P_CH; ++i) {
+            const int q = tid + i * 256;
+            const int prow = q / CPA, ch = (q % CPA) * 8;
+            const int p = pbase + prow;
+            const int ca = ta * BA + ch;
+            if (q < BP * CPA && p < p_end && ca < a.CAp) raww_load<T>(pr[i], P + (size_t)p * a.p_pstride + ca);
+            else raww_zero<T>(pr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < Q_CH; ++i) {
+            const int p = pbase + (tid >> 4) + i * 16;
+            int h = qh[i] * a.step - a.pad + kh, w = qw[i] * a.step - a.pad + kw;
+            bool ok = tap_ok && p < p_end;
+            if (a.pad_mode == DL_PAD_REFLECT) { h = reflect_idx_w(h, a.Hq); w = reflect_idx_w(w, a.Wq); }
+            else ok = ok && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
+            if (ok) raww_load<T>(qr[i], Q + ((size_t)(qn[i] * a.Hq + h) * a.Wq + w) * a.q_pstride + cb);
+            else raww_zero<T>(qr[i]);
+            // advance this row by 32 pixels (mixed radix add with single carries)
+            qw[i] += a.dw;
+            const int cw = qw[i] >= a.Wp;
+            qw[i] -= cw ? a.Wp : 0;
+            qh[i] += a.dh + cw;
+            const int chh = qh[i] >= a.Hp;
+            qh[i] -= chh ? a.Hp : 0;
+            qn[i] += a.dn + chh;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        bf16_t *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < P_CH; ++i) {
+            const int q = tid + i * 256;
+            if (q < BP * CPA) {
+                const int prow = q / CPA, ch = (q % CPA) * 8;
+                u32x4_t hi, lo;
+                raww_to_planes<T, PREC>(pr[i], a.p_act, hi, lo);
+                *reinterpret_cast<u32x4_t *>(base + prow * ROWA + ch) = hi;
+                if constexpr (PREC == 3) *reinterpret_cast<u32x4_t *>(base + TA + prow * ROWA + ch) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Q_CH; ++i) {
+            const int prow = (tid >> 4) + i * 16;
+            u32x4_t hi, lo;
+            raww_to_planes<T, PREC>(qr[i], a.q_act, hi, lo);
+            *reinterpret_cast<u32x4_t *>(base + NPL * TA + prow * ROWJ + qcol * 8) = hi;
+            if constexpr (PREC == 3) *reinterpret_cast<u32x4_t *>(base + NPL * TA + TJ + prow * ROWJ + qcol * 8) = lo;
+        }
+    };
+
+    f32x4_t acc[FA][FJ];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        const bf16_t *base = smem + cur * BUF;
+        const bf16_t *Ps = base, *Qs = base + NPL * TA;
+        bf16x8_t af[NPL][FA], bf[NPL][FJ];
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            af[0][i] = tr_fragment<ROWA>(Ps, wa * PA + i * 16, lane);
+            if constexpr (PREC == 3) af[1][i] = tr_fragment<ROWA>(Ps + TA, wa * PA + i * 16, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            bf[0][j] = tr_fragment<ROWJ>(Qs, wj * PJ + j * 16, lane);
+            if constexpr (PREC == 3) bf[1][j] = tr_fragment<ROWJ>(Qs + TJ, wj * PJ + j * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                if constexpr (PREC == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+            }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: slab[ks][ca][j]; lane: column j = .. + (lane & 15), rows ca = .. + (lane>>4)*4 + r
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int jj = tj * BJ + wj * PJ + j * 16 + fr;
+            if (jj >= a.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
+                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+            }
+        }
+}
+
+// grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
+                                                           int KK, float *grad, int accumulate) {
+    const int total = CA * CB * KK;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % KK;
+        const int b = (i / KK) % CB;
+        const int ca = i / (KK * CB);
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += slab[((size_t)k * CAp + ca) * J + t * CBp + b];
+        grad[i] = accumulate ? grad[i] + s : s;
+    }
+}
+
+template <typename T, int PREC, int BA, int WA, int WJ>
+static int launch_wgrad(WgradArgs a, hipStream_t stream) {
+    constexpr int NPL = (PREC == 3) ? 2 : 1;
+    constexpr size_t smem = (size_t)2 * NPL * 32 * ((BA + 16) + (128 + 16)) * sizeof(bf16_t);
+    a.tiles_a = (a.CAp + BA - 1) / BA;
+    a.tiles_j = (a.J + 127) / 128;
+    auto kern = wgrad_kernel<T, PREC, BA, WA, WJ>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk), dim3(256), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_wgrad");
+    return 0;
+}
+
+template <typename T, int PREC>
+static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
+    if (a.CAp <= 16) return launch_wgrad<T, PREC, 16, 1, 4>(a, stream);
+    if (a.CAp <= 64) return launch_wgrad<T, PREC, 64, 2, 2>(a, stream);
+    return launch_wgrad<T, PREC, 128, 2, 2>(a, stream);
+}
+
+extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !P || !Q || !grad || !slab) DL_FAIL("dl_conv_wgrad: null argument");
+    const int l2 = ilog2_exact(d->CBp);
+    if (l2 < 3) DL_FAIL("dl_conv_wgrad: CBp=%d must be a power of two >= 8", d->CBp);
+    if (d->CAp % 8) DL_FAIL("dl_conv_wgrad: CAp=%d must be a multiple of 8", d->CAp);
+    if (d->p_pstride % 8 || d->q_pstride % 8) DL_FAIL("dl_conv_wgrad: pixel strides must be multiples of 8");
+    if (d->splitk < 1) DL_FAIL("dl_conv_wgrad: splitk=%d", d->splitk);
+    if (d->prec == DL_PREC_BF16X3 && d->dtype != DL_F32) DL_FAIL("dl_conv_wgrad: BF16X3 needs fp32 activations");
+
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = P; a.Q = Q; a.slab = slab;
+    a.N = d->N; a.Hp = d->Hp; a.Wp = d->Wp; a.CAp = d->CAp; a.p_pstride = d->p_pstride;
+    a.Hq = d->Hq; a.Wq = d->Wq; a.CBp = d->CBp; a.log2CB = l2; a.q_pstride = d->q_pstride;
+    a.KH = d->KH; a.KW = d->KW; a.step = d->step; a.pad = d->pad; a.pad_mode = d->pad_mode;
+    a.J = d->KH * d->KW * d->CBp;
+    a.Ptot = d->N * d->Hp * d->Wp;
+    a.splitk = d->splitk;
+    a.pchunk = ((a.Ptot + d->splitk - 1) / d->splitk + 31) / 32 * 32;
+    const int hw = d->Hp * d->Wp;
+    a.dn = 32 / hw; a.dh = (32 % hw) / d->Wp; a.dw = (32 % hw) % d->Wp;
+    a.p_act = d->p_act; a.q_act = d->q_act;
+
+    int rc;
+    if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
+    else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
+    else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<float, 1>(a, stream);
+    else DL_FAIL("dl_conv_wgrad: unsupported dtype/precision combination");
+    if (rc) return rc;
+
+    const int KK = d->KH * d->KW;
+    const int total = d->CA * d->CB * KK;
+    const int blocks = min(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
+                       grad, d->accumulate);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");
+    return 0;
+}

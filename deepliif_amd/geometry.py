@@ -1,0 +1,188 @@
+"""Layer geometry: turns one Conv2d / ConvTranspose2d of the reference networks into the descriptors the HIP gather-GEMM,
+weight-pack and weight-gradient kernels consume (include/deepliif_hip.h).  Pure Python, no device work -- the formulas are
+unit-tested on CPU against torch's own convolutions (tests/test_geometry.py).
+
+Conventions (reference layouts, networks.py): Conv2d weight OIHW = src[A=out][B=in][kh][kw];
+ConvTranspose2d weight IOHW = src[A=in][B=out][kh][kw].
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+from . import _lib as L
+
+
+def cpad(c: int) -> int:
+    """Padded channel count of an engine tensor: the next power of two, at least 8."""
+    p = 8
+    while p < c:
+        p *= 2
+    return p
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class GatherPlan:
+    """One gather-GEMM problem family (forward or data-gradient of a layer), independent of N/H/W."""
+    n_phase: int
+    phase_off: List[Tuple[int, int]]            # (oh, ow) per phase
+    phase_taps: List[List[Tuple[int, int, int, int]]]   # per phase: (dh, dw, kh, kw)
+    out_step: int
+    in_step: int
+    pad_mode: int
+    row_is_a: bool                              # packed row = src dim A ?
+    rows_real: int                              # output channels (real)
+    cc_real: int                                # contracted channels (real)
+
+    # derived
+    rows_pad: int = 0
+    cc_pad: int = 0
+    kbase: List[int] = field(default_factory=list)
+    kstride: int = 0
+
+    def finish(self):
+        self.rows_pad = round_up(cpad(self.rows_real), 128)
+        self.cc_pad = cpad(self.cc_real)
+        self.kbase = []
+        k = 0
+        for taps in self.phase_taps:
+            self.kbase.append(k)
+            k += round_up(len(taps) * self.cc_pad, 64)
+        self.kstride = k
+        assert sum(len(t) for t in self.phase_taps) <= L.MAX_TAPS
+        return self
+
+    def taps_flat(self):
+        return [t for ph in self.phase_taps for t in ph]
+
+    def tap_begin(self):
+        b = [0]
+        for ph in self.phase_taps:
+            b.append(b[-1] + len(ph))
+        return b + [b[-1]] * (L.MAX_PHASES + 1 - len(b))
+
+
+@dataclass
+class ConvSpec:
+    """Static description of one convolution layer of the reference networks."""
+    kind: str          # 'conv' | 'convT'
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad: int
+    pad_mode: int = L.PAD_ZERO      # reflect = an explicit nn.ReflectionPad2d(pad) in front of a padding=0 Conv2d
+    out_pad: int = 0
+
+    def out_hw(self, h, w):
+        if self.kind == 'conv':
+            return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
+        return ((h - 1) * self.stride - 2 * self.pad + self.k + self.out_pad,
+                (w - 1) * self.stride - 2 * self.pad + self.k + self.out_pad)
+
+    # ---- forward: y = layer(x)
+    def forward_plan(self) -> GatherPlan:
+        k, p, s = self.k, self.pad, self.stride
+        if self.kind == 'conv':
+            taps = [(kh - p, kw - p, kh, kw) for kh in range(k) for kw in range(k)]
+            return GatherPlan(1, [(0, 0)], [taps], 1, s, self.pad_mode, True, self.cout, self.cin).finish()
+        assert s == 2, 'ConvTranspose2d on this path is always stride 2 (networks.py:426-430, 584-600)'
+        offs, phases = [], []
+        for ph in range(2):
+            for pw in range(2):
+                taps = [((ph + p - kh) // 2, (pw + p - kw) // 2, kh, kw)
+                        for kh in range(k) if (ph + p - kh) % 2 == 0
+                        for kw in range(k) if (pw + p - kw) % 2 == 0]
+                offs.append((ph, pw))
+                phases.append(taps)
+        return GatherPlan(4, offs, phases, 2, 1, L.PAD_ZERO, False, self.cout, self.cin).finish()
+
+    # ---- data gradient: dx = layer^T(dy)
+    def dgrad_plan(self) -> GatherPlan:
+        k, p, s = self.k, self.pad, self.stride
+        if self.kind == 'conv':
+            if self.pad_mode != L.PAD_ZERO:
+                raise NotImplementedError('backward through a reflection-padded conv (round 1: zero padding only; the '
+                                          'reference forces zero padding for deterministic training, cli.py:267-269)')
+            if s == 1:
+                taps = [(p - kh, p - kw, kh, kw) for kh in range(k) for kw in range(k)]
+                return GatherPlan(1, [(0, 0)], [taps], 1, 1, L.PAD_ZERO, False, self.cin, self.cout).finish()
+            assert s == 2
+            offs, phases = [], []
+            for ph in range(2):
+                for pw in range(2):
+                    taps = [((ph + p - kh) // 2, (pw + p - kw) // 2, kh, kw)
+                            for kh in range(k) if (ph + p - kh) % 2 == 0
+                            for kw in range(k) if (pw + p - kw) % 2 == 0]
+                    offs.append((ph, pw))
+                    phases.append(taps)
+            return GatherPlan(4, offs, phases, 2, 1, L.PAD_ZERO, False, self.cin, self.cout).finish()
+        # ConvTranspose2d: dx[ci][hi] = sum dy[co][hi*2 - p + kh] * Wt[ci][co][kh]  -> a stride-2 conv over dy
+        taps = [(kh - p, kw - p, kh, kw) for kh in range(k) for kw in range(k)]
+        return GatherPlan(1, [(0, 0)], [taps], 1, s, L.PAD_ZERO, True, self.cin, self.cout).finish()
+
+
+def fill_pack_desc(plan: GatherPlan, A: int, B: int, k: int) -> L.PackDesc:
+    d = L.PackDesc()
+    d.A, d.B, d.KH, d.KW = A, B, k, k
+    d.row_is_a = 1 if plan.row_is_a else 0
+    d.rows_real, d.rows_pad = plan.rows_real, plan.rows_pad
+    d.Cc, d.Cc_pad = plan.cc_real, plan.cc_pad
+    d.n_phase = plan.n_phase
+    for i, v in enumerate(plan.tap_begin()):
+        d.phase_tap_begin[i] = v
+    for i, v in enumerate(plan.kbase):
+        d.phase_kbase[i] = v
+    for i, (_, _, kh, kw) in enumerate(plan.taps_flat()):
+        d.tap_kh[i], d.tap_kw[i] = kh, kw
+    d.kstride = plan.kstride
+    return d
+
+
+def conv_tile(co_pad: int):
+    """(BM pixels, BN channels) the kernel dispatch picks (conv_gemm.hip dispatch_tile)."""
+    if co_pad <= 16:
+        return 256, 16
+    if co_pad <= 64:
+        return 128, 64
+    return 128, 128
+
+
+def choose_splitk(plan: GatherPlan, n: int, hq: int, wq: int, co_pad: int, target_blocks: int = 512, max_split: int = 32) -> int:
+    bm, bn = conv_tile(co_pad)
+    blocks = ((n * hq * wq + bm - 1) // bm) * ((co_pad + bn - 1) // bn) * plan.n_phase
+    if blocks >= 256:
+        return 1
+    nk64 = min(round_up(len(t) * plan.cc_pad, 64) // 64 for t in plan.phase_taps)
+    sk = min(max_split, nk64, (target_blocks + blocks - 1) // blocks)
+    return max(1, sk)
+
+
+def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, ho: int, wo: int, out_cp: int, out_pstride: int,
+                   hq: int, wq: int, dtype: int, prec: int, act: int, in_act: int, bias_n: int, splitk: int) -> L.ConvDesc:
+    d = L.ConvDesc()
+    d.N, d.Hi, d.Wi, d.Ci, d.in_pstride = n, hi, wi, plan.cc_pad, in_pstride
+    d.Ho, d.Wo, d.Co, d.out_pstride = ho, wo, out_cp, out_pstride
+    d.Hq, d.Wq, d.out_step, d.in_step, d.n_phase = hq, wq, plan.out_step, plan.in_step, plan.n_phase
+    for i, (oh, ow) in enumerate(plan.phase_off):
+        d.phase_oh[i], d.phase_ow[i] = oh, ow
+    for i, v in enumerate(plan.tap_begin()):
+        d.phase_tap_begin[i] = v
+    for i, v in enumerate(plan.kbase):
+        d.phase_kbase[i] = v
+    for i, (dh, dw, _, _) in enumerate(plan.taps_flat()):
+        d.tap_dh[i], d.tap_dw[i] = dh, dw
+    d.pad_mode, d.w_kstride, d.w_rows = plan.pad_mode, plan.kstride, plan.rows_pad
+    d.act, d.in_dtype, d.out_dtype, d.prec, d.splitk, d.in_act, d.bias_n = act, dtype, dtype, prec, splitk, in_act, bias_n
+    return d
+
+
+def choose_wgrad_splitk(cap: int, j: int, ptot: int, target_blocks: int = 1024, max_split: int = 256) -> int:
+    ba = 16 if cap <= 16 else (64 if cap <= 64 else 128)
+    tiles = ((cap + ba - 1) // ba) * ((j + 127) // 128)
+    sk = min(max_split, (target_blocks + tiles - 1) // tiles, max(1, ptot // 64))
+    return max(1, sk)

