@@ -1,0 +1,347 @@
+"""Execution engine: NHWC activations, a reverse-mode tape and the differentiable building blocks of the three reference
+networks.  This replaces torch.autograd + ATen for the hot path: every forward/backward node below launches the
+hand-written gfx950 kernels through deepliif_amd.ops (C ABI), on torch's current HIP stream.
+
+Precision policies:
+  'bf16' : activations bf16, one bf16 MFMA pass, fp32 accumulate / statistics / losses / master weights  (throughput mode)
+  'fp32' : activations fp32, split-bf16 x3 MFMA (fp32-class accuracy)                                   (strict parity mode)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .geometry import ConvSpec, cpad
+
+
+@dataclass(frozen=True)
+class Precision:
+    name: str
+    dtype: torch.dtype
+    prec: int
+
+    @staticmethod
+    def get(name: str) -> 'Precision':
+        if name in ('bf16', 'bfloat16'):
+            return Precision('bf16', torch.bfloat16, L.PREC_BF16)
+        if name in ('fp32', 'float32'):
+            return Precision('fp32', torch.float32, L.PREC_BF16X3)
+        if name == 'fp32_bf16mma':
+            return Precision('fp32_bf16mma', torch.float32, L.PREC_BF16)
+        raise ValueError(f'unknown precision {name!r} (bf16 | fp32 | fp32_bf16mma)')
+
+
+class Act:
+    """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
+    __slots__ = ('t', 'C', 'grad', 'needs_grad')
+
+    def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
+        self.t = t
+        self.C = C
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def detach(self) -> 'Act':
+        return Act(self.t, self.C, False)
+
+    def add_grad(self, g: torch.Tensor):
+        """accumulate a gradient contribution (first one is adopted, later ones are added with the axpby kernel)"""
+        if self.grad is None:
+            self.grad = g
+        else:
+            ops.impl().axpby(1.0, self.grad, 1.0, g, self.grad)
+
+
+class Tape:
+    """Reverse-mode tape: forward ops append closures, backward() runs them last-to-first."""
+
+    def __init__(self):
+        self.nodes: List[Callable[[], None]] = []
+
+    def record(self, fn: Callable[[], None]):
+        self.nodes.append(fn)
+
+    def backward(self):
+        nodes, self.nodes = self.nodes, []
+        for fn in reversed(nodes):
+            fn()
+
+
+def new_act(n, h, w, c, prec: Precision, device, zero=False) -> Act:
+    cp = cpad(c)
+    t = (torch.zeros if zero else torch.empty)((n, h, w, cp), dtype=prec.dtype, device=device)
+    return Act(t, c)
+
+
+def empty_like_act(a: torch.Tensor) -> torch.Tensor:
+    return torch.empty(a.shape, dtype=a.dtype, device=a.device)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layers (parameter holders are the nn.Modules in networks.py; these classes own geometry + packed weight images)
+# ---------------------------------------------------------------------------------------------------------------
+class ConvLayer:
+    """One Conv2d / ConvTranspose2d of the reference networks bound to its nn.Parameter(s)."""
+
+    def __init__(self, spec: ConvSpec, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter]):
+        self.spec = spec
+        self.weight = weight
+        self.bias = bias
+        self.fwd_plan = spec.forward_plan()
+        self._dgrad_plan = None
+        self.packed_fwd: Optional[ops.PackedWeights] = None
+        self.packed_dgrad: Optional[ops.PackedWeights] = None
+        self.fwd_key = None
+        self.dgrad_key = None
+
+    @property
+    def dgrad_plan(self):
+        if self._dgrad_plan is None:
+            self._dgrad_plan = self.spec.dgrad_plan()
+        return self._dgrad_plan
+
+    def ensure_packed(self, prec: Precision, need_dgrad: bool):
+        """(Re)build the bf16 GEMM images when the fp32 master weights changed: torch-side in-place updates bump
+        `_version`; the fused Adam kernel writes through raw pointers and bumps `_dl_epoch` instead (optim.py)."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device))
+        with_lo = prec.prec == L.PREC_BF16X3
+        be = ops.impl()
+        if self.fwd_key != key:
+            if self.packed_fwd is None or self.packed_fwd.hi.device != w.device or (with_lo and self.packed_fwd.lo is None):
+                self.packed_fwd = ops.PackedWeights(self.fwd_plan, w.device, with_lo)
+            be.pack_weights(self.packed_fwd, w.detach())
+            self.fwd_key = key
+        if need_dgrad and self.dgrad_key != key:
+            if self.packed_dgrad is None or self.packed_dgrad.hi.device != w.device or (with_lo and self.packed_dgrad.lo is None):
+                self.packed_dgrad = ops.PackedWeights(self.dgrad_plan, w.device, with_lo)
+            be.pack_weights(self.packed_dgrad, w.detach())
+            self.dgrad_key = key
+
+
+class NormLayer:
+    """BatchNorm2d-on-batch-statistics (affine, optional running-stat tracking) or InstanceNorm2d (no affine)."""
+
+    def __init__(self, kind: str, C: int, module: Optional[torch.nn.Module]):
+        self.kind = kind
+        self.C = C
+        self.module = module        # nn.BatchNorm2d holding weight/bias/running_* (None for instance norm)
+
+    @property
+    def scope(self):
+        return L.NORM_BATCH if self.kind == 'batch' else L.NORM_INSTANCE
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# differentiable ops
+# ---------------------------------------------------------------------------------------------------------------
+class Ctx:
+    """Per-call execution context."""
+
+    def __init__(self, prec: Precision, tape: Optional[Tape], training: bool, per_sample_norm: bool = False):
+        self.prec = prec
+        self.tape = tape
+        self.training = training            # BatchNorm running-stat updates (module.training and tracking enabled)
+        # batched inference must normalise per sample to reproduce the reference's one-tile-per-forward outputs
+        # (SURVEY 0 #5): BatchNorm on batch statistics with N=1 == InstanceNorm + affine
+        self.per_sample_norm = per_sample_norm
+
+
+def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None) -> Act:
+    """y = act(conv(in_act(x)) + bias).  `out` may be a channel-slice view of a concat buffer."""
+    be = ops.impl()
+    spec = layer.spec
+    n, hi, wi, _ = x.t.shape
+    ho, wo = spec.out_hw(hi, wi)
+    w_needs = layer.weight.requires_grad and ctx.tape is not None
+    x_needs = x.needs_grad and ctx.tape is not None
+    layer.ensure_packed(ctx.prec, need_dgrad=x_needs)
+    if out is None:
+        out = torch.empty((n, ho, wo, cpad(spec.cout)), dtype=ctx.prec.dtype, device=x.t.device)
+    hq, wq = (ho, wo) if spec.kind == 'conv' else (hi, wi)
+    if spec.kind == 'convT':
+        assert (ho, wo) == (2 * hi, 2 * wi)
+    be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act, ctx.prec.prec)
+    y = Act(out, spec.cout, x_needs or w_needs)
+    if not (x_needs or w_needs):
+        return y
+
+    def backward():
+        g = y.grad
+        y.grad = None
+        if g is None:
+            return
+        if act != L.ACT_NONE:                       # epilogue activation: derivative from the saved output
+            gp = empty_like_act(g)
+            be.act_backward(act, g, y.t, gp)
+            g = gp
+        if w_needs:
+            if spec.kind == 'conv':
+                be.conv_wgrad(g, x.t, layer.weight.grad, spec.k, spec.stride, spec.pad, spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True)
+            else:
+                be.conv_wgrad(x.t, g, layer.weight.grad, spec.k, spec.stride, spec.pad, L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True)
+            if layer.bias is not None and layer.bias.requires_grad:
+                be.channel_sum(g, spec.cout, layer.bias.grad, True)
+        if x_needs:
+            dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
+            if spec.kind == 'conv' and spec.stride == 2:
+                assert (hi, wi) == (2 * ho, 2 * wo), 'stride-2 data-gradient assumes even input sizes'
+                dq = (ho, wo)
+            else:
+                dq = (hi, wi)
+            be.conv_forward(layer.packed_dgrad, g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec)
+            if in_act != L.ACT_NONE:                # relu / lrelu keep the sign: mask from the un-activated input
+                be.act_backward(in_act, dx, x.t, dx)
+            x.add_grad(dx)
+
+    ctx.tape.record(backward)
+    return y
+
+
+def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE, residual: Optional[Act] = None,
+             out: Optional[torch.Tensor] = None) -> Act:
+    """z = act(norm(y)) (+ residual).  norm None = identity norm (norm='none')."""
+    be = ops.impl()
+    if out is None:
+        out = empty_like_act(y.t)
+    needs = ctx.tape is not None and (y.needs_grad or (residual is not None and residual.needs_grad))
+    if norm is None:
+        be.act_forward(act, y.t, out)
+        if residual is not None:
+            be.axpby(1.0, out, 1.0, residual.t, out)
+        z = Act(out, y.C, needs)
+        if needs:
+            def backward_plain():
+                g = z.grad
+                z.grad = None
+                if g is None:
+                    return
+                if residual is not None and residual.needs_grad:
+                    residual.add_grad(g)
+                if y.needs_grad:
+                    dy = empty_like_act(g)
+                    # out = act(y) + res : act' from act(y) = out - res is not available; recompute from y's sign (relu family)
+                    be.act_backward(act, g, y.t if act in (L.ACT_RELU, L.ACT_LRELU) else out, dy)
+                    y.add_grad(dy)
+            ctx.tape.record(backward_plain)
+        return z
+
+    m = norm.module
+    gamma = m.weight.detach() if m is not None else None
+    beta = m.bias.detach() if m is not None else None
+    scope = L.NORM_INSTANCE if ctx.per_sample_norm else norm.scope
+    rm = rv = None
+    momentum = -1.0
+    if m is not None and ctx.training and m.training and m.track_running_stats and m.running_mean is not None and scope == L.NORM_BATCH:
+        rm, rv, momentum = m.running_mean, m.running_var, (m.momentum if m.momentum is not None else 0.1)
+        m.num_batches_tracked += 1
+    stats = be.norm_forward(y.t, out, norm.C, scope, act, gamma, beta, rm, rv, momentum, residual.t if residual is not None else None)
+    z = Act(out, y.C, needs)
+    if not needs:
+        return z
+
+    def backward():
+        g = z.grad
+        z.grad = None
+        if g is None:
+            return
+        if residual is not None and residual.needs_grad:
+            residual.add_grad(g)
+        affine = m is not None and m.weight.requires_grad
+        if y.needs_grad or affine:
+            dy = empty_like_act(g)
+            be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None)
+            if y.needs_grad:
+                y.add_grad(dy)
+
+    ctx.tape.record(backward)
+    return z
+
+
+def concat_channels(ctx: Ctx, parts: List[Act]) -> Act:
+    """torch.cat(parts, 1) for small channel counts (D inputs: cat(cond, image), DeepLIIF_model.py:223)."""
+    be = ops.impl()
+    ctot = sum(p.C for p in parts)
+    n, h, w, _ = parts[0].t.shape
+    out = torch.zeros((n, h, w, cpad(ctot)), dtype=parts[0].t.dtype, device=parts[0].t.device)
+    c0 = 0
+    for p in parts:
+        be.copy_channels(p.t, 0, out, c0, p.C)
+        c0 += p.C
+    needs = ctx.tape is not None and any(p.needs_grad for p in parts)
+    z = Act(out, ctot, needs)
+    if needs:
+        def backward():
+            g = z.grad
+            z.grad = None
+            if g is None:
+                return
+            c = 0
+            for p in parts:
+                if p.needs_grad:
+                    gp = torch.zeros(p.t.shape, dtype=g.dtype, device=g.device)
+                    be.copy_channels(g, c, gp, 0, p.C)
+                    p.add_grad(gp)
+                c += p.C
+        ctx.tape.record(backward)
+    return z
+
+
+def weighted_sum(ctx: Ctx, parts: List[Act], weights: List[float]) -> Act:
+    """stack([w_i * x_i]).sum(0)  (DeepLIIF_model.py:203, 258-262)."""
+    be = ops.impl()
+    out = empty_like_act(parts[0].t)
+    be.axpby(weights[0], parts[0].t, 0.0, None, out)
+    for p, w in zip(parts[1:], weights[1:]):
+        be.axpby(1.0, out, w, p.t, out)
+    needs = ctx.tape is not None and any(p.needs_grad for p in parts)
+    z = Act(out, parts[0].C, needs)
+    if needs:
+        def backward():
+            g = z.grad
+            z.grad = None
+            if g is None:
+                return
+            for p, w in zip(parts, weights):
+                if p.needs_grad:
+                    gp = empty_like_act(g)
+                    be.axpby(w, g, 0.0, None, gp)
+                    p.add_grad(gp)
+        ctx.tape.record(backward)
+    return z
+
+
+def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: float, weight: float, loss_out: torch.Tensor) -> None:
+    """loss_out[0] = mean loss (unweighted, as the reference logs it); if x needs grad, d(weight*loss)/dx is queued."""
+    be = ops.impl()
+    needs = ctx.tape is not None and x.needs_grad
+    grad = empty_like_act(x.t) if needs else None
+    be.loss(kind, x.t, target.t if target is not None else None, target_const, x.C, loss_out, grad, weight)
+    if needs:
+        def backward():
+            x.add_grad(grad)
+        ctx.tape.record(backward)
+
+
+def to_engine(x_nchw: torch.Tensor, prec: Precision) -> Act:
+    """NCHW fp32 (the reference's tensors) -> engine NHWC with padded channels."""
+    x = x_nchw.detach().contiguous().float()
+    n, c, h, w = x.shape
+    a = new_act(n, h, w, c, prec, x.device)
+    ops.impl().nchw_to_nhwc(x, a.t, 0, a.t.shape[3])
+    return a
+
+
+def from_engine(a: Act) -> torch.Tensor:
+    n, h, w, _ = a.t.shape
+    out = torch.empty((n, a.C, h, w), dtype=torch.float32, device=a.t.device)
+    ops.impl().nhwc_to_nchw(a.t, 0, out)
+    return out

@@ -1,0 +1,509 @@
+"""Drop-in counterparts of deepliif/models/networks.py for the hot path: same constructor signatures, same module tree
+(so state_dict keys, init_weights RNG order and the BatchNorm toggles of deepliif/util/__init__.py:743-770 keep working),
+but `forward` runs the MI355X engine (deepliif_amd.engine -> HIP kernels) instead of ATen.
+
+The torch.nn leaf modules (Conv2d, ConvTranspose2d, BatchNorm2d, ...) are used as *parameter containers* only -- their own
+forward is never called.  Reference citations: networks.py:25-44 get_norm_layer, :84-139 init_weights/init_net,
+:142-238 define_G/define_D, :244-317 GANLoss, :357-513 ResnetGenerator, :516-615 UnetGenerator, :618-664 NLayerDiscriminator.
+"""
+from __future__ import annotations
+
+import functools
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+from torch.optim import lr_scheduler
+
+from . import _lib as L
+from . import engine as E
+from .geometry import ConvSpec
+
+DEFAULT_PRECISION = os.environ.get('DEEPLIIF_AMD_PRECISION', 'bf16')
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def get_norm_layer(norm_type='instance'):
+    """networks.py:25-44.  'batch': BatchNorm2d(affine, tracked);  'instance': InstanceNorm2d(no affine, untracked)."""
+    if norm_type == 'batch':
+        return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
+    if norm_type == 'instance':
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    if norm_type == 'none':
+        return lambda c: Identity()
+    raise NotImplementedError('normalization layer [%s] is not supported by the MI355X engine' % norm_type)
+
+
+def _norm_kind(norm_layer) -> str:
+    f = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+    if f is nn.BatchNorm2d:
+        return 'batch'
+    if f is nn.InstanceNorm2d:
+        return 'instance'
+    return 'none'
+
+
+def _uses_bias(norm_layer) -> bool:
+    # conv bias only when the following norm has no affine shift (networks.py:381-384,570-573,631-634)
+    return _norm_kind(norm_layer) == 'instance'
+
+
+# -------------------------------------------------------------------------------------------------------------
+# engine-backed module base
+# -------------------------------------------------------------------------------------------------------------
+class EngineNet(nn.Module):
+    """Common machinery: precision policy, lazily-built layer bindings, NCHW<->engine conversion at the seam."""
+
+    def __init__(self):
+        super().__init__()
+        self.precision = DEFAULT_PRECISION
+        self.batched_per_sample_norm = True     # N>1 inference reproduces N one-tile forwards
+        self._bound = None
+
+    def set_precision(self, name: str):
+        self.precision = name
+        return self
+
+    def _layers(self):
+        if self._bound is None:
+            self._bound = self._bind()
+        return self._bound
+
+    def _bind(self):
+        raise NotImplementedError
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        raise NotImplementedError
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Inference seam: NCHW fp32 in, NCHW fp32 out (deepliif/models/__init__.py:285-291 calls net(tensor))."""
+        prec = E.Precision.get(self.precision)
+        ctx = E.Ctx(prec, None, training=False, per_sample_norm=self.batched_per_sample_norm)
+        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+
+
+def _norm_binding(kind: str, C: int, module: nn.Module) -> Optional[E.NormLayer]:
+    if kind == 'none':
+        return None
+    return E.NormLayer(kind, C, module if kind == 'batch' else None)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# ResnetGenerator
+# -------------------------------------------------------------------------------------------------------------
+class ResnetBlock(nn.Module):
+    """Parameter container with the reference's conv_block indices (networks.py:467-508)."""
+
+    def __init__(self, dim, padding_type, norm_layer, use_dropout, use_bias, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise NotImplementedError('spectral norm is not on the MI355X hot path')
+        if padding_type not in ('zero', 'reflect'):
+            raise NotImplementedError('padding [%s] is not supported by the MI355X engine' % padding_type)
+        seq: List[nn.Module] = []
+        self.idx = {}
+        for half in (0, 1):
+            if padding_type == 'reflect':
+                seq.append(nn.ReflectionPad2d(1))
+            self.idx[f'conv{half}'] = len(seq)
+            seq.append(nn.Conv2d(dim, dim, kernel_size=3, padding=1 if padding_type == 'zero' else 0, bias=use_bias))
+            self.idx[f'norm{half}'] = len(seq)
+            seq.append(norm_layer(dim))
+            if half == 0:
+                seq.append(nn.ReLU(True))
+                if use_dropout:
+                    seq.append(nn.Dropout(0.5))
+        self.conv_block = nn.Sequential(*seq)
+        self.use_dropout = use_dropout
+
+
+class ResnetGenerator(EngineNet):
+    def __init__(self, input_nc, output_nc, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False, n_blocks=6, padding_type='zero',
+                 upsample='convtranspose', use_spectral_norm=False):
+        assert n_blocks >= 0
+        super().__init__()
+        if upsample != 'convtranspose' or use_spectral_norm:
+            raise NotImplementedError('only upsample=convtranspose without spectral norm is on the MI355X hot path')
+        self.norm_kind = _norm_kind(norm_layer)
+        self.padding_type = padding_type
+        self.n_blocks = n_blocks
+        self.ngf, self.input_nc, self.output_nc = ngf, input_nc, output_nc
+        use_bias = _uses_bias(norm_layer)
+        pad3 = nn.ReflectionPad2d(3) if padding_type == 'reflect' else nn.ZeroPad2d(3)
+        seq: List[nn.Module] = [pad3, nn.Conv2d(input_nc, ngf, kernel_size=7, padding=0, bias=use_bias), norm_layer(ngf), nn.ReLU(True)]
+        for i in range(2):
+            m = 2 ** i
+            seq += [nn.Conv2d(ngf * m, ngf * m * 2, kernel_size=3, stride=2, padding=1, bias=use_bias), norm_layer(ngf * m * 2), nn.ReLU(True)]
+        for _ in range(n_blocks):
+            seq.append(ResnetBlock(ngf * 4, padding_type, norm_layer, use_dropout, use_bias))
+        for i in range(2):
+            m = 2 ** (2 - i)
+            seq += [nn.ConvTranspose2d(ngf * m, ngf * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1, bias=use_bias),
+                    norm_layer(ngf * m // 2), nn.ReLU(True)]
+        seq.append(nn.ReflectionPad2d(3) if padding_type == 'reflect' else nn.ZeroPad2d(3))
+        seq.append(nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0))
+        seq.append(nn.Tanh())
+        self.model = nn.Sequential(*seq)
+
+    def _bind(self):
+        ngf, k = self.ngf, self.norm_kind
+        pm = L.PAD_REFLECT if self.padding_type == 'reflect' else L.PAD_ZERO
+        m = self.model
+        b = {}
+        b['stem'] = (E.ConvLayer(ConvSpec('conv', self.input_nc, ngf, 7, 1, 3, pm), m[1].weight, m[1].bias), _norm_binding(k, ngf, m[2]))
+        b['down'] = []
+        idx = 4
+        for i in range(2):
+            c = ngf * 2 ** i
+            b['down'].append((E.ConvLayer(ConvSpec('conv', c, 2 * c, 3, 2, 1), m[idx].weight, m[idx].bias), _norm_binding(k, 2 * c, m[idx + 1])))
+            idx += 3
+        b['blocks'] = []
+        for _ in range(self.n_blocks):
+            blk = m[idx]
+            cb = blk.conv_block
+            ent = []
+            for half in (0, 1):
+                cm, nm = cb[blk.idx[f'conv{half}']], cb[blk.idx[f'norm{half}']]
+                ent.append((E.ConvLayer(ConvSpec('conv', ngf * 4, ngf * 4, 3, 1, 1, pm), cm.weight, cm.bias), _norm_binding(k, ngf * 4, nm)))
+            b['blocks'].append((ent, blk))
+            idx += 1
+        b['up'] = []
+        for i in range(2):
+            c = ngf * 2 ** (2 - i)
+            b['up'].append((E.ConvLayer(ConvSpec('convT', c, c // 2, 3, 2, 1, out_pad=1), m[idx].weight, m[idx].bias),
+                            _norm_binding(k, c // 2, m[idx + 1])))
+            idx += 3
+        idx += 1
+        b['head'] = E.ConvLayer(ConvSpec('conv', ngf, self.output_nc, 7, 1, 3, pm), m[idx].weight, m[idx].bias)
+        return b
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        b = self._layers()
+        c, n = b['stem']
+        h = E.norm_act(ctx, E.conv(ctx, x, c), n, L.ACT_RELU)
+        for c, n in b['down']:
+            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
+        for ent, blk in b['blocks']:
+            if blk.use_dropout and blk.training and ctx.tape is not None:
+                raise NotImplementedError('dropout inside the training graph is not implemented yet (use no_dropout=True); '
+                                          'all parity vectors are dropout-free (SURVEY 0)')
+            (c1, n1), (c2, n2) = ent
+            r = E.norm_act(ctx, E.conv(ctx, h, c1), n1, L.ACT_RELU)
+            h = E.norm_act(ctx, E.conv(ctx, r, c2), n2, L.ACT_NONE, residual=h)
+        for c, n in b['up']:
+            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
+        return E.conv(ctx, h, b['head'], act=L.ACT_TANH)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# UnetGenerator
+# -------------------------------------------------------------------------------------------------------------
+class UnetSkipConnectionBlock(nn.Module):
+    """Parameter container reproducing the reference's nested Sequential layout (networks.py:583-609)."""
+
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False, norm_layer=nn.BatchNorm2d,
+                 use_dropout=False):
+        super().__init__()
+        self.outermost, self.innermost = outermost, innermost
+        use_bias = _uses_bias(norm_layer)
+        if input_nc is None:
+            input_nc = outer_nc
+        self.outer_nc, self.inner_nc, self.input_nc = outer_nc, inner_nc, input_nc
+        downconv = nn.Conv2d(input_nc, inner_nc, kernel_size=4, stride=2, padding=1, bias=use_bias)
+        downrelu = nn.LeakyReLU(0.2, True)
+        downnorm = norm_layer(inner_nc)
+        uprelu = nn.ReLU(True)
+        upnorm = norm_layer(outer_nc)
+        self.use_dropout = False
+        if outermost:
+            upconv = nn.ConvTranspose2d(inner_nc * 2, outer_nc, kernel_size=4, stride=2, padding=1)
+            seq = [downconv, submodule, uprelu, upconv, nn.Tanh()]
+            self.pos = dict(down=0, sub=1, up=3)
+        elif innermost:
+            upconv = nn.ConvTranspose2d(inner_nc, outer_nc, kernel_size=4, stride=2, padding=1, bias=use_bias)
+            seq = [downrelu, downconv, uprelu, upconv, upnorm]
+            self.pos = dict(down=1, up=3, upnorm=4)
+        else:
+            upconv = nn.ConvTranspose2d(inner_nc * 2, outer_nc, kernel_size=4, stride=2, padding=1, bias=use_bias)
+            seq = [downrelu, downconv, downnorm, submodule, uprelu, upconv, upnorm]
+            self.pos = dict(down=1, downnorm=2, sub=3, up=5, upnorm=6)
+            if use_dropout:
+                seq.append(nn.Dropout(0.5))
+                self.use_dropout = True
+        self.model = nn.Sequential(*seq)
+
+
+class UnetGenerator(EngineNet):
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False):
+        super().__init__()
+        self.norm_kind = _norm_kind(norm_layer)
+        self.num_downs = num_downs
+        blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=None, norm_layer=norm_layer, innermost=True)
+        for _ in range(num_downs - 5):
+            blk = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=blk, norm_layer=norm_layer, use_dropout=use_dropout)
+        blk = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=blk, norm_layer=norm_layer)
+        blk = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=blk, norm_layer=norm_layer)
+        blk = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=blk, norm_layer=norm_layer)
+        self.model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=blk, outermost=True, norm_layer=norm_layer)
+
+    def _bind(self):
+        k = self.norm_kind
+        chain = []
+        blk = self.model
+        while blk is not None:
+            chain.append(blk)
+            blk = None if blk.innermost else blk.model[blk.pos['sub']]
+        levels = []
+        for blk in chain:
+            dm, um = blk.model[blk.pos['down']], blk.model[blk.pos['up']]
+            down = E.ConvLayer(ConvSpec('conv', blk.input_nc, blk.inner_nc, 4, 2, 1), dm.weight, dm.bias)
+            up_in = blk.inner_nc if blk.innermost else blk.inner_nc * 2
+            up = E.ConvLayer(ConvSpec('convT', up_in, blk.outer_nc, 4, 2, 1), um.weight, um.bias)
+            dn = _norm_binding(k, blk.inner_nc, blk.model[blk.pos['downnorm']]) if 'downnorm' in blk.pos else None
+            un = _norm_binding(k, blk.outer_nc, blk.model[blk.pos['upnorm']]) if 'upnorm' in blk.pos else None
+            levels.append(dict(block=blk, down=down, up=up, downnorm=dn, upnorm=un, has_downnorm='downnorm' in blk.pos,
+                               has_upnorm='upnorm' in blk.pos))
+        return levels
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        """networks.py:611-615.  The in-place LeakyReLU makes every skip carry lrelu(h); the up-path ReLU then
+        sees relu(lrelu(h)) = relu(h), so the concat buffer stores the raw pre-activations [h_d | u_d] and the consumers
+        apply the activation while staging (in_act), with no standalone activation pass."""
+        lv = self._layers()
+        D = len(lv)
+        dev, dt = x.t.device, ctx.prec.dtype
+        n = x.t.shape[0]
+        for l in lv:
+            if l['block'].use_dropout and l['block'].training and ctx.tape is not None:
+                raise NotImplementedError('dropout inside the training graph is not implemented yet (use no_dropout=True)')
+        # ---- down path.  cat[d] (d = 1..D-1) = [h_d | u_d] at the resolution of block d's input
+        cats: List[Optional[torch.Tensor]] = [None] * D
+        firsts: List[Optional[E.Act]] = [None] * D
+        h = x
+        for d in range(D):
+            l = lv[d]
+            hi, wi = h.t.shape[1], h.t.shape[2]
+            ho, wo = hi // 2, wi // 2
+            cin_act = L.ACT_NONE if d == 0 else L.ACT_LRELU
+            cin = l['down'].spec.cout
+            if d < D - 1:
+                # output of this down step is the input (pre-activation) of block d+1 -> first half of cat[d+1]
+                cpad_c = E.cpad(cin)
+                assert cpad_c == cin, 'UNet feature widths must be powers of two >= 8 for zero-copy concat'
+                buf = torch.empty((n, ho, wo, 2 * cin), dtype=dt, device=dev)
+                first = buf[..., :cin]
+                if l['has_downnorm'] and l['downnorm'] is not None:
+                    y = E.conv(ctx, h, l['down'], in_act=cin_act)
+                    hn = E.norm_act(ctx, y, l['downnorm'], L.ACT_NONE, out=first)
+                else:
+                    hn = E.conv(ctx, h, l['down'], in_act=cin_act, out=first)
+                cats[d + 1], firsts[d + 1] = buf, hn
+                h = hn
+            else:
+                h = E.conv(ctx, h, l['down'], in_act=cin_act)      # innermost: no down-norm
+        # ---- up path
+        u_in = h                                   # innermost down-conv output; consumers apply ReLU while staging
+        for d in range(D - 1, 0, -1):
+            l = lv[d]
+            cat = cats[d]
+            cout = l['up'].spec.cout
+            second = cat[..., cout:]
+            y = E.conv(ctx, u_in, l['up'], in_act=L.ACT_RELU)
+            if l['upnorm'] is not None:
+                u = E.norm_act(ctx, y, l['upnorm'], L.ACT_NONE, out=second)
+            else:
+                u = E.norm_act(ctx, y, None, L.ACT_NONE, out=second)
+            u_in = _JoinedAct(cat, 2 * cout, firsts[d], u, ctx)
+        return E.conv(ctx, u_in, lv[0]['up'], act=L.ACT_TANH, in_act=L.ACT_RELU)
+
+
+class _JoinedAct(E.Act):
+    """A concat buffer whose halves were written in place by their producers; routes the gradient back to both."""
+    __slots__ = ('first', 'second')
+
+    def __init__(self, t, C, first: E.Act, second: E.Act, ctx: E.Ctx):
+        super().__init__(t, C, ctx.tape is not None and (first.needs_grad or second.needs_grad))
+        self.first, self.second = first, second
+
+    def add_grad(self, g: torch.Tensor):
+        c = self.first.t.shape[3]
+        if self.first.needs_grad:
+            self.first.add_grad(g[..., :c])
+        if self.second.needs_grad:
+            self.second.add_grad(g[..., c:])
+
+
+# -------------------------------------------------------------------------------------------------------------
+# NLayerDiscriminator
+# -------------------------------------------------------------------------------------------------------------
+class NLayerDiscriminator(EngineNet):
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_spectral_norm=False):
+        super().__init__()
+        if use_spectral_norm:
+            raise NotImplementedError('spectral norm is not on the MI355X hot path')
+        self.norm_kind = _norm_kind(norm_layer)
+        use_bias = _uses_bias(norm_layer)
+        self.input_nc, self.ndf, self.n_layers = input_nc, ndf, n_layers
+        seq: List[nn.Module] = [nn.Conv2d(input_nc, ndf, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(0.2, True)]
+        prev = 1
+        self._chan = []
+        for n in range(1, n_layers + 1):
+            mult = min(2 ** n, 8)
+            stride = 2 if n < n_layers else 1
+            seq += [nn.Conv2d(ndf * prev, ndf * mult, kernel_size=4, stride=stride, padding=1, bias=use_bias), norm_layer(ndf * mult),
+                    nn.LeakyReLU(0.2, True)]
+            self._chan.append((ndf * prev, ndf * mult, stride))
+            prev = mult
+        seq.append(nn.Conv2d(ndf * prev, 1, kernel_size=4, stride=1, padding=1))
+        self._last_in = ndf * prev
+        self.model = nn.Sequential(*seq)
+
+    def _bind(self):
+        m, k = self.model, self.norm_kind
+        b = {'first': E.ConvLayer(ConvSpec('conv', self.input_nc, self.ndf, 4, 2, 1), m[0].weight, m[0].bias), 'mid': []}
+        idx = 2
+        for cin, cout, stride in self._chan:
+            b['mid'].append((E.ConvLayer(ConvSpec('conv', cin, cout, 4, stride, 1), m[idx].weight, m[idx].bias), _norm_binding(k, cout, m[idx + 1])))
+            idx += 3
+        b['last'] = E.ConvLayer(ConvSpec('conv', self._last_in, 1, 4, 1, 1), m[idx].weight, m[idx].bias)
+        return b
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        b = self._layers()
+        h = E.conv(ctx, x, b['first'], act=L.ACT_LRELU)
+        for c, n in b['mid']:
+            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_LRELU)
+        return E.conv(ctx, h, b['last'])
+
+    def forward(self, x):
+        prec = E.Precision.get(self.precision)
+        ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
+        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+
+
+# -------------------------------------------------------------------------------------------------------------
+# factories / init  (networks.py:84-238)
+# -------------------------------------------------------------------------------------------------------------
+def init_weights(net, init_type='normal', init_gain=0.02):
+    def init_func(m):
+        classname = m.__class__.__name__
+        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
+            if init_type == 'normal':
+                init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+            if hasattr(m, 'bias') and m.bias is not None:
+                init.constant_(m.bias.data, 0.0)
+        elif classname.find('BatchNorm2d') != -1:
+            init.normal_(m.weight.data, 1.0, init_gain)
+            init.constant_(m.bias.data, 0.0)
+    net.apply(init_func)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """networks.py:118-139.  One process per GPU: the net goes to gpu_ids[0]; there is no DataParallel / DDP wrapper
+    (gradient exchange is done on flat buffers by deepliif_amd.distributed, not by per-module reducers)."""
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(torch.device('cuda', gpu_ids[0]))
+    init_weights(net, init_type, init_gain=init_gain)
+    return net
+
+
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[],
+             padding_type='reflect', upsample='convtranspose'):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if netG.startswith('resnet_'):
+        n_blocks = int(netG.split('_')[1].replace('blocks', ''))
+        net = ResnetGenerator(input_nc, output_nc, ngf, norm_layer=norm_layer, use_dropout=use_dropout, n_blocks=n_blocks,
+                              padding_type=padding_type, upsample=upsample)
+    elif netG in ('unet_32', 'unet_64', 'unet_128', 'unet_256', 'unet_512'):
+        downs = {'unet_32': 5, 'unet_64': 6, 'unet_128': 7, 'unet_256': 8, 'unet_512': 9}[netG]
+        net = UnetGenerator(input_nc, output_nc, downs, ngf, norm_layer=norm_layer, use_dropout=use_dropout)
+    else:
+        raise NotImplementedError('Generator model name [%s] is not on the MI355X hot path' % netG)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[]):
+    norm_layer = get_norm_layer(norm_type=norm)
+    if netD == 'basic':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)
+    elif netD == 'n_layers':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not on the MI355X hot path' % netD)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# losses / optimiser / schedule
+# -------------------------------------------------------------------------------------------------------------
+class GANLoss(nn.Module):
+    """networks.py:244-317, modes 'vanilla' (BCE-with-logits) and 'lsgan' (MSE) against a constant target.
+    On engine activations use `.kind` / `.target(...)` with engine.loss_op; calling it on a plain tensor returns the loss
+    computed by the HIP loss kernel as a 0-dim device tensor (no gradient graph)."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, label_smoothing=0.0):
+        super().__init__()
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self.gan_mode = gan_mode
+        self.label_smoothing = label_smoothing
+        if gan_mode == 'lsgan':
+            self.kind = L.LOSS_MSE
+        elif gan_mode == 'vanilla':
+            self.kind = L.LOSS_BCE_LOGITS
+        else:
+            raise NotImplementedError('gan mode %s is not on the MI355X hot path' % gan_mode)
+
+    def target(self, target_is_real: bool) -> float:
+        if target_is_real:
+            return float(self.real_label) * (1 - self.label_smoothing)
+        return float(self.fake_label) * self.label_smoothing
+
+    def __call__(self, prediction, target_is_real):
+        prec = E.Precision.get('fp32_bf16mma')
+        a = prediction if isinstance(prediction, E.Act) else E.to_engine(prediction, prec)
+        out = torch.zeros(1, dtype=torch.float32, device=a.t.device)
+        E.loss_op(E.Ctx(prec, None, False), self.kind, a, None, self.target(target_is_real), 1.0, out)
+        return out[0]
+
+
+def get_optimizer(optimizer_name):
+    """networks.py:46-53.  'adam' maps to the fused flat Adam kernel; anything else falls back to torch.optim (plumbing)."""
+    if optimizer_name.lower() == 'adam':
+        from .optim import FusedAdam
+        return FusedAdam
+    names = {n.lower(): n for n in dir(torch.optim) if n[0].isupper()}
+    try:
+        return getattr(torch.optim, names[optimizer_name.lower()])
+    except KeyError:
+        raise NotImplementedError('optimizer [%s] is not found' % optimizer_name)
+
+
+def get_scheduler(optimizer, opt):
+    """networks.py:55-81."""
+    if opt.lr_policy == 'linear':
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.epoch_count - opt.n_epochs) / float(opt.n_epochs_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.lr_policy == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    if opt.lr_policy == 'plateau':
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2, threshold=0.01, patience=5)
+    if opt.lr_policy == 'cosine':
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.n_epochs, eta_min=0)
+    raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)

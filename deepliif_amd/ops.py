@@ -1,0 +1,225 @@
+"""Tensor-level wrappers over the C ABI (include/deepliif_hip.h).
+
+Every function takes torch tensors that live on the GPU (PyTorch is only the allocator / stream owner here), extracts
+raw pointers + strides, and launches the hand-written gfx950 kernels on torch's *current* HIP stream.  There is no CPU or
+PyTorch-op fallback: a non-CUDA tensor raises.
+
+Engine tensors are NHWC views `[N, H, W, C]` with unit channel stride; `stride(2)` is the pixel stride, so a tensor may be
+a channel slice of a wider (concat) buffer.
+
+`_impl` is the single dispatch seam: the product always uses HipBackend; the CPU test-suite swaps in an emulation to
+exercise the host logic without a GPU (tests/fake_backend.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .geometry import GatherPlan, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc
+
+
+def dl_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.DL_F32
+    if t.dtype == torch.bfloat16:
+        return L.DL_BF16
+    raise TypeError(f'engine tensors are fp32 or bf16, got {t.dtype}')
+
+
+def pstride(t: torch.Tensor) -> int:
+    assert t.dim() == 4 and t.stride(3) == 1, 'NHWC view with unit channel stride expected'
+    ps = t.stride(2)
+    assert t.stride(1) == t.shape[2] * ps and t.stride(0) == t.shape[1] * t.shape[2] * ps, 'pixels must be densely strided'
+    return ps
+
+
+class Workspace:
+    """Grow-only fp32 scratch buffers, one per purpose.  All kernels run in stream order on one stream, so a buffer can be
+    reused by the next call of the same kind."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name: str, nfloats: int, device) -> torch.Tensor:
+        b = self.bufs.get(name)
+        if b is None or b.numel() < nfloats or b.device != device:
+            b = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
+            self.bufs[name] = b
+        return b
+
+
+WS = Workspace()
+
+
+class PackedWeights:
+
+    def __init__(self, plan: GatherPlan, device, with_lo: bool):
+        n = plan.rows_pad * plan.kstride
+        self.plan = plan
+        self.hi = torch.empty(n, dtype=torch.bfloat16, device=device)
+        self.lo = torch.empty(n, dtype=torch.bfloat16, device=device) if with_lo else None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.HipLibraryError('deepliif_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback')
+
+
+class HipBackend:
+    """The product path: ctypes calls into libdeepliif_hip.so."""
+
+    def __init__(self):
+        self.lib = L.load()
+
+    # ---- weights
+    def pack_weights(self, packed: PackedWeights, src: torch.Tensor):
+        _need_cuda(src, packed.hi)
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        d = fill_pack_desc(packed.plan, src.shape[0], src.shape[1], src.shape[2])
+        L.check(self.lib.dl_pack_weights(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), _stream()), 'dl_pack_weights')
+
+    # ---- convolution forward / data-gradient (gather GEMM)
+    def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
+                     act: int, in_act: int, prec: int, splitk: Optional[int] = None):
+        _need_cuda(x, out, bias)
+        plan = packed.plan
+        n, hi, wi, cp = x.shape
+        assert cp == plan.cc_pad, (cp, plan.cc_pad)
+        _, ho, wo, cop = out.shape
+        if splitk is None:
+            splitk = choose_splitk(plan, n, hq, wq, cop)
+        d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, pstride(out), hq, wq, dl_dtype(x), prec, act, in_act,
+                           0 if bias is None else bias.numel(), splitk)
+        assert dl_dtype(out) == d.in_dtype
+        slab = WS.get('conv_slab', splitk * n * ho * wo * cop, x.device) if splitk > 1 else None
+        L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
+                                         _stream()), 'dl_conv_forward')
+
+    # ---- weight gradient
+    def conv_wgrad(self, P: torch.Tensor, Q: torch.Tensor, grad: torch.Tensor, k: int, step: int, pad: int, pad_mode: int,
+                   p_act: int, q_act: int, prec: int, accumulate: bool, splitk: Optional[int] = None):
+        _need_cuda(P, Q, grad)
+        assert grad.dtype == torch.float32 and grad.is_contiguous()
+        d = L.WgradDesc()
+        d.N, d.Hp, d.Wp, d.CAp = P.shape
+        d.p_pstride = pstride(P)
+        _, d.Hq, d.Wq, d.CBp = Q.shape
+        d.q_pstride = pstride(Q)
+        d.KH = d.KW = k
+        d.step, d.pad, d.pad_mode = step, pad, pad_mode
+        d.CA, d.CB = grad.shape[0], grad.shape[1]
+        d.dtype, d.prec = dl_dtype(P), prec
+        j = k * k * d.CBp
+        d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp)
+        d.accumulate = 1 if accumulate else 0
+        d.p_act, d.q_act = p_act, q_act
+        slab = WS.get('wgrad_slab', d.splitk * d.CAp * j, P.device)
+        L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
+
+    # ---- normalisation
+    def _norm_desc(self, y, C_real, scope, act, momentum, z_ps, r_ps):
+        d = L.NormDesc()
+        d.N, d.H, d.W, d.Cp = y.shape
+        d.C = C_real
+        d.y_pstride, d.z_pstride, d.r_pstride = pstride(y), z_ps, r_ps
+        d.dtype, d.scope, d.act = dl_dtype(y), scope, act
+        d.eps, d.momentum = 1e-5, momentum
+        return d
+
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual):
+        _need_cuda(y, z, gamma, beta, residual)
+        d = self._norm_desc(y, C_real, scope, act, momentum, pstride(z), pstride(residual) if residual is not None else 8)
+        stats = torch.empty(4, y.shape[0], y.shape[3], dtype=torch.float32, device=y.device)   # mean, rstd, scale, shift
+        ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
+        L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                         _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(z),
+                                         _ptr(ws), _stream()), 'dl_norm_forward')
+        return stats
+
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta):
+        _need_cuda(dz, y, dy)
+        d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
+        ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
+        L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
+                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(ws), _stream()), 'dl_norm_backward')
+
+    # ---- elementwise
+    def act_forward(self, act, x, y):
+        _need_cuda(x, y)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        L.check(self.lib.dl_act_forward(act, dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], _stream()), 'dl_act_forward')
+
+    def act_backward(self, act, dy, y, dx):
+        _need_cuda(dy, y, dx)
+        npix = y.shape[0] * y.shape[1] * y.shape[2]
+        L.check(self.lib.dl_act_backward(act, dl_dtype(y), _ptr(dy), pstride(dy), _ptr(y), pstride(y), _ptr(dx), pstride(dx), npix,
+                                         y.shape[3], _stream()), 'dl_act_backward')
+
+    def axpby(self, alpha, a, beta, b, out):
+        _need_cuda(a, b, out)
+        npix = a.shape[0] * a.shape[1] * a.shape[2]
+        L.check(self.lib.dl_axpby(dl_dtype(a), float(alpha), _ptr(a), pstride(a), float(beta), _ptr(b), pstride(b) if b is not None else 8,
+                                  _ptr(out), pstride(out), npix, a.shape[3], _stream()), 'dl_axpby')
+
+    def copy_channels(self, src, s_c0, dst, d_c0, nch, accumulate=False):
+        _need_cuda(src, dst)
+        npix = src.shape[0] * src.shape[1] * src.shape[2]
+        L.check(self.lib.dl_copy_channels(dl_dtype(src), _ptr(src), pstride(src), s_c0, _ptr(dst), pstride(dst), d_c0, npix, nch,
+                                          1 if accumulate else 0, _stream()), 'dl_copy_channels')
+
+    def channel_sum(self, x, C_real, out, accumulate):
+        _need_cuda(x, out)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        ws = WS.get('csum_ws', 256 * x.shape[3], x.device)
+        L.check(self.lib.dl_channel_sum(dl_dtype(x), _ptr(x), pstride(x), npix, x.shape[3], C_real, _ptr(out), 1 if accumulate else 0,
+                                        _ptr(ws), _stream()), 'dl_channel_sum')
+
+    def nchw_to_nhwc(self, src, dst, c0, zero_pad_to):
+        _need_cuda(src, dst)
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        n, c, h, w = src.shape
+        L.check(self.lib.dl_nchw_to_nhwc(_ptr(src), n, c, h, w, dl_dtype(dst), _ptr(dst), pstride(dst), c0, zero_pad_to, _stream()),
+                'dl_nchw_to_nhwc')
+
+    def nhwc_to_nchw(self, src, c0, dst):
+        _need_cuda(src, dst)
+        assert dst.dtype == torch.float32 and dst.is_contiguous()
+        n, c, h, w = dst.shape
+        L.check(self.lib.dl_nhwc_to_nchw(dl_dtype(src), _ptr(src), pstride(src), c0, _ptr(dst), n, c, h, w, _stream()), 'dl_nhwc_to_nchw')
+
+    # ---- losses
+    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
+        _need_cuda(x, target, loss_out, grad)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        ws = WS.get('loss_ws', self.lib.dl_loss_ws_floats(), x.device)
+        L.check(self.lib.dl_loss(kind, dl_dtype(x), _ptr(x), pstride(x), _ptr(target), pstride(target) if target is not None else 8,
+                                 float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), _ptr(grad),
+                                 pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss')
+
+    # ---- optimiser
+    def adam_step(self, p, g, m, v, lr, b1, b2, eps, step, gscale):
+        _need_cuda(p, g, m, v)
+        L.check(self.lib.dl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+                                      float(gscale), _stream()), 'dl_adam_step')
+
+
+_impl = None
+
+
+def impl():
+    global _impl
+    if _impl is None:
+        _impl = HipBackend()        # raises if the .so is missing
+    return _impl

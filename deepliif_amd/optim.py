@@ -1,0 +1,89 @@
+"""Flat parameter sets and the fused Adam step.
+
+All parameters of one optimizer (the generator set / the discriminator set, DeepLIIF_model.py:128-147) live in ONE flat
+fp32 buffer with a matching flat gradient buffer: the optimizer step is a single HBM-streaming kernel (dl_adam_step) and
+the data-parallel gradient exchange operates on contiguous slices (deepliif_amd.distributed).  nn.Parameter objects stay
+valid: their .data / .grad become views into the flat buffers, so state_dict()/load_state_dict() and any torch.optim
+optimizer keep working on them.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        assert self.params, 'empty parameter set'
+        dev = self.params[0].device
+        assert all(p.device == dev and p.dtype == torch.float32 for p in self.params), 'one device, fp32 master weights'
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4        # keep every tensor 16-byte aligned
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            view = self.data[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            p._dl_epoch = getattr(p, '_dl_epoch', 0)
+
+    def attached(self) -> bool:
+        """False if something (e.g. module.to()) re-allocated a parameter away from the flat buffer."""
+        base = self.data.data_ptr()
+        return all(p.data_ptr() == base + 4 * off and p.grad is not None and p.grad.data_ptr() == self.grad.data_ptr() + 4 * off
+                   for p, off in zip(self.params, self.offsets))
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):       # re-attach views a caller may have dropped (zero_grad(set_to_none))
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def bump_epoch(self):
+        for p in self.params:
+            p._dl_epoch += 1
+
+    def slice_of(self, params: Iterable[torch.nn.Parameter]):
+        """(start, end) element range of the flat buffers covered by a contiguous run of this set's parameters."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), 'parameters of one network must be contiguous in the flat set'
+        end = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else self.numel
+        return self.offsets[idx[0]], end
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0, amsgrad=False) semantics on a FlatParams set, one kernel per
+    step.  A torch lr_scheduler drives param_groups[0]['lr'] as usual (networks.py:55-81, base_model.py:132-141)."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.flat = FlatParams(params)
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.step_count = 0
+        self.grad_scale = 1.0          # set to 1/world_size by the data-parallel driver (sum all-reduce)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        if not self.flat.attached():
+            raise RuntimeError('parameters were moved after the optimizer was built; rebuild the optimizer (FlatParams lost its views)')
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                             self.step_count, self.grad_scale)
+        self.flat.bump_epoch()         # packed bf16 weight images are stale now (engine.ConvLayer.ensure_packed)

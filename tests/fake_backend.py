@@ -1,0 +1,233 @@
+"""CPU emulation of the ops backend (deepliif_amd/ops.py HipBackend) -- TEST INFRASTRUCTURE ONLY.
+
+It implements the documented formula of every C-ABI entry point (include/deepliif_hip.h) with plain torch CPU ops, so the
+CPU test-suite can run the *host* logic (geometry, tape autograd, network programs, model step, optimizer, data-parallel
+exchange) without a GPU and compare it with the oracle.  It is never importable from the product package.
+"""
+import torch
+
+from deepliif_amd import _lib as L
+from deepliif_amd import ops
+
+
+def _act(act, v):
+    if act == L.ACT_RELU:
+        return torch.relu(v)
+    if act == L.ACT_LRELU:
+        return torch.where(v > 0, v, 0.2 * v)
+    if act == L.ACT_TANH:
+        return torch.tanh(v)
+    return v
+
+
+def _act_grad_from_output(act, y):
+    if act == L.ACT_RELU:
+        return (y > 0).to(y.dtype)
+    if act == L.ACT_LRELU:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+    if act == L.ACT_TANH:
+        return 1 - y * y
+    return torch.ones_like(y)
+
+
+def _reflect(idx, n):
+    idx = idx.abs()
+    return torch.where(idx >= n, 2 * n - 2 - idx, idx)
+
+
+def _gather(x, hq, wq, step, dh, dw, reflect):
+    """x [N,H,W,C] -> g[n,a,b,:] = x[n, a*step+dh, b*step+dw, :] (zero / reflect outside)."""
+    N, H, W, C = x.shape
+    hi = torch.arange(hq) * step + dh
+    wi = torch.arange(wq) * step + dw
+    if reflect:
+        hi, wi = _reflect(hi, H), _reflect(wi, W)
+        return x[:, hi][:, :, wi]
+    mh, mw = (hi >= 0) & (hi < H), (wi >= 0) & (wi < W)
+    g = x[:, hi.clamp(0, H - 1)][:, :, wi.clamp(0, W - 1)]
+    return g * (mh[:, None] & mw[None, :]).to(x.dtype)[None, :, :, None]
+
+
+class FakeBackend:
+    def __init__(self):
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def pack_weights(self, packed, src):
+        self._count('pack')
+        plan = packed.plan
+        W = torch.zeros(plan.rows_pad, plan.kstride, dtype=torch.float32)
+        for ph, taps in enumerate(plan.phase_taps):
+            for tl, (_, _, kh, kw) in enumerate(taps):
+                k0 = plan.kbase[ph] + tl * plan.cc_pad
+                blk = src[:, :, kh, kw].float()
+                W[:plan.rows_real, k0:k0 + plan.cc_real] = blk if plan.row_is_a else blk.t()
+        packed.fake_w = W
+
+    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None):
+        self._count('conv')
+        plan = packed.plan
+        xv = _act(in_act, x.float())
+        cop = out.shape[3]
+        acc = torch.zeros(out.shape, dtype=torch.float32)
+        for ph, taps in enumerate(plan.phase_taps):
+            oh, ow = plan.phase_off[ph]
+            for tl, (dh, dw, _, _) in enumerate(taps):
+                k0 = plan.kbase[ph] + tl * plan.cc_pad
+                Wt = packed.fake_w[:cop, k0:k0 + plan.cc_pad]
+                g = _gather(xv, hq, wq, plan.in_step, dh, dw, plan.pad_mode == L.PAD_REFLECT)
+                acc[:, oh::plan.out_step, ow::plan.out_step, :][:, :hq, :wq] += g @ Wt.t()
+        if bias is not None:
+            acc[..., :bias.numel()] += bias.float()
+        out.copy_(_act(act, acc).to(out.dtype))
+
+    def conv_wgrad(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, accumulate, splitk=None):
+        self._count('wgrad')
+        Pv, Qv = _act(p_act, P.float()), _act(q_act, Q.float())
+        CA, CB = grad.shape[0], grad.shape[1]
+        N, Hp, Wp, _ = Pv.shape
+        g = torch.zeros_like(grad)
+        for kh in range(k):
+            for kw in range(k):
+                qg = _gather(Qv, Hp, Wp, step, kh - pad, kw - pad, pad_mode == L.PAD_REFLECT)
+                g[:, :, kh, kw] = torch.einsum('nhwa,nhwb->ab', Pv[..., :CA], qg[..., :CB])
+        if accumulate:
+            grad.add_(g)
+        else:
+            grad.copy_(g)
+
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual):
+        self._count('norm_fwd')
+        yv = y.float()
+        dims = (0, 1, 2) if scope == L.NORM_BATCH else (1, 2)
+        mean = yv.mean(dim=dims, keepdim=True)
+        var = yv.var(dim=dims, unbiased=False, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        Cp = y.shape[3]
+        ga = torch.zeros(Cp)
+        be = torch.zeros(Cp)
+        ga[:C_real] = gamma.float() if gamma is not None else 1.0
+        if beta is not None:
+            be[:C_real] = beta.float()
+        scale = ga * rstd
+        shift = be - mean * scale
+        if running_mean is not None and momentum >= 0:
+            cnt = yv.numel() // Cp
+            running_mean.mul_(1 - momentum).add_(momentum * mean.reshape(-1)[:C_real])
+            running_var.mul_(1 - momentum).add_(momentum * var.reshape(-1)[:C_real] * cnt / max(cnt - 1, 1))
+        v = _act(act, yv * scale + shift)
+        if residual is not None:
+            v = v + residual.float()
+        z.copy_(v.to(z.dtype))
+        N = y.shape[0]
+        stats = torch.empty(4, N, Cp)
+        for i, t in enumerate((mean, rstd, scale, shift)):
+            stats[i] = t.reshape(-1, Cp).expand(N, Cp)
+        return stats
+
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta):
+        self._count('norm_bwd')
+        yv, g = y.float(), dz.float()
+        N, H, W, Cp = yv.shape
+        mean, rstd, scale, shift = (stats[i].view(N, 1, 1, Cp) for i in range(4))
+        nv = yv * scale + shift
+        if act == L.ACT_RELU:
+            dn = g * (nv > 0)
+        elif act == L.ACT_LRELU:
+            dn = torch.where(nv > 0, g, 0.2 * g)
+        elif act == L.ACT_TANH:
+            dn = g * (1 - torch.tanh(nv) ** 2)
+        else:
+            dn = g
+        xh = (yv - mean) * rstd
+        dims = (0, 1, 2) if scope == L.NORM_BATCH else (1, 2)
+        c1 = dn.mean(dim=dims, keepdim=True)
+        c2 = (dn * xh).mean(dim=dims, keepdim=True)
+        ga = torch.zeros(Cp)
+        ga[:C_real] = gamma.float() if gamma is not None else 1.0
+        dy.copy_((ga * rstd * (dn - c1 - xh * c2)).to(dy.dtype))
+        if dgamma is not None:
+            dgamma.add_((dn * xh).sum(dim=(0, 1, 2))[:C_real])
+            dbeta.add_(dn.sum(dim=(0, 1, 2))[:C_real])
+
+    def act_forward(self, act, x, y):
+        self._count('act')
+        y.copy_(_act(act, x.float()).to(y.dtype))
+
+    def act_backward(self, act, dy, y, dx):
+        self._count('act_bwd')
+        dx.copy_((dy.float() * _act_grad_from_output(act, y.float())).to(dx.dtype))
+
+    def axpby(self, alpha, a, beta, b, out):
+        self._count('axpby')
+        v = alpha * a.float()
+        if b is not None:
+            v = v + beta * b.float()
+        out.copy_(v.to(out.dtype))
+
+    def copy_channels(self, src, s_c0, dst, d_c0, nch, accumulate=False):
+        self._count('copy')
+        v = src[..., s_c0:s_c0 + nch].float()
+        if accumulate:
+            v = v + dst[..., d_c0:d_c0 + nch].float()
+        dst[..., d_c0:d_c0 + nch] = v.to(dst.dtype)
+
+    def channel_sum(self, x, C_real, out, accumulate):
+        self._count('csum')
+        s = x.float().sum(dim=(0, 1, 2))[:C_real]
+        if accumulate:
+            out.add_(s)
+        else:
+            out.copy_(s)
+
+    def nchw_to_nhwc(self, src, dst, c0, zero_pad_to):
+        self._count('to_nhwc')
+        C = src.shape[1]
+        dst[..., c0:c0 + C] = src.permute(0, 2, 3, 1).to(dst.dtype)
+        if zero_pad_to > c0 + C:
+            dst[..., c0 + C:zero_pad_to] = 0
+
+    def nhwc_to_nchw(self, src, c0, dst):
+        self._count('to_nchw')
+        C = dst.shape[1]
+        dst.copy_(src[..., c0:c0 + C].permute(0, 3, 1, 2).float())
+
+    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
+        self._count('loss')
+        v = x[..., :C_real].float()
+        t = target[..., :C_real].float() if target is not None else torch.full_like(v, target_const)
+        if kind == L.LOSS_BCE_LOGITS:
+            l = v.clamp(min=0) - v * t + torch.log1p(torch.exp(-v.abs()))
+            g = torch.sigmoid(v) - t
+        elif kind == L.LOSS_MSE:
+            l = (v - t) ** 2
+            g = 2 * (v - t)
+        else:
+            d = v - t
+            l = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
+            g = d.clamp(-1, 1)
+        loss_out[0] = l.mean()
+        if grad is not None:
+            grad.zero_()
+            grad[..., :C_real] = (g * grad_scale / v.numel()).to(grad.dtype)
+
+    def adam_step(self, p, g, m, v, lr, b1, b2, eps, step, gscale):
+        self._count('adam')
+        gi = g * gscale
+        m.mul_(b1).add_(gi, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+def install():
+    """Route deepliif_amd.ops through the CPU emulation (tests only); returns the backend for call counting."""
+    fb = FakeBackend()
+    ops._impl = fb
+    return fb
+
+
+def uninstall():
+    ops._impl = None

@@ -1,0 +1,118 @@
+"""Host logic of the engine-backed networks (deepliif_amd/networks.py + engine.py) on CPU: the ops backend is replaced by
+the formula emulation (tests/fake_backend.py), everything above it -- layer programs, tape autograd, UNet skip aliasing,
+in-place concat routing, parameter binding / state_dict keys -- is the product code.  Compared with the oracle in fp32
+(tolerance 2e-4 relative; both sides are fp32 CPU arithmetic in different summation orders)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fake_backend
+from deepliif_amd import engine as E
+from deepliif_amd import networks as N
+from golden_util import seeded_uniform
+from oracle import deepliif_oracle as O
+
+
+@pytest.fixture(autouse=True)
+def _fake():
+    fake_backend.install()
+    yield
+    fake_backend.uninstall()
+
+
+def rel(a, b, floor=1e-30):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(floor))
+
+
+CASES = [
+    ('resnet_9blocks', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
+    ('resnet_2blocks', 3, 8, 'instance', 'zero', (2, 3, 32, 32)),
+    ('unet_32', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
+    ('unet_32', 9, 8, 'instance', 'zero', (1, 9, 32, 32)),
+    ('unet_64', 3, 8, 'batch', 'zero', (1, 3, 64, 64)),
+    ('n_layers', 6, 8, 'batch', 'zero', (2, 6, 64, 64)),
+    ('n_layers', 12, 8, 'instance', 'zero', (1, 12, 64, 64)),
+]
+
+
+def build(arch, cin, nf, norm, pad):
+    if arch == 'n_layers':
+        return N.define_D(cin, nf, 'n_layers', 4, norm, 'normal', 0.02, [])
+    return N.define_G(cin, 3, nf, arch, norm, False, 'normal', 0.02, [], pad)
+
+
+@pytest.mark.parametrize('arch,cin,nf,norm,pad,shape', CASES)
+def test_forward_backward_matches_oracle(arch, cin, nf, norm, pad, shape):
+    sd = O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(5))
+    net = build(arch, cin, nf, norm, pad)
+    net.load_state_dict(sd, strict=True)            # same keys / shapes as the reference
+    net.train()
+    x = seeded_uniform(shape, 6)
+    prec = E.Precision.get('fp32')
+    tape = E.Tape()
+    ctx = E.Ctx(prec, tape, training=True)
+    xa = E.to_engine(x, prec)
+    xa.needs_grad = True
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    ya = net.run(ctx, xa)
+    y = E.from_engine(ya)
+
+    # oracle
+    sdo = {k: v.clone() for k, v in sd.items()}
+    params = {k: v.requires_grad_(True) for k, v in sdo.items() if v.is_floating_point() and 'running' not in k}
+    xo = x.clone().requires_grad_(True)
+    if arch == 'n_layers':
+        yo = O.nlayer_discriminator(sdo, xo, norm, 4, update_running=(norm == 'batch'))
+    else:
+        yo = O.run_generator(arch, sdo, xo, norm, pad, update_running=(norm == 'batch'))
+    assert rel(y, yo.detach()) < 2e-4
+
+    r = torch.randn(yo.shape, generator=torch.Generator().manual_seed(7))
+    grads = torch.autograd.grad((yo * r).sum(), [xo] + list(params.values()))
+    ya.grad = E.to_engine(r, prec).t
+    tape.backward()
+    dx = E.from_engine(E.Act(xa.grad, xa.C))
+    assert rel(dx, grads[0]) < 2e-4
+    gscale = max(float(g.abs().max()) for g in grads[1:])
+    named = dict(net.named_parameters())
+    for (k, _), g in zip(params.items(), grads[1:]):
+        assert rel(named[k].grad, g, floor=0.05 * gscale) < 5e-4, k
+    # BatchNorm running statistics follow nn.BatchNorm2d
+    if norm == 'batch':
+        for k, v in net.state_dict().items():
+            if 'running' in k:
+                assert rel(v, sdo[k].detach(), floor=1e-3) < 1e-4, k
+
+
+def test_inference_seam_per_sample_norm():
+    """net(x) with N>1 reproduces N single-tile forwards (the reference only ever runs one tile per forward)."""
+    sd = O.random_state_dict('resnet_2blocks', 3, 3, 8, 'batch', 'zero', generator=torch.Generator().manual_seed(1))
+    net = build('resnet_2blocks', 3, 8, 'batch', 'zero').set_precision('fp32')
+    net.load_state_dict(sd)
+    net.eval()
+    x = seeded_uniform((3, 3, 16, 16), 2)
+    y = net(x)
+    for i in range(3):
+        yo = O.resnet_generator(sd, x[i:i + 1], 'batch', 'zero', 2)
+        assert rel(y[i:i + 1], yo) < 2e-4
+
+
+def test_seeded_init_matches_reference_rng_order():
+    """define_G/define_D under torch.manual_seed(0) must give the reference's weights (fixture: per-key sums)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'seeded_init.npz'))
+    cases = {'resnet_9blocks_batch': lambda: N.define_G(3, 3, 64, 'resnet_9blocks', 'batch', False, 'normal', 0.02, [], 'zero'),
+             'resnet_9blocks_instance': lambda: N.define_G(3, 3, 64, 'resnet_9blocks', 'instance', False, 'normal', 0.02, [], 'zero'),
+             'unet_512_batch': lambda: N.define_G(3, 3, 64, 'unet_512', 'batch', False, 'normal', 0.02, []),
+             'n_layers_batch': lambda: N.define_D(6, 64, 'n_layers', 4, 'batch', 'normal', 0.02, [])}
+    for tag, fn in cases.items():
+        torch.manual_seed(0)
+        sd = fn().state_dict()
+        assert list(sd.keys()) == [str(k) for k in z[f'{tag}/keys']]
+        assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in z[f'{tag}/shapes']]
+        sums = np.array([v.double().sum().item() for v in sd.values()])
+        asums = np.array([v.double().abs().sum().item() for v in sd.values()])
+        assert np.allclose(sums, z[f'{tag}/sums'], rtol=1e-9, atol=1e-9), tag
+        assert np.allclose(asums, z[f'{tag}/abs_sums'], rtol=1e-9, atol=1e-9), tag
