@@ -1,0 +1,410 @@
+"""Drop-in model classes for the training seam: create_model(opt) -> model with set_input / optimize_parameters /
+calculate_losses / forward / test / eval / train / get_current_losses / get_current_visuals / save_networks / load_networks /
+update_learning_rate -- the surface cli.py:403-449, train.py and test.py:90-113 rely on.
+
+DeepLIIFModel mirrors deepliif/models/DeepLIIF_model.py (network naming :49-115, forward :175-203, backward_D :205-332,
+backward_G :334-429, optimize_parameters :431-467) but executes on the MI355X engine: explicit forward/backward tape over
+hand-written HIP kernels, one fused Adam kernel per parameter set, gradient exchange on flat buffers.
+The VGG19 perceptual term of the reference (:406-409) needs downloaded torchvision weights and is not on this path
+(SURVEY 0 #4): lambda_feat is accepted and ignored with a one-time notice.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+from . import networks
+from .distributed import GradExchanger
+from .optim import FusedAdam
+
+
+def _get(opt, name, default):
+    return getattr(opt, name) if hasattr(opt, name) else default
+
+
+def init_input_and_mod_id(opt, dir_model=None):
+    """deepliif/util/util.py:242-270 for a fresh training run / explicit opt fields (file-name sniffing of existing
+    checkpoints is done by the reference's Options object, which passes mod_id_seg / input_id through opt)."""
+    if hasattr(opt, 'mod_id_seg') and opt.mod_id_seg is not None:
+        mod_id_seg = opt.mod_id_seg
+    elif not hasattr(opt, 'modalities_names'):
+        mod_id_seg = opt.modalities_no + 1
+    else:
+        mod_id_seg = 'S'
+    input_id = str(_get(opt, 'input_id', '0'))
+    return mod_id_seg, input_id
+
+
+class BaseModel:
+    """deepliif/models/base_model.py surface."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.is_train = opt.is_train
+        self.device = self._device_from_opt(opt)
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.loss_names: List[str] = []
+        self.model_names: List[str] = []
+        self.visual_names: List[str] = []
+        self.optimizers = []
+        self.image_paths = []
+        self.metric = 0
+        self.precision = E.Precision.get(_get(opt, 'precision', networks.DEFAULT_PRECISION))
+
+    def _device_from_opt(self, opt) -> torch.device:
+        if not opt.gpu_ids:
+            raise L.HipLibraryError('deepliif_amd models run on MI355X only: opt.gpu_ids must name a GPU (no CPU fallback)')
+        return torch.device('cuda:{}'.format(opt.gpu_ids[0]))
+
+    def _net_gpu_ids(self):
+        return self.gpu_ids
+
+    # -- lifecycle -------------------------------------------------------------------------------------------
+    def setup(self, opt):
+        self.opt = opt
+        if self.is_train:
+            self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
+        if not self.is_train or _get(opt, 'continue_train', False):
+            suffix = 'iter_%d' % opt.load_iter if _get(opt, 'load_iter', 0) > 0 else opt.epoch
+            self.load_networks(suffix)
+        self.print_networks(_get(opt, 'verbose', False))
+
+    def _nets(self):
+        return [(n, getattr(self, 'net' + n)) for n in self.model_names]
+
+    def train(self):
+        for _, net in self._nets():
+            net.train()
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d) and hasattr(m, 'running_mean_backup'):
+                    m.track_running_stats = True
+                    m.running_mean, m.running_var = m.running_mean_backup, m.running_var_backup
+
+    def eval(self):
+        # base_model.py:103-112 + util/__init__.py:743-755: eval mode still normalises with batch statistics
+        for _, net in self._nets():
+            net.eval()
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d) and m.running_mean is not None:
+                    m.track_running_stats = False
+                    m.running_mean_backup, m.running_var_backup = m.running_mean, m.running_var
+                    m.running_mean = m.running_var = None
+
+    def test(self):
+        self.forward(record=False)
+        self.compute_visuals()
+
+    def compute_visuals(self):
+        pass
+
+    def get_image_paths(self):
+        return self.image_paths
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            if self.opt.lr_policy == 'plateau':
+                s.step(self.metric)
+            else:
+                s.step()
+        print('learning rate = %.7f' % self.optimizers[0].param_groups[0]['lr'])
+
+    def get_current_visuals(self):
+        return OrderedDict((n, getattr(self, n)) for n in self.visual_names if hasattr(self, n))
+
+    def get_current_losses(self):
+        # one device->host copy for all losses (the reference syncs once per loss: base_model.py:173-188)
+        vals = self._loss_buf.detach().cpu().tolist() if hasattr(self, '_loss_buf') else []
+        return OrderedDict((n, float(vals[self._loss_index[n]])) for n in self.loss_names)
+
+    def save_networks(self, epoch, save_from_one_process=False):
+        os.makedirs(self.save_dir, exist_ok=True)
+        for name, net in self._nets():
+            sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+            torch.save(sd, os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name)))
+
+    def load_networks(self, epoch):
+        for name, net in self._nets():
+            path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
+            print('loading the model from %s' % path)
+            sd = torch.load(path, map_location='cpu')
+            if hasattr(sd, '_metadata'):
+                del sd._metadata
+            net.load_state_dict(sd)          # copies into the (flat-buffer backed) parameters in place
+
+    def print_networks(self, verbose):
+        print('---------- Networks initialized -------------')
+        for name, net in self._nets():
+            if verbose:
+                print(net)
+            print('[Network %s] Total number of parameters : %.3f M' % (name, sum(p.numel() for p in net.parameters()) / 1e6))
+        print('-----------------------------------------------')
+
+    def set_requires_grad(self, nets, requires_grad=False):
+        if not isinstance(nets, list):
+            nets = [nets]
+        for net in nets:
+            if net is not None:
+                for p in net.parameters():
+                    p.requires_grad = requires_grad
+
+
+class DeepLIIFModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        if not hasattr(opt, 'net_gs'):
+            opt.net_gs = 'unet_512'
+        self.seg_gen = opt.seg_gen
+        self.seg_weights = list(opt.seg_weights)
+        self.loss_G_weights = list(opt.loss_G_weights)
+        self.loss_D_weights = list(opt.loss_D_weights)
+        self.mod_id_seg, self.input_id = init_input_and_mod_id(opt)
+        M, S = opt.modalities_no, self.mod_id_seg
+
+        # ---- names (DeepLIIF_model.py:33-80)
+        self.loss_names = []
+        self.visual_names = ['real_A']
+        for i in range(1, M + 1):
+            self.loss_names += [f'G_GAN_{i}', f'G_L1_{i}', f'D_real_{i}', f'D_fake_{i}']
+            self.visual_names += [f'fake_B_{i}', f'real_B_{i}']
+        if self.seg_gen:
+            self.loss_names += [f'G_GAN_{S}', f'G_L1_{S}', f'D_real_{S}', f'D_fake_{S}']
+            for i in range(M + 1):
+                self.visual_names += [f'fake_B_{S}{i}']
+            self.visual_names += [f'fake_B_{S}', f'real_B_{S}']
+        off = 0 if self.input_id == '0' else 1
+        self.model_names_g = [f'G{i}' for i in range(1, M + 1)]
+        self.model_names_gs = [f'G{S}{i + off}' for i in range(M + 1)] if self.seg_gen else []
+        self.model_names_d = [f'D{i}' for i in range(1, M + 1)] if self.is_train else []
+        self.model_names_ds = [f'D{S}{i + off}' for i in range(M + 1)] if (self.is_train and self.seg_gen) else []
+        if self.is_train:
+            self.model_names = []
+            for i in range(M):
+                self.model_names += [self.model_names_g[i], self.model_names_d[i]]
+            for i in range(len(self.model_names_gs)):
+                self.model_names += [self.model_names_gs[i], self.model_names_ds[i]]
+        else:
+            self.model_names = self.model_names_g + self.model_names_gs
+
+        # ---- networks, constructed in the reference's order so that seeded init matches (DeepLIIF_model.py:83-115)
+        netG = getattr(opt, 'netG', None) or getattr(opt, 'net_g')
+        if isinstance(netG, str):
+            netG = [netG] * M
+        opt.netG = netG
+        if isinstance(opt.net_gs, str):
+            opt.net_gs = [opt.net_gs] * (M + 1)
+        use_dropout = not _get(opt, 'no_dropout', True)
+        cin = opt.input_nc * _get(opt, 'input_no', 1)
+        gpu = self._net_gpu_ids()
+        for i, n in enumerate(self.model_names_g):
+            setattr(self, 'net' + n, networks.define_G(cin, opt.output_nc, opt.ngf, netG[i], opt.norm, use_dropout, opt.init_type, opt.init_gain,
+                                                         gpu, opt.padding, _get(opt, 'upsample', 'convtranspose')))
+        for i, n in enumerate(self.model_names_gs):
+            # define_G's default padding_type ('reflect') applies to the seg generators (DeepLIIF_model.py:95-99)
+            setattr(self, 'net' + n, networks.define_G(cin, opt.output_nc, opt.ngf, opt.net_gs[i], opt.norm, use_dropout, opt.init_type,
+                                                         opt.init_gain, gpu))
+        netD = getattr(opt, 'netD', None) or _get(opt, 'net_d', 'n_layers')
+        n_layers_D = _get(opt, 'n_layers_D', 4)
+        for n in self.model_names_d + self.model_names_ds:
+            setattr(self, 'net' + n, networks.define_D(cin + opt.output_nc, opt.ndf, netD, n_layers_D, opt.norm, opt.init_type, opt.init_gain, gpu))
+        for _, net in self._nets():
+            net.set_precision(self.precision.name)
+
+        # ---- losses: one fp32 device buffer, loss_<name> attributes are 0-dim views (no host sync in the step)
+        self._loss_index = {n: i for i, n in enumerate(self.loss_names)}
+        self._loss_buf = torch.zeros(max(len(self.loss_names), 1), dtype=torch.float32, device=self.device)
+        for n, i in self._loss_index.items():
+            setattr(self, 'loss_' + n, self._loss_buf[i])
+
+        if self.is_train:
+            self.criterionGAN_mod = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionGAN_seg = networks.GANLoss(opt.gan_mode_s).to(self.device)
+            self.lambda_L1 = _get(opt, 'lambda_L1', 100.0)
+            if _get(opt, 'lambda_feat', 0):
+                print('deepliif_amd: the VGG19 perceptual loss (lambda_feat) is not part of the MI355X hot path; training uses GAN + SmoothL1')
+            params_g = [p for n in self.model_names_g + self.model_names_gs for p in getattr(self, 'net' + n).parameters()]
+            params_d = [p for n in self.model_names_d + self.model_names_ds for p in getattr(self, 'net' + n).parameters()]
+            OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
+            try:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g, betas=(opt.beta1, 0.999))
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d, betas=(opt.beta1, 0.999))
+            except TypeError:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g)
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d)
+            self.optimizers += [self.optimizer_G, self.optimizer_D]
+            self.exchange = GradExchanger()
+        self._tape_G: Optional[E.Tape] = None
+
+    # ---------------------------------------------------------------------------------------------------------
+    def set_input(self, input):
+        """DeepLIIF_model.py:153-173: dict{'A': Tensor|list, 'B': list[Tensor], 'A_paths'}; tensors NCHW fp32 in [-1, 1]."""
+        A = input['A']
+        if isinstance(A, list):
+            A = torch.cat([a.to(self.device) for a in A], dim=1)
+        self.real_A = A.to(self.device, non_blocking=True)
+        self.real_B_array = input['B']
+        M, S = self.opt.modalities_no, self.mod_id_seg
+        for i in range(M):
+            setattr(self, f'real_B_{i + 1}', self.real_B_array[i].to(self.device, non_blocking=True))
+        if self.seg_gen:
+            setattr(self, f'real_B_{S}', self.real_B_array[M].to(self.device, non_blocking=True))
+        self.image_paths = input.get('A_paths', [])
+        # engine-layout copies, made once per batch
+        p = self.precision
+        self._A = E.to_engine(self.real_A, p)
+        self._B = [E.to_engine(getattr(self, f'real_B_{i + 1}'), p) for i in range(M)]
+        self._Bseg = E.to_engine(getattr(self, f'real_B_{S}'), p) if self.seg_gen else None
+        self._real_pairs = None
+
+    def _ctx(self, tape, training=True):
+        return E.Ctx(self.precision, tape, training=training)
+
+    def forward(self, record: Optional[bool] = None):
+        """DeepLIIF_model.py:175-203."""
+        record = self.is_train if record is None else record
+        tape = E.Tape() if record else None
+        ctx = self._ctx(tape, training=record)
+        M, S = self.opt.modalities_no, self.mod_id_seg
+        self._fake = []
+        for i, n in enumerate(self.model_names_g):
+            f = getattr(self, 'net' + n).run(ctx, self._A)
+            self._fake.append(f)
+            setattr(self, f'fake_B_{i + 1}', E.from_engine(f))
+        if self.seg_gen:
+            parts = []
+            for i, n in enumerate(self.model_names_gs):
+                src = self._A if i == 0 else self._fake[i - 1]
+                s = getattr(self, 'net' + n).run(ctx, src)
+                parts.append(s)
+                setattr(self, f'fake_B_{S}_{i}', E.from_engine(s))
+            self._fake_seg = E.weighted_sum(ctx, parts, self.seg_weights[:M + 1])
+            setattr(self, f'fake_B_{S}', E.from_engine(self._fake_seg))
+        self._tape_G = tape
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _pairs_real(self, ctx):
+        if self._real_pairs is None:
+            M = self.opt.modalities_no
+            mod = [E.concat_channels(ctx, [self._A, self._B[i]]) for i in range(M)]
+            seg = []
+            if self.seg_gen:
+                for i in range(M + 1):
+                    cond = self._A if i == 0 else self._B[i - 1]
+                    seg.append(E.concat_channels(ctx, [cond, self._Bseg]))
+            self._real_pairs = (mod, seg)
+        return self._real_pairs
+
+    def _seg_pred(self, ctx, image: E.Act):
+        M = self.opt.modalities_no
+        preds = []
+        for i, n in enumerate(self.model_names_ds):
+            cond = self._A if i == 0 else self._B[i - 1]        # real modalities condition the seg discriminators (:253-255)
+            preds.append(getattr(self, 'net' + n).run(ctx, E.concat_channels(ctx, [cond, image])))
+        return E.weighted_sum(ctx, preds, self.seg_weights[:M + 1])   # weighted BEFORE the lsgan loss (:258-262)
+
+    def backward_D(self):
+        """DeepLIIF_model.py:205-332: D losses on detached fakes and on real pairs."""
+        tape = E.Tape()
+        ctx = self._ctx(tape)
+        M, S = self.opt.modalities_no, self.mod_id_seg
+        wD = self.loss_D_weights
+        cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
+        for i, n in enumerate(self.model_names_d):
+            pair = E.concat_channels(ctx, [self._A, self._fake[i].detach()])
+            pred = getattr(self, 'net' + n).run(ctx, pair)
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * wD[i], getattr(self, f'loss_D_fake_{i + 1}').view(1))
+        if self.seg_gen:
+            pred = self._seg_pred(ctx, self._fake_seg.detach())
+            E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * wD[M], getattr(self, f'loss_D_fake_{S}').view(1))
+        real_mod, real_seg = self._pairs_real(ctx)
+        for i, n in enumerate(self.model_names_d):
+            pred = getattr(self, 'net' + n).run(ctx, real_mod[i])
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * wD[i], getattr(self, f'loss_D_real_{i + 1}').view(1))
+        if self.seg_gen:
+            preds = [getattr(self, 'net' + n).run(ctx, real_seg[i]) for i, n in enumerate(self.model_names_ds)]
+            pred = E.weighted_sum(ctx, preds, self.seg_weights[:M + 1])
+            E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * wD[M], getattr(self, f'loss_D_real_{S}').view(1))
+        tape.backward()
+
+    def backward_G(self):
+        """DeepLIIF_model.py:334-429 (VGG term excluded).  The seg term is weighted by loss_G_weights[modalities_no - 1]:
+        the reference reuses the stale loop index (:418-421)."""
+        tape = self._tape_G
+        assert tape is not None, 'forward() must run in training mode before backward_G()'
+        ctx = self._ctx(tape)
+        M, S = self.opt.modalities_no, self.mod_id_seg
+        wG = self.loss_G_weights
+        cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
+        for i, n in enumerate(self.model_names_d):
+            pair = E.concat_channels(ctx, [self._A, self._fake[i]])
+            pred = getattr(self, 'net' + n).run(ctx, pair)
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), wG[i], getattr(self, f'loss_G_GAN_{i + 1}').view(1))
+        if self.seg_gen:
+            pred = self._seg_pred(ctx, self._fake_seg)
+            E.loss_op(ctx, cs.kind, pred, None, cs.target(True), wG[M - 1], getattr(self, f'loss_G_GAN_{S}').view(1))
+        for i in range(M):
+            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, wG[i] * self.lambda_L1, self._l1_raw(i))
+        if self.seg_gen:
+            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_seg, self._Bseg, 0.0, wG[M - 1] * self.lambda_L1, self._l1_raw(M))
+        tape.backward()
+        self._tape_G = None
+        # the reference logs loss_G_L1 already multiplied by lambda_L1 (:398-400)
+        self._loss_buf[self._l1_slots] *= self.lambda_L1
+
+    def _l1_raw(self, i):
+        M, S = self.opt.modalities_no, self.mod_id_seg
+        name = f'G_L1_{i + 1}' if i < M else f'G_L1_{S}'
+        return self._loss_buf[self._loss_index[name]].view(1)
+
+    @property
+    def _l1_slots(self):
+        if not hasattr(self, '_l1_slots_cache'):
+            idx = [self._loss_index[n] for n in self.loss_names if n.startswith('G_L1_')]
+            self._l1_slots_cache = torch.tensor(idx, dtype=torch.long, device=self.device)
+        return self._l1_slots_cache
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _d_nets(self):
+        return [getattr(self, 'net' + n) for n in self.model_names_d + self.model_names_ds]
+
+    def optimize_parameters(self):
+        """DeepLIIF_model.py:431-467."""
+        self.forward()
+        self.set_requires_grad(self._d_nets(), True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.exchange.all_reduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.set_requires_grad(self._d_nets(), False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.exchange.all_reduce(self.optimizer_G)
+        self.optimizer_G.step()
+
+    def calculate_losses(self):
+        """DeepLIIF_model.py:469-507: losses + gradients without the optimizer steps (validation)."""
+        self.forward()
+        self.set_requires_grad(self._d_nets(), True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.set_requires_grad(self._d_nets(), False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+
+
+_MODEL_CLASSES = {'DeepLIIF': DeepLIIFModel}
+
+
+def create_model(opt):
+    """deepliif/models/__init__.py:101-114."""
+    name = _get(opt, 'model', 'DeepLIIF')
+    if name not in _MODEL_CLASSES:
+        raise NotImplementedError(f'model [{name}] is not on the MI355X hot path (available: {sorted(_MODEL_CLASSES)})')
+    instance = _MODEL_CLASSES[name](opt)
+    print('model [%s] was created' % type(instance).__name__)
+    return instance

@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() or os.environ.get('DL_TEST_DRYRUN') == '1':
         return
     skip = pytest.mark.skip(reason='no GPU in this container')
     for item in items:

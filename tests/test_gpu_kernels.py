@@ -1,0 +1,315 @@
+"""GPU parity of every C-ABI kernel family, called through deepliif_amd.ops.HipBackend (ctypes -> libdeepliif_hip.so) and
+checked against the CPU formula emulation (tests/fake_backend.py, itself pinned to torch's convolutions by
+tests/test_geometry.py and to the oracle by tests/test_host_networks.py).
+
+Tolerances (relative to the max |expected| of the tensor):
+  fp32 policy (split-bf16 x3 MFMA, fp32 storage) : 1e-4   -- north-star bar is 1e-3
+  bf16 policy (bf16 storage, one MFMA pass)      : inputs/weights are pre-rounded to bf16 so both sides see identical
+                                                   operands; remaining error = bf16 output rounding (2^-9) + fp32
+                                                   summation order -> 6e-3
+"""
+import numpy as np
+import pytest
+import torch
+
+import fake_backend
+from deepliif_amd import _lib as L
+from deepliif_amd import ops
+from deepliif_amd.engine import Precision
+from deepliif_amd.geometry import ConvSpec, cpad
+
+import os
+
+pytestmark = pytest.mark.gpu
+# DL_TEST_DRYRUN=1 runs this file on CPU with the emulation on both sides: a self-check of the test code only
+DRY = os.environ.get('DL_TEST_DRYRUN') == '1'
+DEV = 'cpu' if DRY else 'cuda'
+
+
+def hip():
+    if DRY:
+        return fake_backend.FakeBackend()
+    ops._impl = None
+    return ops.impl()
+
+
+def sync():
+    if not DRY:
+        torch.cuda.synchronize()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def tol(prec):
+    return 1e-4 if prec.name == 'fp32' else 6e-3
+
+
+def rnd(shape, seed, prec, scale=1.0):
+    t = torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+    return t.to(prec.dtype).float() if prec.dtype == torch.bfloat16 else t
+
+
+# ------------------------------------------------------------------------------------------------ hardware probes
+def test_probe_mfma_fragment_layout():
+    if DRY:
+        pytest.skip('hardware probe')
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(16, 32, generator=g).bfloat16()
+    b = torch.randn(32, 16, generator=g).bfloat16()       # asymmetric operands: catches row/col swaps
+    d = torch.zeros(16, 16, device=DEV)
+    L.check(lib.dl_probe_mfma16(a.to(DEV).data_ptr(), b.to(DEV).data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
+    sync()
+    assert rel(d, a.float() @ b.float()) < 1e-5
+
+
+def test_probe_ds_read_tr16_b64():
+    """lane (m, g) reads 8 B at tile[4g + (m>>2)][(m&3)*4]; the transposing read must return tile[4g + j][m], j = 0..3"""
+    if DRY:
+        pytest.skip('hardware probe')
+    lib = L.load()
+    src = torch.arange(64 * 16, dtype=torch.int16).view(64, 16)
+    dst = torch.zeros(64, 4, dtype=torch.int16, device=DEV)
+    L.check(lib.dl_probe_trread(src.to(DEV).data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
+    sync()
+    dst = dst.cpu()
+    exp = torch.zeros(64, 4, dtype=torch.int16)
+    for lane in range(64):
+        m, g = lane & 15, lane >> 4
+        for j in range(4):
+            exp[lane, j] = src[4 * g + j, m]
+    if not torch.equal(dst, exp):
+        np.save('gpurun_out/trread_actual.npy', dst.numpy())
+    assert torch.equal(dst, exp), f'ds_read_b64_tr_b16 mapping differs; lane0={dst[0].tolist()} lane1={dst[1].tolist()} lane17={dst[17].tolist()}'
+
+
+# ------------------------------------------------------------------------------------------------ conv forward / dgrad
+CONV_CASES = [
+    # kind, cin, cout, k, s, p, pad_mode, out_pad, N, H, W
+    ('conv', 3, 64, 7, 1, 3, L.PAD_ZERO, 0, 2, 40, 36),
+    ('conv', 3, 64, 7, 1, 3, L.PAD_REFLECT, 0, 1, 24, 20),
+    ('conv', 64, 128, 3, 2, 1, L.PAD_ZERO, 0, 2, 32, 24),
+    ('conv', 256, 256, 3, 1, 1, L.PAD_ZERO, 0, 2, 24, 20),
+    ('conv', 128, 128, 3, 1, 1, L.PAD_REFLECT, 0, 1, 12, 16),
+    ('convT', 256, 128, 3, 2, 1, L.PAD_ZERO, 1, 2, 12, 10),
+    ('convT', 128, 64, 3, 2, 1, L.PAD_ZERO, 1, 1, 16, 16),
+    ('conv', 64, 3, 7, 1, 3, L.PAD_ZERO, 0, 2, 24, 28),
+    ('conv', 6, 64, 4, 2, 1, L.PAD_ZERO, 0, 2, 32, 32),
+    ('conv', 12, 64, 4, 2, 1, L.PAD_ZERO, 0, 1, 16, 16),
+    ('conv', 256, 512, 4, 2, 1, L.PAD_ZERO, 0, 2, 16, 16),
+    ('conv', 512, 512, 4, 1, 1, L.PAD_ZERO, 0, 2, 9, 9),
+    ('conv', 512, 1, 4, 1, 1, L.PAD_ZERO, 0, 2, 8, 8),
+    ('convT', 1024, 512, 4, 2, 1, L.PAD_ZERO, 0, 2, 4, 4),
+    ('convT', 128, 3, 4, 2, 1, L.PAD_ZERO, 0, 1, 16, 16),
+    ('conv', 512, 512, 4, 2, 1, L.PAD_ZERO, 0, 8, 2, 2),      # UNet innermost down: split-K path
+    ('convT', 512, 512, 4, 2, 1, L.PAD_ZERO, 0, 8, 1, 1),     # UNet innermost up
+]
+
+
+def _run_conv(be, plan_kind, spec, prec, x, w, bias, act, in_act, H, W_, splitk=None):
+    plan = spec.forward_plan() if plan_kind == 'fwd' else spec.dgrad_plan()
+    dev = x.device
+    packed = ops.PackedWeights(plan, dev, prec.prec == L.PREC_BF16X3)
+    be.pack_weights(packed, w)
+    n = x.shape[0]
+    if plan_kind == 'fwd':
+        ho, wo = spec.out_hw(H, W_)
+        hq, wq = (ho, wo) if spec.kind == 'conv' else (H, W_)
+        cop = cpad(spec.cout)
+    else:
+        ho, wo = H, W_                                  # dx has the layer-input size
+        oh, ow = spec.out_hw(H, W_)
+        hq, wq = (oh, ow) if (spec.kind == 'conv' and spec.stride == 2) else (H, W_)
+        cop = cpad(spec.cin)
+    out = torch.empty((n, ho, wo, cop), dtype=prec.dtype, device=dev)
+    be.conv_forward(packed, x, out, hq, wq, bias, act, in_act, prec.prec, splitk)
+    return out
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}')
+def test_conv_forward_and_dgrad(case, precname):
+    kind, cin, cout, k, s, p, pm, op, N, H, W_ = case
+    prec = Precision.get(precname)
+    spec = ConvSpec(kind, cin, cout, k, s, p, pm, op)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd(wshape, 1, prec, 0.05)
+    bias = rnd((cout,), 2, Precision.get('fp32'), 0.1)
+    x = torch.zeros(N, H, W_, cpad(cin))
+    x[..., :cin] = rnd((N, H, W_, cin), 3, prec)
+    fake, real = fake_backend.FakeBackend(), hip()
+    for act, in_act in ((L.ACT_NONE, L.ACT_NONE), (L.ACT_TANH, L.ACT_LRELU)):
+        exp = _run_conv(fake, 'fwd', spec, prec, x.to(prec.dtype), w, bias, act, in_act, H, W_)
+        got = _run_conv(real, 'fwd', spec, prec, x.to(prec.dtype).to(DEV), w.to(DEV), bias.to(DEV), act, in_act, H, W_)
+        sync()
+        assert rel(got, exp) < tol(prec), ('fwd', act, in_act)
+    # forced split-K must agree with the single-pass result
+    got2 = _run_conv(real, 'fwd', spec, prec, x.to(prec.dtype).to(DEV), w.to(DEV), bias.to(DEV), L.ACT_NONE, L.ACT_NONE, H, W_, splitk=3)
+    exp = _run_conv(fake, 'fwd', spec, prec, x.to(prec.dtype), w, bias, L.ACT_NONE, L.ACT_NONE, H, W_)
+    assert rel(got2, exp) < tol(prec), 'splitk'
+    if pm == L.PAD_ZERO:
+        ho, wo = spec.out_hw(H, W_)
+        if kind == 'conv' and s == 2 and (H != 2 * ho or W_ != 2 * wo):
+            return
+        dy = torch.zeros(N, ho, wo, cpad(cout))
+        dy[..., :cout] = rnd((N, ho, wo, cout), 4, prec)
+        exp = _run_conv(fake, 'dgrad', spec, prec, dy.to(prec.dtype), w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+        got = _run_conv(real, 'dgrad', spec, prec, dy.to(prec.dtype).to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+        sync()
+        assert rel(got, exp) < tol(prec), 'dgrad'
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}')
+def test_conv_wgrad(case, precname):
+    kind, cin, cout, k, s, p, pm, op, N, H, W_ = case
+    prec = Precision.get(precname)
+    spec = ConvSpec(kind, cin, cout, k, s, p, pm, op)
+    ho, wo = spec.out_hw(H, W_)
+    x = torch.zeros(N, H, W_, cpad(cin))
+    x[..., :cin] = rnd((N, H, W_, cin), 5, prec)
+    dy = torch.zeros(N, ho, wo, cpad(cout))
+    dy[..., :cout] = rnd((N, ho, wo, cout), 6, prec)
+    fake, real = fake_backend.FakeBackend(), hip()
+    if kind == 'conv':
+        P, Q, gshape = dy, x, (cout, cin, k, k)
+        args = (k, s, p, pm, L.ACT_NONE, L.ACT_LRELU)
+    else:
+        P, Q, gshape = x, dy, (cin, cout, k, k)
+        args = (k, s, p, L.PAD_ZERO, L.ACT_RELU, L.ACT_NONE)
+    g_exp = torch.zeros(gshape)
+    fake.conv_wgrad(P.to(prec.dtype), Q.to(prec.dtype), g_exp, *args, prec.prec, False)
+    g0 = torch.randn(gshape, generator=torch.Generator().manual_seed(9))
+    g_got = g0.clone().to(DEV)
+    real.conv_wgrad(P.to(prec.dtype).to(DEV), Q.to(prec.dtype).to(DEV), g_got, *args, prec.prec, True)
+    sync()
+    # accumulate=True adds onto the existing gradient; bf16 policy: operands identical on both sides, fp32 accumulation
+    assert rel(g_got.cpu() - g0, g_exp) < (1e-4 if precname == 'fp32' else 1e-3)
+    g_got2 = torch.empty(gshape, device=DEV)
+    real.conv_wgrad(P.to(prec.dtype).to(DEV), Q.to(prec.dtype).to(DEV), g_got2, *args, prec.prec, False, splitk=1)
+    sync()
+    assert rel(g_got2, g_exp) < (1e-4 if precname == 'fp32' else 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ norm / elementwise / loss / adam
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('scope', [L.NORM_INSTANCE, L.NORM_BATCH])
+@pytest.mark.parametrize('shape,C', [((2, 20, 24, 64), 64), ((3, 7, 5, 256), 256), ((2, 33, 31, 8), 3), ((8, 1, 1, 512), 512), ((1, 64, 64, 16), 12)])
+def test_norm_forward_backward(shape, C, scope, precname):
+    prec = Precision.get(precname)
+    N, H, W_, Cp = shape
+    if scope == L.NORM_INSTANCE and H * W_ == 1:
+        pytest.skip('instance norm over a single pixel is degenerate (var = 0)')
+    y = torch.zeros(shape)
+    y[..., :C] = rnd((N, H, W_, C), 1, prec) * 1.7 + 0.3
+    res = torch.zeros(shape)
+    res[..., :C] = rnd((N, H, W_, C), 2, prec)
+    dz = torch.zeros(shape)
+    dz[..., :C] = rnd((N, H, W_, C), 3, prec)
+    affine = scope == L.NORM_BATCH
+    gamma = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(4))) if affine else None
+    beta = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(5))) if affine else None
+    fake, real = fake_backend.FakeBackend(), hip()
+    for act, use_res in ((L.ACT_RELU, False), (L.ACT_NONE, True), (L.ACT_LRELU, False)):
+        rm_f, rv_f = (torch.zeros(C), torch.ones(C)) if affine else (None, None)
+        rm_r, rv_r = (torch.zeros(C, device=DEV), torch.ones(C, device=DEV)) if affine else (None, None)
+        z_f = torch.empty(shape, dtype=prec.dtype)
+        st_f = fake.norm_forward(y.to(prec.dtype), z_f, C, scope, act, gamma, beta, rm_f, rv_f, 0.1 if affine else -1.0, res.to(prec.dtype) if use_res else None)
+        z_r = torch.empty(shape, dtype=prec.dtype, device=DEV)
+        g_r, b_r = (gamma.to(DEV), beta.to(DEV)) if affine else (None, None)
+        st_r = real.norm_forward(y.to(prec.dtype).to(DEV), z_r, C, scope, act, g_r, b_r, rm_r, rv_r, 0.1 if affine else -1.0,
+                                 res.to(prec.dtype).to(DEV) if use_res else None)
+        sync()
+        t = 2e-5 if precname == 'fp32' else 1e-2
+        assert rel(z_r, z_f) < t, ('z', act)
+        assert rel(st_r[0][:, :C], st_f[0][:, :C]) < 1e-4 and rel(st_r[1][:, :C], st_f[1][:, :C]) < 1e-4
+        if affine:
+            assert rel(rm_r, rm_f) < 1e-4 and rel(rv_r, rv_f) < 1e-4
+        dy_f = torch.empty(shape, dtype=prec.dtype)
+        dg_f, db_f = (torch.zeros(C), torch.zeros(C)) if affine else (None, None)
+        fake.norm_backward(dz.to(prec.dtype), y.to(prec.dtype), dy_f, st_f, C, scope, act, gamma, dg_f, db_f)
+        dy_r = torch.empty(shape, dtype=prec.dtype, device=DEV)
+        dg_r, db_r = (torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)) if affine else (None, None)
+        real.norm_backward(dz.to(prec.dtype).to(DEV), y.to(prec.dtype).to(DEV), dy_r, st_r, C, scope, act, g_r, dg_r, db_r)
+        sync()
+        assert rel(dy_r, dy_f) < (1e-4 if precname == 'fp32' else 2e-2), ('dy', act)
+        if affine:
+            assert rel(dg_r, dg_f) < 1e-3 and rel(db_r, db_f) < 1e-3
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_elementwise_family(precname):
+    prec = Precision.get(precname)
+    fake, real = fake_backend.FakeBackend(), hip()
+    shape = (2, 9, 11, 32)
+    a, b = rnd(shape, 1, prec), rnd(shape, 2, prec)
+    buf = rnd((2, 9, 11, 64), 3, prec)
+    t = 1e-6 if precname == 'fp32' else 8e-3
+    for act in (L.ACT_RELU, L.ACT_LRELU, L.ACT_TANH):
+        yf = torch.empty(shape, dtype=prec.dtype); fake.act_forward(act, a.to(prec.dtype), yf)
+        yr = torch.empty(shape, dtype=prec.dtype, device=DEV); real.act_forward(act, a.to(prec.dtype).to(DEV), yr)
+        assert rel(yr, yf) < t
+        df = torch.empty(shape, dtype=prec.dtype); fake.act_backward(act, b.to(prec.dtype), yf, df)
+        dr = torch.empty(shape, dtype=prec.dtype, device=DEV); real.act_backward(act, b.to(prec.dtype).to(DEV), yr, dr)
+        assert rel(dr, df) < 2 * t
+    # axpby into a channel slice of a wider buffer
+    bf_, br_ = buf.clone().to(prec.dtype), buf.clone().to(prec.dtype).to(DEV)
+    fake.axpby(0.25, a.to(prec.dtype), -1.5, b.to(prec.dtype), bf_[..., 32:])
+    real.axpby(0.25, a.to(prec.dtype).to(DEV), -1.5, b.to(prec.dtype).to(DEV), br_[..., 32:])
+    assert rel(br_, bf_) < t
+    # channel copies (cat / slice), 3 channels at offset 3
+    cf, cr = torch.zeros((2, 9, 11, 8), dtype=prec.dtype), torch.zeros((2, 9, 11, 8), dtype=prec.dtype, device=DEV)
+    fake.copy_channels(a.to(prec.dtype), 5, cf, 3, 3); real.copy_channels(a.to(prec.dtype).to(DEV), 5, cr, 3, 3)
+    fake.copy_channels(b.to(prec.dtype), 0, cf, 3, 3, True); real.copy_channels(b.to(prec.dtype).to(DEV), 0, cr, 3, 3, True)
+    assert rel(cr, cf) < t
+    # channel sums
+    sf, sr = torch.ones(20), torch.ones(20, device=DEV)
+    fake.channel_sum(a.to(prec.dtype), 20, sf, True); real.channel_sum(a.to(prec.dtype).to(DEV), 20, sr, True)
+    assert rel(sr, sf) < 1e-4
+    # layout converters
+    x = torch.randn(2, 3, 9, 11)
+    nf, nr = torch.ones((2, 9, 11, 8), dtype=prec.dtype), torch.ones((2, 9, 11, 8), dtype=prec.dtype, device=DEV)
+    fake.nchw_to_nhwc(x, nf, 0, 8); real.nchw_to_nhwc(x.to(DEV), nr, 0, 8)
+    assert torch.equal(nr.cpu(), nf)
+    of, orr = torch.empty(2, 3, 9, 11), torch.empty(2, 3, 9, 11, device=DEV)
+    fake.nhwc_to_nchw(nf, 0, of); real.nhwc_to_nchw(nr, 0, orr)
+    assert torch.equal(orr.cpu(), of)
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_losses(precname):
+    prec = Precision.get(precname)
+    fake, real = fake_backend.FakeBackend(), hip()
+    x = torch.zeros(2, 30, 30, 8); x[..., :1] = rnd((2, 30, 30, 1), 1, prec) * 3
+    a = torch.zeros(2, 16, 16, 8); a[..., :3] = rnd((2, 16, 16, 3), 2, prec)
+    b = torch.zeros(2, 16, 16, 8); b[..., :3] = rnd((2, 16, 16, 3), 3, prec) * 2
+    for kind, t, tgt, C, const in ((L.LOSS_BCE_LOGITS, x, None, 1, 1.0), (L.LOSS_BCE_LOGITS, x, None, 1, 0.0), (L.LOSS_MSE, x, None, 1, 1.0),
+                                   (L.LOSS_SMOOTH_L1, a, b, 3, 0.0)):
+        lf, lr = torch.zeros(1), torch.zeros(1, device=DEV)
+        gf = torch.empty(t.shape, dtype=prec.dtype)
+        gr = torch.full(t.shape, 7.0, dtype=prec.dtype, device=DEV)
+        fake.loss(kind, t.to(prec.dtype), tgt.to(prec.dtype) if tgt is not None else None, const, C, lf, gf, 0.37)
+        real.loss(kind, t.to(prec.dtype).to(DEV), tgt.to(prec.dtype).to(DEV) if tgt is not None else None, const, C, lr, gr, 0.37)
+        sync()
+        assert abs(float(lr) - float(lf)) < 1e-5 * max(1.0, abs(float(lf))), kind
+        assert rel(gr, gf) < (1e-5 if precname == 'fp32' else 8e-3), kind
+
+
+def test_adam_matches_torch():
+    n = 100003
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g) * 0.02
+    real = hip()
+    p_t = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_t], lr=2e-4, betas=(0.5, 0.999))
+    p_r = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 1e-3
+        p_t.grad = grad.clone()
+        opt.step()
+        real.adam_step(p_r, grad.to(DEV), m, v, 2e-4, 0.5, 0.999, 1e-8, step, 1.0)
+    sync()
+    assert float((p_r.cpu() - p_t.detach()).abs().max()) < 2e-8
