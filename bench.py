@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- DeepLIIF training-step throughput on MI355X (BASELINE.json metric: 512x512 tiles/s, train step 5G+5D).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = model.set_input(batch) + model.optimize_parameters() of the DeepLIIF model
+(modalities_no=5, seg_gen=False -> 5 x ResnetGenerator-9block + 5 x NLayerDiscriminator(n=4), GAN + SmoothL1, Adam) on a
+batch of 8 synthetic 512x512x3 tiles per GPU that is already resident in HBM (BASELINE.json configs[2] per GPU; weak
+scaling).  `--workload infer` times the 9-generator inference DAG of configs[1] instead (4 Resnet-9 + 5 UNet-512, batch 8).
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : dominant kernel = conv_gemm 128x128x64 (3x3, 256->256 ch, 8x128x128 pixels: the 18 ResnetBlock convs and
+                 their data-gradients), per-launch time from HIP events recorded on the launch stream inside the timed region
+  cpu_baseline : the CPU oracle (oracle/deepliif_oracle.py, a port of the reference's PyTorch step) timed on this box's host
+                 cores for ONE step at batch 1 (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GF_PER_TILE_TRAIN_5R5D = 6817.0      # BASELINE.md / SURVEY 8(d): conv MACs only, FLOP = 2*MAC
+GF_PER_TILE_INFER = 1828.0
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_opt(args, device_index):
+    M = 5
+    w = [1.0 / (M + 1)] * (M + 1)      # cli.py:349-371 defaults for modalities_no != 4
+    return types.SimpleNamespace(
+        model='DeepLIIF', name='bench', checkpoints_dir='/tmp/dl_amd_bench', gpu_ids=[device_index], is_train=True, phase='train',
+        continue_train=False, modalities_no=M, seg_gen=False, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=64, ndf=64,
+        net_g='resnet_9blocks', net_gs='unet_512', net_d='n_layers', n_layers_D=4, norm=args.norm, no_dropout=True, init_type='normal',
+        init_gain=0.02, padding='zero', upsample='convtranspose', gan_mode='vanilla', gan_mode_s='lsgan', optimizer='adam', lr_g=2e-4,
+        lr_d=2e-4, beta1=0.5, lr_policy='linear', n_epochs=100, n_epochs_decay=100, epoch_count=0, seg_weights=w, loss_G_weights=w,
+        loss_D_weights=w, lambda_L1=100.0, verbose=False, epoch='latest', load_iter=0, precision=args.precision)
+
+
+class KernelTimer:
+    """Records HIP events around every launch of the dominant conv kernel (on the stream the kernel is launched on)."""
+
+    def __init__(self, backend, shape):
+        self.backend, self.shape, self.pairs, self.enabled = backend, tuple(shape), [], False
+        self._orig = backend.conv_forward
+        backend.conv_forward = self._wrapped
+
+    def _wrapped(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None):
+        hit = self.enabled and tuple(x.shape) == self.shape and tuple(out.shape) == self.shape and packed.plan.n_phase == 1
+        if hit:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+        self._orig(packed, x, out, hq, wq, bias, act, in_act, prec, splitk)
+        if hit:
+            e.record()
+            self.pairs.append((s, e))
+
+    def mean_seconds(self):
+        if not self.pairs:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs) * 1e-3
+
+
+def cpu_baseline(args):
+    """One optimize_parameters() step of the CPU oracle at batch 1, 512x512, same model family (random init)."""
+    from oracle import deepliif_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.OracleConfig(modalities_no=5, seg_gen=False, norm=args.norm, padding='zero', ngf=64, ndf=64)
+    g = torch.Generator().manual_seed(0)
+    nets = {}
+    for i in range(1, 6):
+        nets[f'G{i}'] = O.random_state_dict('resnet_9blocks', 3, 3, 64, args.norm, 'zero', generator=g)
+        nets[f'D{i}'] = O.random_state_dict('n_layers', 6, 3, 64, args.norm, 'zero', 4, generator=g)
+    om = O.OracleDeepLIIF(cfg, nets)
+    A = torch.rand(1, 3, args.size, args.size, generator=g) * 2 - 1
+    B = [torch.rand(1, 3, args.size, args.size, generator=g) * 2 - 1 for _ in range(5)]
+    om.set_input({'A': A, 'B': B})
+    t0 = time.time()
+    om.optimize_parameters()
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'tiles/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 optimize_parameters() step of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, '
+                      f'{args.size}x{args.size}, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='tiles per GPU per step')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp32_bf16mma'])
+    ap.add_argument('--norm', default='instance', choices=['instance', 'batch'])
+    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from deepliif_amd import distributed as D
+    from deepliif_amd import models as M
+    from deepliif_amd import ops
+    rank, world, local_rank = D.init_process_group_from_env('nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    sys.stdout = open(os.devnull, 'w')      # the model classes print like the reference does; the contract is ONE JSON line
+
+    torch.manual_seed(0)
+    opt = make_opt(args, local_rank)
+    n, s = args.batch, args.size
+
+    def synth(seed):
+        g = torch.Generator().manual_seed(seed + 1000 * rank)       # distinct tiles per rank (data-parallel shards)
+        return (torch.rand(n, 3, s, s, generator=g) * 2 - 1).to(dev)
+
+    if args.workload == 'train':
+        model = M.create_model(opt)
+        model.setup(opt)
+        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}
+
+        def step():
+            model.set_input(batch)
+            model.optimize_parameters()
+        gf_per_tile = GF_PER_TILE_TRAIN_5R5D
+        dom_shape = (n, s // 4, s // 4, 256)
+        workload = 'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
+    else:
+        from deepliif_amd import inference as I
+        iopt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3,
+                                     ngf=64, norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_512', input_no=1,
+                                     modalities_names=['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], gpu_ids=[local_rank])
+        nets = I.build_generators(iopt, dev, args.precision)
+        tiles = synth(1234)
+
+        def step():
+            I.run_generators(tiles, nets, iopt, seg_weights=[0.25, 0.15, 0.25, 0.1, 0.25])
+        gf_per_tile = GF_PER_TILE_INFER
+        dom_shape = (n, s // 4, s // 4, 256)
+        workload = 'DeepLIIF inference, 4x Resnet-9block + 5x UNet-512 generators + weighted seg sum (BASELINE configs[1])'
+
+    timer = KernelTimer(ops.impl(), dom_shape)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    tiles_total = args.steps * n * world
+    value = tiles_total / dt
+    kt = timer.mean_seconds()
+    flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * 256 * 256 * 9
+    roofline = None
+    if kt:
+        ach = flops_per_launch / kt / 1e12
+        roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                    'traffic': None, 'kernel': 'conv_gemm_kernel<128x128x64> 3x3 256->256 @ 8x128x128 (ResnetBlock conv fwd + dgrad)',
+                    'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
+    out = {
+        'metric': '512x512 tiles/s train-step (5G+5D)' if args.workload == 'train' else '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)',
+        'value': round(value, 3), 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if args.precision == 'bf16' else ('f32(split-bf16x3 MFMA)' if args.precision == 'fp32' else 'f32 storage/bf16 MFMA'),
+        'data': 'synthetic U(-1,1) tiles (seeds 1234..), N(0,0.02) random-init weights (torch.manual_seed(0)), dropout off, VGG loss off',
+        'config': {'workload': workload, 'tile': f'{s}x{s}x3', 'batch_per_gpu': n, 'global_batch': n * world, 'norm': args.norm,
+                   'precision_policy': args.precision, 'parallelism': f'dp{world}'},
+        'model_tflops': round(value * gf_per_tile / 1e3, 1),
+        'model_frac_of_bf16_peak': round(value * gf_per_tile / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+        'roofline': roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train':
+        out['cpu_baseline'] = cpu_baseline(args)
+    else:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        sys.stdout = sys.__stdout__
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -61,7 +61,8 @@ def test_probe_mfma_fragment_layout():
     a = torch.randn(16, 32, generator=g).bfloat16()
     b = torch.randn(32, 16, generator=g).bfloat16()       # asymmetric operands: catches row/col swaps
     d = torch.zeros(16, 16, device=DEV)
-    L.check(lib.dl_probe_mfma16(a.to(DEV).data_ptr(), b.to(DEV).data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
+    ad, bd = a.to(DEV), b.to(DEV)          # keep the device copies alive across the launch
+    L.check(lib.dl_probe_mfma16(ad.data_ptr(), bd.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
     sync()
     assert rel(d, a.float() @ b.float()) < 1e-5
 
@@ -73,7 +74,8 @@ def test_probe_ds_read_tr16_b64():
     lib = L.load()
     src = torch.arange(64 * 16, dtype=torch.int16).view(64, 16)
     dst = torch.zeros(64, 4, dtype=torch.int16, device=DEV)
-    L.check(lib.dl_probe_trread(src.to(DEV).data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
+    sd = src.to(DEV)
+    L.check(lib.dl_probe_trread(sd.data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream), 'probe')
     sync()
     dst = dst.cpu()
     exp = torch.zeros(64, 4, dtype=torch.int16)
