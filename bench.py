@@ -68,26 +68,59 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs) * 1e-3
 
 
-def cpu_baseline(args):
-    """One optimize_parameters() step of the CPU oracle at batch 1, 512x512, same model family (random init)."""
+def usable_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_child(norm, size):
+    """(child process) one optimize_parameters() step of the CPU oracle at batch 1, same model family, random init."""
     from oracle import deepliif_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    cfg = O.OracleConfig(modalities_no=5, seg_gen=False, norm=args.norm, padding='zero', ngf=64, ndf=64)
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(modalities_no=5, seg_gen=False, norm=norm, padding='zero', ngf=64, ndf=64)
     g = torch.Generator().manual_seed(0)
     nets = {}
     for i in range(1, 6):
-        nets[f'G{i}'] = O.random_state_dict('resnet_9blocks', 3, 3, 64, args.norm, 'zero', generator=g)
-        nets[f'D{i}'] = O.random_state_dict('n_layers', 6, 3, 64, args.norm, 'zero', 4, generator=g)
+        nets[f'G{i}'] = O.random_state_dict('resnet_9blocks', 3, 3, 64, norm, 'zero', generator=g)
+        nets[f'D{i}'] = O.random_state_dict('n_layers', 6, 3, 64, norm, 'zero', 4, generator=g)
     om = O.OracleDeepLIIF(cfg, nets)
-    A = torch.rand(1, 3, args.size, args.size, generator=g) * 2 - 1
-    B = [torch.rand(1, 3, args.size, args.size, generator=g) * 2 - 1 for _ in range(5)]
+    A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    B = [torch.rand(1, 3, size, size, generator=g) * 2 - 1 for _ in range(5)]
     om.set_input({'A': A, 'B': B})
     t0 = time.time()
     om.optimize_parameters()
     dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'tiles/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 optimize_parameters() step of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, '
-                      f'{args.size}x{args.size}, {dt:.1f} s'}
+    print(json.dumps({'seconds': dt, 'cores': cores, 'size': size}), flush=True)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port of the reference's PyTorch training step) timed on this box's host cores: ONE step at batch 1
+    (the reference's default batch size, cli.py:110).  Runs in a child process with a time limit so that a slow / oversubscribed
+    host cannot stall the benchmark; falls back to a 256x256 tile (reported in 512x512-tile equivalents) if 512x512 does not
+    finish in time."""
+    import subprocess
+    for size, limit in ((args.size, 240), (args.size // 2, 180)):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--norm', args.norm, '--size', str(size)],
+                               capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+            d = json.loads(line)
+        except Exception as e:            # timeout / crash: try the smaller sample, else report nothing
+            last = f'{type(e).__name__}'
+            continue
+        scale = (size * size) / float(args.size * args.size)
+        return {'value': round(scale / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
+                'sample': f"1 optimize_parameters() step of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, "
+                          f"{size}x{size} tile, {d['seconds']:.1f} s" + ('' if size == args.size else f' (scaled to {args.size}x{args.size}-tile units by pixel count)')}
+    return {'value': None, 'unit': 'tiles/s', 'cores': usable_cores(), 'kind': 'port', 'sample': f'CPU oracle step did not finish within the time limit ({last})'}
 
 
 def main():
@@ -101,7 +134,10 @@ def main():
     ap.add_argument('--norm', default='instance', choices=['instance', 'batch'])
     ap.add_argument('--workload', default='train', choices=['train', 'infer'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.norm, args.size)
 
     from deepliif_amd import distributed as D
     from deepliif_amd import models as M

@@ -151,12 +151,22 @@ __global__ void __launch_bounds__(256) channel_sum_partial_kernel(const T *x, in
         __syncthreads();
     }
 }
+// block = 32 channels x 8 partial lanes
 __global__ void __launch_bounds__(256) channel_sum_final_kernel(const float *part, int nblocks, int Cp, int C, float *out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)part[(size_t)b * Cp + c];
-    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int b = kl; b < nblocks; b += 8) s += part[(size_t)b * Cp + c];
+    red[kl][cl] = s;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += (double)red[r][cl];
+        out[c] = (accumulate ? out[c] : 0.f) + (float)a;
+    }
 }
 extern "C" int dl_channel_sum(int dtype, const void *x, int ps, int64_t npix, int Cp, int C, float *out, int accumulate, float *ws,
                               void *stream_) {
@@ -165,7 +175,7 @@ extern "C" int dl_channel_sum(int dtype, const void *x, int ps, int64_t npix, in
     if (dtype == DL_F32) hipLaunchKernelGGL(channel_sum_partial_kernel<float>, dim3(CS_BLOCKS), dim3(256), 0, stream, (const float *)x, ps, (size_t)npix, Cp, ws);
     else hipLaunchKernelGGL(channel_sum_partial_kernel<bf16_t>, dim3(CS_BLOCKS), dim3(256), 0, stream, (const bf16_t *)x, ps, (size_t)npix, Cp, ws);
     DL_CHECK_LAUNCH("dl_channel_sum(partial)");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, ws, CS_BLOCKS, Cp, C, out, accumulate);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, ws, CS_BLOCKS, Cp, C, out, accumulate);
     DL_CHECK_LAUNCH("dl_channel_sum(final)");
     return 0;
 }

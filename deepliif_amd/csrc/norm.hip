@@ -23,7 +23,7 @@ static NormGeom make_geom(const dl_norm_desc *d) {
 
 extern "C" size_t dl_norm_ws_floats(const dl_norm_desc *d) {
     NormGeom g = make_geom(d);
-    return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)2 * g.N * g.Cp + 64;
+    return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)4 * g.N * g.Cp + 64;    // partials | chunk sums | c1 | c2
 }
 
 // MODE 0: forward statistics  (s1 = sum y, s2 = sum y^2)
@@ -97,8 +97,34 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const T *y, int y_ps,
     }
 }
 
+// stage A of both finalizers: S[n][0|1][c] = sum over the image's chunks of the per-block partials.
+// block = 32 channels x 8 chunk lanes; grid = (Cp/32 rounded up, N)
+__global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums) {
+    __shared__ float red[2][8][33];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < g.Cp) {
+        for (int k = kl; k < g.nchunks; k += 8) {
+            const float *o = part + ((size_t)(n * g.nchunks + k) * 2) * g.Cp + c;
+            s1 += o[0];
+            s2 += o[g.Cp];
+        }
+    }
+    red[0][kl][cl] = s1;
+    red[1][kl][cl] = s2;
+    __syncthreads();
+    if (kl == 0 && c < g.Cp) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a1 += (double)red[0][r][cl]; a2 += (double)red[1][r][cl]; }
+        sums[((size_t)n * 2) * g.Cp + c] = (float)a1;
+        sums[((size_t)n * 2 + 1) * g.Cp + c] = (float)a2;
+    }
+}
+
 // forward finalize: one thread per channel (batch) or per (n, channel) (instance)
-__global__ void __launch_bounds__(256) norm_fwd_finalize_kernel(const float *part, NormGeom g, int scope, float eps, const float *gamma,
+__global__ void __launch_bounds__(256) norm_fwd_finalize_kernel(const float *sums, NormGeom g, int scope, float eps, const float *gamma,
                                                                 const float *beta, float *running_mean, float *running_var, float momentum,
                                                                 float *mean, float *rstd, float *scale, float *shift) {
     const int total = (scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
@@ -108,12 +134,10 @@ __global__ void __launch_bounds__(256) norm_fwd_finalize_kernel(const float *par
     const int n0 = (scope == DL_NORM_BATCH) ? 0 : i / g.Cp;
     const int n1 = (scope == DL_NORM_BATCH) ? g.N : n0 + 1;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = n0; n < n1; ++n)
-        for (int k = 0; k < g.nchunks; ++k) {
-            const float *o = part + ((size_t)(n * g.nchunks + k) * 2) * g.Cp + c;
-            s1 += (double)o[0];
-            s2 += (double)o[g.Cp];
-        }
+    for (int n = n0; n < n1; ++n) {
+        s1 += (double)sums[((size_t)n * 2) * g.Cp + c];
+        s2 += (double)sums[((size_t)n * 2 + 1) * g.Cp + c];
+    }
     const double cnt = (double)(n1 - n0) * g.HW;
     const double mu = s1 / cnt;
     double var = s2 / cnt - mu * mu;
@@ -135,43 +159,46 @@ __global__ void __launch_bounds__(256) norm_fwd_finalize_kernel(const float *par
     }
 }
 
+// z = act(y*scale + shift) (+res): each thread owns one 8-channel column of one image (per-channel constants live in
+// registers) and walks down the pixels; grid = (pixel blocks, N)
 template <typename T>
 __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, const float *scale, const float *shift, const T *res, int r_ps,
                                                          T *z, int z_ps, NormGeom g, int act) {
     const int cvec = g.Cp / 8;
-    const size_t total = (size_t)g.N * g.HW * cvec;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = i / cvec;
-        const int c0 = (int)(i % cvec) * 8;
-        const int n = (int)(pix / g.HW);
-        float v[8];
-        Vec8<T>::load(y + pix * y_ps + c0, v);
-        const float *sc = scale + n * g.Cp + c0, *sh = shift + n * g.Cp + c0;
+    const int n = blockIdx.y;
+    for (int cbase = 0; cbase < cvec; cbase += 256) {
+        const int tpp = min(cvec - cbase, 256), rows = 256 / tpp;
+        const int col = threadIdx.x % tpp, row = threadIdx.x / tpp;
+        if (row >= rows) continue;
+        const int c0 = (cbase + col) * 8;
+        float sc[8], sh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = apply_act(act, v[k] * sc[k] + sh[k]);
-        if (res) {
-            float r[8];
-            Vec8<T>::load(res + pix * r_ps + c0, r);
+        for (int k = 0; k < 8; ++k) { sc[k] = scale[n * g.Cp + c0 + k]; sh[k] = shift[n * g.Cp + c0 + k]; }
+        for (int p = blockIdx.x * rows + row; p < g.HW; p += gridDim.x * rows) {
+            const size_t pix = (size_t)n * g.HW + p;
+            float v[8];
+            Vec8<T>::load(y + pix * y_ps + c0, v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += r[k];
+            for (int k = 0; k < 8; ++k) v[k] = apply_act(act, v[k] * sc[k] + sh[k]);
+            if (res) {
+                float r[8];
+                Vec8<T>::load(res + pix * r_ps + c0, r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += r[k];
+            }
+            Vec8<T>::store(z + pix * z_ps + c0, v);
         }
-        Vec8<T>::store(z + pix * z_ps + c0, v);
     }
 }
 
-// backward finalize: c1 = S1/m, c2 = S2/m per (n,c); dgamma/dbeta per channel
-__global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float *part, NormGeom g, int scope, float *c1, float *c2,
+// backward finalize: c1 = S1/m, c2 = S2/m per (n,c); dgamma/dbeta per channel.  One thread per channel, N is small.
+__global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float *sums, NormGeom g, int scope, float *c1, float *c2,
                                                                 float *dgamma, float *dbeta, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.Cp) return;
     double t1 = 0.0, t2 = 0.0;
     for (int n = 0; n < g.N; ++n) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < g.nchunks; ++k) {
-            const float *o = part + ((size_t)(n * g.nchunks + k) * 2) * g.Cp + c;
-            s1 += (double)o[0];
-            s2 += (double)o[g.Cp];
-        }
+        const double s1 = (double)sums[((size_t)n * 2) * g.Cp + c], s2 = (double)sums[((size_t)n * 2 + 1) * g.Cp + c];
         t1 += s1; t2 += s2;
         if (scope == DL_NORM_INSTANCE) { c1[n * g.Cp + c] = (float)(s1 / g.HW); c2[n * g.Cp + c] = (float)(s2 / g.HW); }
     }
@@ -185,33 +212,55 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float *par
     }
 }
 
+// dy = gamma*rstd*(dn - c1 - xhat*c2): same thread->column ownership as norm_apply_kernel
 template <typename T>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz_ps, const T *y, int y_ps, const float *gamma,
                                                              const float *mean, const float *rstd, const float *scale, const float *shift,
                                                              const float *c1, const float *c2, T *dy, int dy_ps, NormGeom g, int act) {
     const int cvec = g.Cp / 8;
-    const size_t total = (size_t)g.N * g.HW * cvec;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = i / cvec;
-        const int c0 = (int)(i % cvec) * 8;
-        const int n = (int)(pix / g.HW);
-        float v[8], d[8], o[8];
-        Vec8<T>::load(y + pix * y_ps + c0, v);
-        Vec8<T>::load(dz + pix * dz_ps + c0, d);
-        const int b = n * g.Cp + c0;
+    const int n = blockIdx.y;
+    for (int cbase = 0; cbase < cvec; cbase += 256) {
+        const int tpp = min(cvec - cbase, 256), rows = 256 / tpp;
+        const int col = threadIdx.x % tpp, row = threadIdx.x / tpp;
+        if (row >= rows) continue;
+        const int c0 = (cbase + col) * 8;
+        float sc[8], sh[8], rs[8], mr[8], k1[8], k2[8], gr[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float nv = v[k] * scale[b + k] + shift[b + k];
-            float dn = d[k];
-            if (act == DL_ACT_RELU) dn = nv > 0.f ? dn : 0.f;
-            else if (act == DL_ACT_LRELU) dn = nv > 0.f ? dn : 0.2f * dn;
-            else if (act == DL_ACT_TANH) { const float t = tanhf(nv); dn *= 1.f - t * t; }
-            const float xh = (v[k] - mean[b + k]) * rstd[b + k];
+            const int b = n * g.Cp + c0 + k;
+            sc[k] = scale[b]; sh[k] = shift[b]; rs[k] = rstd[b]; mr[k] = -mean[b] * rstd[b]; k1[k] = c1[b]; k2[k] = c2[b];
             const float ga = (c0 + k < g.C) ? (gamma ? gamma[c0 + k] : 1.f) : 0.f;
-            o[k] = ga * rstd[b + k] * (dn - c1[b + k] - xh * c2[b + k]);
+            gr[k] = ga * rs[k];
         }
-        Vec8<T>::store(dy + pix * dy_ps + c0, o);
+        for (int p = blockIdx.x * rows + row; p < g.HW; p += gridDim.x * rows) {
+            const size_t pix = (size_t)n * g.HW + p;
+            float v[8], d[8], o[8];
+            Vec8<T>::load(y + pix * y_ps + c0, v);
+            Vec8<T>::load(dz + pix * dz_ps + c0, d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float nv = v[k] * sc[k] + sh[k];
+                float dn = d[k];
+                if (act == DL_ACT_RELU) dn = nv > 0.f ? dn : 0.f;
+                else if (act == DL_ACT_LRELU) dn = nv > 0.f ? dn : 0.2f * dn;
+                else if (act == DL_ACT_TANH) { const float t = tanhf(nv); dn *= 1.f - t * t; }
+                const float xh = v[k] * rs[k] + mr[k];
+                o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
+            }
+            Vec8<T>::store(dy + pix * dy_ps + c0, o);
+        }
     }
+}
+
+// grid of the apply kernels: (pixel blocks per image, N); ~16 pixels per thread, at least enough blocks to fill 256 CUs
+static dim3 apply_grid(const NormGeom &g) {
+    const int cvec = g.Cp / 8;
+    const int rows = 256 / (cvec < 256 ? cvec : 256);
+    int bx = (g.HW + rows * 16 - 1) / (rows * 16);
+    const int want = (2048 + g.N - 1) / g.N;
+    if (bx > want) bx = want;
+    if (bx < 1) bx = 1;
+    return dim3(bx, g.N);
 }
 
 static int check_desc(const dl_norm_desc *d, const char *who) {
@@ -237,17 +286,19 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
         hipLaunchKernelGGL((norm_partial_kernel<bf16_t, 0>), dim3(pblocks), dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride,
                            (const bf16_t *)nullptr, 0, g, 0, nullptr, nullptr, nullptr, nullptr, ws);
     DL_CHECK_LAUNCH("dl_norm_forward(stats)");
+    float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
+    hipLaunchKernelGGL(norm_chunk_sum_kernel, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums);
+    DL_CHECK_LAUNCH("dl_norm_forward(chunk sums)");
     const int ftotal = (d->scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
-    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, ws, g, d->scope, d->eps, gamma, beta,
+    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, d->eps, gamma, beta,
                        running_mean, running_var, d->momentum, mean, rstd, scale, shift);
     DL_CHECK_LAUNCH("dl_norm_forward(finalize)");
-    const size_t total = (size_t)g.N * g.HW * (g.Cp / 8);
-    const int blocks = (int)min((size_t)8192, (total + 255) / 256);
+    const dim3 blocks = apply_grid(g);
     if (d->dtype == DL_F32)
-        hipLaunchKernelGGL(norm_apply_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)y, d->y_pstride, scale, shift,
+        hipLaunchKernelGGL(norm_apply_kernel<float>, blocks, dim3(256), 0, stream, (const float *)y, d->y_pstride, scale, shift,
                            (const float *)residual, d->r_pstride, (float *)z, d->z_pstride, g, d->act);
     else
-        hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride, scale, shift,
+        hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, blocks, dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride, scale, shift,
                            (const bf16_t *)residual, d->r_pstride, (bf16_t *)z, d->z_pstride, g, d->act);
     DL_CHECK_LAUNCH("dl_norm_forward(apply)");
     return 0;
@@ -261,7 +312,8 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
     if (!dz || !y || !dy || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
     const NormGeom g = make_geom(d);
     float *part = ws;
-    float *c1 = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
+    float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
+    float *c1 = sums + (size_t)2 * g.N * g.Cp;
     float *c2 = c1 + (size_t)g.N * g.Cp;
     const int pblocks = g.N * g.nchunks;
     // dz uses z_pstride, dy uses r_pstride slot of the desc (documented in ops.py): keep explicit names here
@@ -273,16 +325,17 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
         hipLaunchKernelGGL((norm_partial_kernel<bf16_t, 1>), dim3(pblocks), dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride,
                            (const bf16_t *)dz, dz_ps, g, d->act, mean, rstd, scale, shift, part);
     DL_CHECK_LAUNCH("dl_norm_backward(reduce)");
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, part, g, d->scope, c1, c2, dgamma, dbeta,
+    hipLaunchKernelGGL(norm_chunk_sum_kernel, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums);
+    DL_CHECK_LAUNCH("dl_norm_backward(chunk sums)");
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, c1, c2, dgamma, dbeta,
                        accumulate_affine);
     DL_CHECK_LAUNCH("dl_norm_backward(finalize)");
-    const size_t total = (size_t)g.N * g.HW * (g.Cp / 8);
-    const int blocks = (int)min((size_t)8192, (total + 255) / 256);
+    const dim3 blocks = apply_grid(g);
     if (d->dtype == DL_F32)
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *)dz, dz_ps, (const float *)y,
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, blocks, dim3(256), 0, stream, (const float *)dz, dz_ps, (const float *)y,
                            d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (float *)dy, dy_ps, g, d->act);
     else
-        hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t *)dz, dz_ps, (const bf16_t *)y,
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, blocks, dim3(256), 0, stream, (const bf16_t *)dz, dz_ps, (const bf16_t *)y,
                            d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, d->act);
     DL_CHECK_LAUNCH("dl_norm_backward(apply)");
     return 0;
