@@ -10,6 +10,7 @@
 // Pipeline: register-staged double buffer (global loads of tile t+1 are issued before the MFMAs of tile t and written
 // to the other LDS buffer after them), one barrier per K step.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const void *in;
@@ -307,6 +308,247 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: both tiles go HBM -> LDS directly (global_load_lds_dwordx4, 16 B per lane), no VGPR round trip, no
+// ds_write pass.  The LDS image of a wave-instruction is lane-linear (M0 base + lane*16), so the XOR chunk swizzle is
+// applied on the SOURCE side: the lane that fills LDS slot (row, c') fetches global chunk c' ^ f(row) of that row; the
+// fragment reads use the same involution.  Zero padding = lanes point at a zero page.  Two LDS buffers: the DMA of tile
+// t+1 is issued before the MFMAs of tile t and drained (vmcnt(0)) at the single barrier per K step.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
+
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP>
+__global__ void __launch_bounds__(256) conv_gemm_glds_kernel(const ConvArgs a) {
+    constexpr int CPR = BK / 8;                        // 16-byte chunks per LDS row
+    constexpr int RPI = 64 / CPR;                      // tile rows filled by one wave-instruction
+    constexpr int X_INS = (BM + 4 * RPI - 1) / (4 * RPI);   // glds instructions per wave, activation tile
+    constexpr int W_INS = (BN + 4 * RPI - 1) / (4 * RPI);
+    constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
+    constexpr int XT = BM * BK, WT = BN * BK, BUF = XT + WT;
+    static_assert(WM * WN == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+    int16_t *tap_lds = reinterpret_cast<int16_t *>(smem + 2 * BUF);
+    int *tapd_lds = reinterpret_cast<int *>(tap_lds + DL_MAX_TAPS);     // element offset (dh*Wi + dw)*pstride of every tap
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
+    const int phase = blockIdx.y / a.splitk, ks = blockIdx.y % a.splitk;
+    const int tap0 = a.phase_tap_begin[phase];
+    const int ntaps = a.phase_tap_begin[phase + 1] - tap0;
+    const int kbase = a.phase_kbase[phase];
+    const int nk_total = (ntaps * a.Ci + 63) / 64 * 64 / BK;
+    const int nk_per = (nk_total + a.splitk - 1) / a.splitk;
+    const int kt_begin = ks * nk_per;
+    const int kt_end = min(nk_total, kt_begin + nk_per);
+
+    if (tid < DL_MAX_TAPS) {
+        const int16_t tp = a.taps[tid];
+        tap_lds[tid] = tp;
+        tapd_lds[tid] = ((int)(int8_t)(tp & 0xff) * a.Wi + (int)(int8_t)((tp >> 8) & 0xff)) * a.in_pstride;
+    }
+
+    const bf16_t *in = reinterpret_cast<const bf16_t *>(a.in);
+    const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_zero_page);
+    const int HWq = a.Hq * a.Wq;
+    const int lrow = lane / CPR, lcp = lane % CPR;    // row within the instruction's slab, LDS chunk position
+
+    // ---- per-thread geometry: row r_i = (wave * X_INS + i) * RPI + lrow of the activation tile
+    const bf16_t *x_ptr[X_INS];          // base pixel + this lane's swizzled chunk offset
+    int x_hi0[X_INS], x_wi0[X_INS], x_chunk[X_INS];
+    bool x_ok[X_INS];
+    unsigned long long x_mask[X_INS];    // bit t: tap (tap0 + t) of this row is inside the image (zero padding)
+#pragma unroll
+    for (int i = 0; i < X_INS; ++i) {
+        const int row = (wave * X_INS + i) * RPI + lrow;
+        const int m = tm * BM + row;
+        x_ok[i] = (row < BM) && (m < a.Mtot);
+        const int mm = x_ok[i] ? m : 0;
+        const int n = mm / HWq, rem = mm - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        x_hi0[i] = hq * a.in_step;
+        x_wi0[i] = wq * a.in_step;
+        x_chunk[i] = swz_chunk<CPR>(row, lcp);        // global chunk this lane fetches for its LDS slot
+        x_ptr[i] = in + ((size_t)(n * a.Hi + x_hi0[i]) * a.Wi + x_wi0[i]) * (size_t)a.in_pstride + x_chunk[i] * 8;
+        unsigned long long mk = 0;
+        if (UTAP && x_ok[i]) {               // (the generic path checks bounds per chunk instead: many taps, short K loops)
+            for (int t = 0; t < ntaps; ++t) {
+                const int16_t tp = a.taps[tap0 + t];
+                const int hi = x_hi0[i] + (int)(int8_t)(tp & 0xff), wi = x_wi0[i] + (int)(int8_t)((tp >> 8) & 0xff);
+                if (a.pad_mode == DL_PAD_REFLECT || (((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi))) mk |= 1ull << t;
+            }
+        }
+        x_mask[i] = mk;
+    }
+    const bf16_t *w_ptr[W_INS];
+#pragma unroll
+    for (int i = 0; i < W_INS; ++i) {
+        const int row = (wave * W_INS + i) * RPI + lrow;
+        const int c = swz_chunk<CPR>(row, lcp);
+        // rows beyond the tile (narrow-N configs) re-read row 0: their LDS slots are never consumed
+        w_ptr[i] = a.w_hi + (size_t)(tn * BN + (row < BN ? row : 0)) * a.w_kstride + kbase + c * 8 + (size_t)kt_begin * BK;
+    }
+
+    int tapd_next = 0;                   // pixel offset of the tap of the NEXT tile to issue (read from LDS one step ahead)
+    auto issue_tile = [&](int kt, int buf) {
+        bf16_t *base = smem + buf * BUF;
+        if constexpr (UTAP) {
+            // every chunk of this K step belongs to ONE tap (Ci >= BK): the tap and the channel base are wave-uniform
+            const int kb = kt * BK;
+            const int tl = kb >> a.log2Ci;
+            const ptrdiff_t delta = (ptrdiff_t)tapd_next + (kb & (a.Ci - 1));
+            const int tl2 = min((kb + BK) >> a.log2Ci, ntaps - 1);
+            tapd_next = tapd_lds[tap0 + tl2];    // consumed by the next call: its LDS latency hides behind this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < X_INS; ++i) {
+                const int row0 = (wave * X_INS + i) * RPI;
+                if (row0 < BM) {
+                    const bool ok = (x_mask[i] >> tl) & 1ull;
+                    const bf16_t *src = ok ? x_ptr[i] + delta : zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(base + row0 * BK), 16, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < X_INS; ++i) {
+                const int row0 = (wave * X_INS + i) * RPI;
+                if (row0 < BM) {
+                    const int k0 = kt * BK + x_chunk[i] * 8;
+                    const int tl = k0 >> a.log2Ci;
+                    const int ci = k0 & (a.Ci - 1);
+                    const int tli = tl < ntaps ? tl : 0;
+                    const int16_t t = tap_lds[tap0 + tli];
+                    const int dh = (int)(int8_t)(t & 0xff), dw = (int)(int8_t)((t >> 8) & 0xff);
+                    int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
+                    if (a.pad_mode == DL_PAD_REFLECT) { hi = reflect_idx(hi, a.Hi); wi = reflect_idx(wi, a.Wi); }
+                    const bool ok = x_ok[i] && (tl < ntaps) && ((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi);
+                    const ptrdiff_t off = ((ptrdiff_t)(hi - x_hi0[i]) * a.Wi + (wi - x_wi0[i])) * (ptrdiff_t)a.in_pstride + ci - x_chunk[i] * 8;
+                    const bf16_t *src = ok ? x_ptr[i] + off : zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(base + row0 * BK), 16, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_INS; ++i) {
+            const int row0 = (wave * W_INS + i) * RPI;
+            if (row0 < BN) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[i] + (size_t)(kt - kt_begin) * BK),
+                                                 (__attribute__((address_space(3))) void *)(base + XT + row0 * BK), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();     // tap tables visible
+    if constexpr (UTAP) tapd_next = tapd_lds[tap0 + min((kt_begin * BK) >> a.log2Ci, ntaps - 1)];
+    if (kt_begin < kt_end) issue_tile(kt_begin, 0);
+    __syncthreads();     // drains the DMA (vmcnt(0)) + barrier
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment offsets: row = 16*j + fr (+ wave base, multiples of 16) so the swizzle term depends on the lane only;
+    // per kk the chunk is (kk*4 + fg) ^ s  ->  two lane-constant element offsets, everything else is an immediate
+    int foff[BK / 32];
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) foff[kk] = (fr * CPR + swz_chunk<CPR>(fr, kk * 4 + fg)) * 8;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);
+        const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t wf[FN], xf[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t *>(Ws + (wn * PN + i * 16) * BK + foff[kk]);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) xf[j] = *reinterpret_cast<const bf16x8_t *>(Xs + (wm * PM + j * 16) * BK + foff[kk]);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to the register-staged kernel)
+    const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = tm * BM + wm * PM + j * 16 + fr;
+        if (m >= a.Mtot) continue;
+        const int n = m / HWq, rem = m - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int co = tn * BN + wn * PN + i * 16 + fg * 4;
+            if (co >= a.Co) continue;
+            f32x4_t v = acc[i][j];
+            if (a.splitk > 1) {
+                float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
+                }
+                if (a.act != DL_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(a.act, v[r]);
+                }
+                bf16_t *dst = reinterpret_cast<bf16_t *>(a.out) + opix * a.out_pstride + co;
+                u32x2_t p;
+                p[0] = pack2_bf16(v[0], v[1]);
+                p[1] = pack2_bf16(v[2], v[3]);
+                *reinterpret_cast<u32x2_t *>(dst) = p;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP>
+static int launch_conv_glds_impl(const ConvArgs &a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.Mtot + BM - 1) / BM;
+    a.tiles_n = (a.Co + BN - 1) / BN;
+    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * (sizeof(int16_t) + sizeof(int));
+    auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_forward: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.n_phase * a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_forward(glds)");
+    return 0;
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_conv_glds(const ConvArgs &a, hipStream_t stream) {
+    // UTAP: every BK-wide K step lies inside one tap (Cin >= BK) and padding is zero -> scalar tap decode
+    if (a.Ci >= BK && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<BM, BN, BK, WM, WN, true>(a, stream);
+    return launch_conv_glds_impl<BM, BN, BK, WM, WN, false>(a, stream);
+}
+
+static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
+    if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
+    if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
+    return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
+}
+
 // out[p][c] = act(bias[c] + sum_ks slab[ks][p][c]), fixed summation order (deterministic)
 template <typename TOut>
 __global__ void __launch_bounds__(256) conv_slab_reduce_kernel(const float *slab, int splitk, size_t npix, int Co,
@@ -392,7 +634,9 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     a.Mtot = d->N * d->Hq * d->Wq;
 
     int rc;
-    if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
+    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
+    if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
+    else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_tile<float, float, 3>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_tile<float, float, 1>(a, stream);
     else DL_FAIL("dl_conv_forward: unsupported dtype/precision combination (%d, %d)", d->in_dtype, d->prec);
