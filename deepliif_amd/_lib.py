@@ -62,7 +62,7 @@ SIGNATURES = {
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),
     'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'dl_act_forward': (_i, [_i, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_act_backward': (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_axpby': (_i, [_i, _f, _vp, _i, _f, _vp, _i, _vp, _i, _i64, _i, _vp]),

@@ -318,14 +318,15 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
 template <int BM, int BN, int BK, int WM, int WN, bool UTAP>
-__global__ void __launch_bounds__(256) conv_gemm_glds_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN;                        // waves per workgroup (4 or 8)
     constexpr int CPR = BK / 8;                        // 16-byte chunks per LDS row
     constexpr int RPI = 64 / CPR;                      // tile rows filled by one wave-instruction
-    constexpr int X_INS = (BM + 4 * RPI - 1) / (4 * RPI);   // glds instructions per wave, activation tile
-    constexpr int W_INS = (BN + 4 * RPI - 1) / (4 * RPI);
+    constexpr int X_INS = (BM + NW * RPI - 1) / (NW * RPI);   // glds instructions per wave, activation tile
+    constexpr int W_INS = (BN + NW * RPI - 1) / (NW * RPI);
     constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
     constexpr int XT = BM * BK, WT = BN * BK, BUF = XT + WT;
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
@@ -531,7 +532,7 @@ static int launch_conv_glds_impl(const ConvArgs &a0, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, a.n_phase * a.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, stream, a);
     DL_CHECK_LAUNCH("dl_conv_forward(glds)");
     return 0;
 }
@@ -546,6 +547,11 @@ static int launch_conv_glds(const ConvArgs &a, hipStream_t stream) {
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
+    static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
+    // 256x256x64, 8 waves (each 128 pixels x 64 channels): twice the FLOP per staged byte of the 128x128 tile; needs
+    // enough tiles to fill 256 CUs
+    if (!no_big && a.Co >= 256 && (a.Co % 256) == 0 && (size_t)((a.Mtot + 255) / 256) * (a.Co / 256) * a.n_phase * a.splitk >= 256)
+        return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
 }
 

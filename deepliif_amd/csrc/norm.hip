@@ -23,7 +23,7 @@ static NormGeom make_geom(const dl_norm_desc *d) {
 
 extern "C" size_t dl_norm_ws_floats(const dl_norm_desc *d) {
     NormGeom g = make_geom(d);
-    return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)4 * g.N * g.Cp + 64;    // partials | chunk sums | c1 | c2
+    return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)4 * g.N * g.Cp + (size_t)2048 * g.Cp + 64;    // partials | chunk sums | c1 | c2 | dy channel-sum partials
 }
 
 // MODE 0: forward statistics  (s1 = sum y, s2 = sum y^2)
@@ -99,7 +99,11 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const T *y, int y_ps,
 
 // stage A of both finalizers: S[n][0|1][c] = sum over the image's chunks of the per-block partials.
 // block = 32 channels x 8 chunk lanes; grid = (Cp/32 rounded up, N)
-__global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums) {
+// With FUSE != 0 (instance scope) the per-(n,c) statistics / backward constants are finalised right here:
+//   FUSE 1 (forward) : mean, rstd, scale, shift           FUSE 2 (backward): c1 = S1/HW, c2 = S2/HW
+template <int FUSE>
+__global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums, float eps, float *o0, float *o1,
+                                                             float *o2, float *o3) {
     __shared__ float red[2][8][33];
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
@@ -120,6 +124,16 @@ __global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, 
         for (int r = 0; r < 8; ++r) { a1 += (double)red[0][r][cl]; a2 += (double)red[1][r][cl]; }
         sums[((size_t)n * 2) * g.Cp + c] = (float)a1;
         sums[((size_t)n * 2 + 1) * g.Cp + c] = (float)a2;
+        if (FUSE == 1) {           // InstanceNorm2d: no affine (networks.py:36-37)
+            const double mu = a1 / g.HW;
+            double var = a2 / g.HW - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float rs = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = c < g.C ? rs : 0.f;
+            o0[n * g.Cp + c] = (float)mu; o1[n * g.Cp + c] = rs; o2[n * g.Cp + c] = sc; o3[n * g.Cp + c] = -(float)mu * sc;
+        } else if (FUSE == 2) {
+            o0[n * g.Cp + c] = (float)(a1 / g.HW); o1[n * g.Cp + c] = (float)(a2 / g.HW);
+        }
     }
 }
 
@@ -216,14 +230,19 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float *sum
 template <typename T>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz_ps, const T *y, int y_ps, const float *gamma,
                                                              const float *mean, const float *rstd, const float *scale, const float *shift,
-                                                             const float *c1, const float *c2, T *dy, int dy_ps, NormGeom g, int act) {
+                                                             const float *c1, const float *c2, T *dy, int dy_ps, NormGeom g, int act,
+                                                             float *bpart) {
+    __shared__ float bred[256 * 9];
     const int cvec = g.Cp / 8;
     const int n = blockIdx.y;
     for (int cbase = 0; cbase < cvec; cbase += 256) {
         const int tpp = min(cvec - cbase, 256), rows = 256 / tpp;
         const int col = threadIdx.x % tpp, row = threadIdx.x / tpp;
-        if (row >= rows) continue;
         const int c0 = (cbase + col) * 8;
+        float bs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[k] = 0.f;
+        if (row < rows) {
         float sc[8], sh[8], rs[8], mr[8], k1[8], k2[8], gr[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -246,9 +265,46 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                 else if (act == DL_ACT_TANH) { const float t = tanhf(nv); dn *= 1.f - t * t; }
                 const float xh = v[k] * rs[k] + mr[k];
                 o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
+                bs[k] += o[k];
             }
             Vec8<T>::store(dy + pix * dy_ps + c0, o);
         }
+        }
+        if (bpart) {       // per-block channel sums of dy: the gradient of the conv bias in front of this norm
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bred[threadIdx.x * 9 + k] = bs[k];
+            __syncthreads();
+            if (threadIdx.x < tpp) {
+                float a[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = 0.f;
+                for (int r = 0; r < rows; ++r)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] += bred[(r * tpp + threadIdx.x) * 9 + k];
+                float *o = bpart + ((size_t)(n * gridDim.x + blockIdx.x)) * g.Cp + (cbase + threadIdx.x) * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = a[k];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[c] += sum over the per-block partials (block = 32 channels x 8 partial lanes)
+__global__ void __launch_bounds__(256) norm_bias_final_kernel(const float *part, int nparts, int Cp, int C, float *out) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int b = kl; b < nparts; b += 8) s += part[(size_t)b * Cp + c];
+    red[kl][cl] = s;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += (double)red[r][cl];
+        out[c] += (float)a;
     }
 }
 
@@ -287,12 +343,17 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
                            (const bf16_t *)nullptr, 0, g, 0, nullptr, nullptr, nullptr, nullptr, ws);
     DL_CHECK_LAUNCH("dl_norm_forward(stats)");
     float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
-    hipLaunchKernelGGL(norm_chunk_sum_kernel, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums);
-    DL_CHECK_LAUNCH("dl_norm_forward(chunk sums)");
-    const int ftotal = (d->scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
-    hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, d->eps, gamma, beta,
-                       running_mean, running_var, d->momentum, mean, rstd, scale, shift);
-    DL_CHECK_LAUNCH("dl_norm_forward(finalize)");
+    if (d->scope == DL_NORM_INSTANCE && !gamma && !beta) {
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<1>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums, d->eps, mean, rstd, scale, shift);
+        DL_CHECK_LAUNCH("dl_norm_forward(chunk sums + finalize)");
+    } else {
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        DL_CHECK_LAUNCH("dl_norm_forward(chunk sums)");
+        const int ftotal = (d->scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
+        hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, d->eps, gamma, beta,
+                           running_mean, running_var, d->momentum, mean, rstd, scale, shift);
+        DL_CHECK_LAUNCH("dl_norm_forward(finalize)");
+    }
     const dim3 blocks = apply_grid(g);
     if (d->dtype == DL_F32)
         hipLaunchKernelGGL(norm_apply_kernel<float>, blocks, dim3(256), 0, stream, (const float *)y, d->y_pstride, scale, shift,
@@ -306,7 +367,7 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
 
 extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const void *y, const float *gamma,
                                 const float *mean, const float *rstd, const float *scale, const float *shift,
-                                void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *ws, void *stream_) {
+                                void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_backward")) return -1;
     if (!dz || !y || !dy || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
@@ -325,18 +386,28 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
         hipLaunchKernelGGL((norm_partial_kernel<bf16_t, 1>), dim3(pblocks), dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride,
                            (const bf16_t *)dz, dz_ps, g, d->act, mean, rstd, scale, shift, part);
     DL_CHECK_LAUNCH("dl_norm_backward(reduce)");
-    hipLaunchKernelGGL(norm_chunk_sum_kernel, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums);
-    DL_CHECK_LAUNCH("dl_norm_backward(chunk sums)");
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, c1, c2, dgamma, dbeta,
-                       accumulate_affine);
-    DL_CHECK_LAUNCH("dl_norm_backward(finalize)");
+    if (d->scope == DL_NORM_INSTANCE && !dgamma) {
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<2>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums, d->eps, c1, c2, nullptr, nullptr);
+        DL_CHECK_LAUNCH("dl_norm_backward(chunk sums + finalize)");
+    } else {
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        DL_CHECK_LAUNCH("dl_norm_backward(chunk sums)");
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, c1, c2, dgamma, dbeta,
+                           accumulate_affine);
+        DL_CHECK_LAUNCH("dl_norm_backward(finalize)");
+    }
+    float *bpart = dy_chansum ? c2 + (size_t)g.N * g.Cp : nullptr;
     const dim3 blocks = apply_grid(g);
     if (d->dtype == DL_F32)
         hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, blocks, dim3(256), 0, stream, (const float *)dz, dz_ps, (const float *)y,
-                           d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (float *)dy, dy_ps, g, d->act);
+                           d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (float *)dy, dy_ps, g, d->act, bpart);
     else
         hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, blocks, dim3(256), 0, stream, (const bf16_t *)dz, dz_ps, (const bf16_t *)y,
-                           d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, d->act);
+                           d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, d->act, bpart);
     DL_CHECK_LAUNCH("dl_norm_backward(apply)");
+    if (dy_chansum) {
+        hipLaunchKernelGGL(norm_bias_final_kernel, dim3((g.C + 31) / 32), dim3(256), 0, stream, bpart, (int)(blocks.x * blocks.y), g.Cp, g.C, dy_chansum);
+        DL_CHECK_LAUNCH("dl_norm_backward(bias sum)");
+    }
     return 0;
 }

@@ -37,13 +37,15 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
         self.C = C
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self.bias_grad: Optional[torch.Tensor] = None     # conv output: where the producer's bias gradient accumulates
+        self.bias_done = False                            # set when a consumer's backward already added sum(dy) to it
 
     @property
     def shape(self):
@@ -173,6 +175,8 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     y = Act(out, spec.cout, x_needs or w_needs)
     if not (x_needs or w_needs):
         return y
+    if w_needs and act == L.ACT_NONE and layer.bias is not None and layer.bias.requires_grad:
+        y.bias_grad = layer.bias.grad           # a following norm_act folds sum(dy) into its backward pass
 
     def backward():
         g = y.grad
@@ -188,7 +192,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 be.conv_wgrad(g, x.t, layer.weight.grad, spec.k, spec.stride, spec.pad, spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True)
             else:
                 be.conv_wgrad(x.t, g, layer.weight.grad, spec.k, spec.stride, spec.pad, L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True)
-            if layer.bias is not None and layer.bias.requires_grad:
+            if layer.bias is not None and layer.bias.requires_grad and not y.bias_done:
                 be.channel_sum(g, spec.cout, layer.bias.grad, True)
         if x_needs:
             dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
@@ -258,7 +262,11 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
         affine = m is not None and m.weight.requires_grad
         if y.needs_grad or affine:
             dy = empty_like_act(g)
-            be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None)
+            fuse_bias = y.bias_grad is not None and y.grad is None and not y.bias_done     # dy is y's ONLY gradient contribution
+            be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None,
+                             y.bias_grad if fuse_bias else None)
+            if fuse_bias:
+                y.bias_done = True
             if y.needs_grad:
                 y.add_grad(dy)
 

@@ -148,12 +148,12 @@ class HipBackend:
                                          _ptr(ws), _stream()), 'dl_norm_forward')
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta):
-        _need_cuda(dz, y, dy)
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
+        _need_cuda(dz, y, dy, dy_chansum)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
-                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(ws), _stream()), 'dl_norm_backward')
+                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _stream()), 'dl_norm_backward')
 
     # ---- elementwise
     def act_forward(self, act, x, y):

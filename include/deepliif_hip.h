@@ -148,10 +148,12 @@ int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, co
                     const void *residual, void *z, float *ws, void *stream);
 
 /* dy = d/dy of [ z = act(norm(y)) (+res) ] given dz; dgamma/dbeta (+)= ...; the residual branch receives dz itself.
- * Strides: y uses d->y_pstride, dz uses d->z_pstride, dy uses d->r_pstride. */
+ * Strides: y uses d->y_pstride, dz uses d->z_pstride, dy uses d->r_pstride.
+ * dy_chansum (may be NULL): dy_chansum[c] += sum over pixels of dy[.,c] -- the gradient of the bias of the convolution that
+ * produced y (Conv2d(bias=True) in front of InstanceNorm2d, networks.py:381-384), fused into the same pass. */
 int dl_norm_backward(const dl_norm_desc *d, const void *dz, const void *y, const float *gamma,
                      const float *mean, const float *rstd, const float *scale, const float *shift,
-                     void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *ws, void *stream);
+                     void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise (networks.py nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh, torch.cat, the seg weighted sum

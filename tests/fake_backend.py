@@ -127,7 +127,7 @@ class FakeBackend:
             stats[i] = t.reshape(-1, Cp).expand(N, Cp)
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta):
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
         self._count('norm_bwd')
         yv, g = y.float(), dz.float()
         N, H, W, Cp = yv.shape
@@ -147,7 +147,10 @@ class FakeBackend:
         c2 = (dn * xh).mean(dim=dims, keepdim=True)
         ga = torch.zeros(Cp)
         ga[:C_real] = gamma.float() if gamma is not None else 1.0
-        dy.copy_((ga * rstd * (dn - c1 - xh * c2)).to(dy.dtype))
+        dyv = ga * rstd * (dn - c1 - xh * c2)
+        dy.copy_(dyv.to(dy.dtype))
+        if dy_chansum is not None:
+            dy_chansum.add_(dyv.sum(dim=(0, 1, 2))[:C_real])
         if dgamma is not None:
             dgamma.add_((dn * xh).sum(dim=(0, 1, 2))[:C_real])
             dbeta.add_(dn.sum(dim=(0, 1, 2))[:C_real])

@@ -232,12 +232,15 @@ def test_norm_forward_backward(shape, C, scope, precname):
             assert rel(rm_r, rm_f) < 1e-4 and rel(rv_r, rv_f) < 1e-4
         dy_f = torch.empty(shape, dtype=prec.dtype)
         dg_f, db_f = (torch.zeros(C), torch.zeros(C)) if affine else (None, None)
-        fake.norm_backward(dz.to(prec.dtype), y.to(prec.dtype), dy_f, st_f, C, scope, act, gamma, dg_f, db_f)
+        cs_f, cs_r = torch.ones(C), torch.ones(C, device=DEV)
+        fake.norm_backward(dz.to(prec.dtype), y.to(prec.dtype), dy_f, st_f, C, scope, act, gamma, dg_f, db_f, cs_f)
         dy_r = torch.empty(shape, dtype=prec.dtype, device=DEV)
         dg_r, db_r = (torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)) if affine else (None, None)
-        real.norm_backward(dz.to(prec.dtype).to(DEV), y.to(prec.dtype).to(DEV), dy_r, st_r, C, scope, act, g_r, dg_r, db_r)
+        real.norm_backward(dz.to(prec.dtype).to(DEV), y.to(prec.dtype).to(DEV), dy_r, st_r, C, scope, act, g_r, dg_r, db_r, cs_r)
         sync()
         assert rel(dy_r, dy_f) < (1e-4 if precname == 'fp32' else 2e-2), ('dy', act)
+        # fused conv-bias gradient: 1 + sum over pixels of dy (analytically 0: compare absolutely, scaled by sum |dy|)
+        assert float((cs_r.cpu() - cs_f).abs().max()) <= 1e-5 * float(dy_f.float().abs().sum()) / C + 1e-5, 'dy channel sums'
         if affine:
             assert rel(dg_r, dg_f) < 1e-3 and rel(db_r, db_f) < 1e-3
 
