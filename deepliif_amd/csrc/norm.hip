@@ -290,20 +290,20 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
     }
 }
 
-// out[c] += sum over the per-block partials (block = 32 channels x 8 partial lanes)
-__global__ void __launch_bounds__(256) norm_bias_final_kernel(const float *part, int nparts, int Cp, int C, float *out) {
-    __shared__ float red[8][33];
+// out[c] += sum over the per-block partials (block = 32 channels x 32 partial lanes)
+__global__ void __launch_bounds__(1024) norm_bias_final_kernel(const float *part, int nparts, int Cp, int C, float *out) {
+    __shared__ float red[32][33];
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < C)
-        for (int b = kl; b < nparts; b += 8) s += part[(size_t)b * Cp + c];
+        for (int b = kl; b < nparts; b += 32) s += part[(size_t)b * Cp + c];
     red[kl][cl] = s;
     __syncthreads();
     if (kl == 0 && c < C) {
         double a = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a += (double)red[r][cl];
+        for (int r = 0; r < 32; ++r) a += (double)red[r][cl];
         out[c] += (float)a;
     }
 }
@@ -406,7 +406,7 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
                            d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, d->act, bpart);
     DL_CHECK_LAUNCH("dl_norm_backward(apply)");
     if (dy_chansum) {
-        hipLaunchKernelGGL(norm_bias_final_kernel, dim3((g.C + 31) / 32), dim3(256), 0, stream, bpart, (int)(blocks.x * blocks.y), g.Cp, g.C, dy_chansum);
+        hipLaunchKernelGGL(norm_bias_final_kernel, dim3((g.C + 31) / 32), dim3(1024), 0, stream, bpart, (int)(blocks.x * blocks.y), g.Cp, g.C, dy_chansum);
         DL_CHECK_LAUNCH("dl_norm_backward(bias sum)");
     }
     return 0;

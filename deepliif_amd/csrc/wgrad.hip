@@ -9,6 +9,7 @@
 // Split-K over pixel ranges writes fp32 slabs; a second kernel combines them in a fixed order (deterministic) and
 // scatters into the parameter-gradient layout [a][b][kh][kw].
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -241,6 +242,183 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast path (v2): 8 waves, tile BA x 256 x 64 pixels, both tiles HBM -> LDS by global_load_lds_dwordx4.
+// LDS rows are unpadded (the DMA image must be lane-linear); ds_read_b64_tr_b16 bank conflicts are removed by an XOR
+// swizzle of the 32-byte slots of a row, slot' = slot ^ g(p) with g(p) = (p & 3) | ((p >> 1) & 4): the 8 pixel rows a
+// half-wave touches in one transposing read then hit 8 different 32-byte bank groups.  The swizzle is applied on the
+// SOURCE side of the DMA (each lane fetches the global chunk that belongs in its LDS slot) and again in the reads.
+// ------------------------------------------------------------------------------------------------------------------
+extern __device__ unsigned char g_wzero_page[];
+__device__ __attribute__((aligned(64))) unsigned char g_wzero_page[64];
+
+__device__ __forceinline__ int wswz(int p) { return (p & 3) | ((p >> 1) & 4); }
+
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_fragment_swz(const bf16_t *tile, int prow0, int slot, int lane) {
+    // rows prow0 + 8g + 4h + (m>>2); 16-channel block `slot` (32 B); returns tile[prow0 + 8g + 4h + j][16*slot + i]
+    const int m = lane & 15, g = lane >> 4;
+    const int x = (m >> 2) | ((g & 1) << 2);             // = wswz(p) for every p this lane reads (independent of h)
+    const char *base = reinterpret_cast<const char *>(tile) + (prow0 + 8 * g + (m >> 2)) * ROWB + ((slot ^ x) << 5) + (m & 3) * 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(base));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3))) *)(base + 4 * ROWB));
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int BA, int WA, int WJ>
+__global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
+    constexpr int BJ = 256, BP = 64, NW = 8;
+    constexpr int PA = BA / WA, PJ = BJ / WJ, FA = PA / 16, FJ = PJ / 16;
+    constexpr int ROWA = BA * 2, ROWJ = BJ * 2;             // row bytes
+    constexpr int TA = BP * BA, TJ = BP * BJ, BUF = TA + TJ; // elements
+    constexpr int A_RPI = 1024 / ROWA, J_RPI = 1024 / ROWJ; // tile rows per wave-instruction
+    constexpr int A_INS = BP / (NW * A_RPI), J_INS = BP / (NW * J_RPI);
+    static_assert(WA * WJ == NW, "8 waves");
+    static_assert(A_INS >= 1 && J_INS >= 1, "tile too small for 8 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave % WA, wj = wave / WA;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
+    const int ks = blockIdx.y;
+    const int p_begin = ks * a.pchunk;
+    const int p_end = min(a.Ptot, p_begin + a.pchunk);
+    const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const bf16_t *P = reinterpret_cast<const bf16_t *>(a.P);
+    const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.Q);
+    const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_wzero_page);
+
+    // ---- P lanes: instruction i of this wave fills tile rows (wave*A_INS + i)*A_RPI + lane*16/ROWA
+    const bf16_t *p_src[A_INS];
+    int p_row[A_INS];
+#pragma unroll
+    for (int i = 0; i < A_INS; ++i) {
+        const int row = (wave * A_INS + i) * A_RPI + (lane * 16) / ROWA;
+        const int cpos = ((lane * 16) % ROWA) / 16;                         // 16-byte position inside the LDS row
+        const int c = (((cpos >> 1) ^ wswz(row)) << 1) | (cpos & 1);        // global chunk that belongs there
+        p_row[i] = row;
+        p_src[i] = P + (size_t)(p_begin + row) * a.p_pstride + ta * BA + c * 8;
+    }
+    // ---- Q lanes: fixed (tap, channel chunk) per lane and instruction, pixel walks by 64 per K step
+    int q_row[J_INS], q_n[J_INS], q_h[J_INS], q_w[J_INS], q_kh[J_INS], q_kw[J_INS], q_cb[J_INS];
+    bool q_tap_ok[J_INS];
+    const int HWp = a.Hp * a.Wp;
+#pragma unroll
+    for (int i = 0; i < J_INS; ++i) {
+        const int row = (wave * J_INS + i) * J_RPI + (lane * 16) / ROWJ;
+        const int cpos = ((lane * 16) % ROWJ) / 16;
+        const int c = (((cpos >> 1) ^ wswz(row)) << 1) | (cpos & 1);
+        const int j0 = tj * BJ + c * 8;
+        const int tap = j0 >> a.log2CB;
+        q_row[i] = row;
+        q_cb[i] = j0 & (a.CBp - 1);
+        q_tap_ok[i] = tap < a.KH * a.KW;
+        q_kh[i] = q_tap_ok[i] ? tap / a.KW : 0;
+        q_kw[i] = q_tap_ok[i] ? tap - q_kh[i] * a.KW : 0;
+        const int p = p_begin + row;
+        q_n[i] = p / HWp;
+        const int rem = p - q_n[i] * HWp;
+        q_h[i] = rem / a.Wp;
+        q_w[i] = rem - q_h[i] * a.Wp;
+    }
+
+    auto issue_tile = [&](int kt, int buf) {
+        bf16_t *base = smem + buf * BUF;
+        const int pbase = p_begin + kt * BP;
+#pragma unroll
+        for (int i = 0; i < A_INS; ++i) {
+            const bf16_t *src = (pbase + p_row[i] < p_end) ? p_src[i] + (size_t)kt * BP * a.p_pstride : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(base + (wave * A_INS + i) * A_RPI * BA), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < J_INS; ++i) {
+            const int h = q_h[i] * a.step - a.pad + q_kh[i], w = q_w[i] * a.step - a.pad + q_kw[i];
+            const bool ok = q_tap_ok[i] && (pbase + q_row[i] < p_end) && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
+            const bf16_t *src = ok ? Q + ((size_t)(q_n[i] * a.Hq + h) * a.Wq + w) * a.q_pstride + q_cb[i] : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(base + TA + (wave * J_INS + i) * J_RPI * BJ), 16, 0, 0);
+            // advance this lane's pixel by 64 (mixed radix add, single carries)
+            q_w[i] += a.dw;
+            const int cw = q_w[i] >= a.Wp;
+            q_w[i] -= cw ? a.Wp : 0;
+            q_h[i] += a.dh + cw;
+            const int chh = q_h[i] >= a.Hp;
+            q_h[i] -= chh ? a.Hp : 0;
+            q_n[i] += a.dn + chh;
+        }
+    };
+
+    f32x4_t acc[FA][FJ];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) issue_tile(0, 0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+        const bf16_t *Ps = smem + cur * BUF, *Qs = Ps + TA;
+#pragma unroll
+        for (int ss = 0; ss < BP / 32; ++ss) {
+            bf16x8_t af[FA], bf[FJ];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) af[i] = tr_fragment_swz<ROWA>(Ps, ss * 32, (wa * PA) / 16 + i, lane);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) bf[j] = tr_fragment_swz<ROWJ>(Qs, ss * 32, (wj * PJ) / 16 + j, lane);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int jj = tj * BJ + wj * PJ + j * 16 + fr;
+            if (jj >= a.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
+                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BA, int WA, int WJ>
+static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
+    constexpr size_t smem = (size_t)2 * 64 * (BA + 256) * sizeof(bf16_t);
+    a.tiles_a = a.CAp / BA;
+    a.tiles_j = (a.J + 255) / 256;
+    a.pchunk = ((a.Ptot + a.splitk - 1) / a.splitk + 63) / 64 * 64;
+    const int hw = a.Hp * a.Wp;
+    a.dn = 64 / hw; a.dh = (64 % hw) / a.Wp; a.dw = (64 % hw) % a.Wp;
+    auto kern = wgrad_glds_kernel<BA, WA, WJ>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk), dim3(512), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(glds)");
+    return 0;
+}
+
 // grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b]
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate) {
@@ -305,7 +483,12 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     a.p_act = d->p_act; a.q_act = d->q_act;
 
     int rc;
-    if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
+    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    const bool fast = d->dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->p_act == DL_ACT_NONE && d->q_act == DL_ACT_NONE &&
+                      d->pad_mode == DL_PAD_ZERO && a.J >= 256 && a.Ptot >= 64 * d->splitk && !no_glds;
+    if (fast && (d->CAp % 256) == 0) rc = launch_wgrad_glds<256, 2, 4>(a, stream);
+    else if (fast && (d->CAp % 128) == 0) rc = launch_wgrad_glds<128, 2, 4>(a, stream);
+    else if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
     else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
     else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<float, 1>(a, stream);
     else DL_FAIL("dl_conv_wgrad: unsupported dtype/precision combination");

@@ -181,7 +181,22 @@ def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, 
     return d
 
 
-def choose_wgrad_splitk(cap: int, j: int, ptot: int, target_blocks: int = 1024, max_split: int = 256) -> int:
+NUM_CUS = 256      # MI355X
+
+
+def wgrad_fast_path(cap: int, j: int, bf16: bool, no_act: bool, zero_pad: bool) -> bool:
+    """mirror of the dispatch predicate in wgrad.hip (direct-to-LDS 8-wave kernel)"""
+    return bf16 and no_act and zero_pad and j >= 256 and cap % 128 == 0
+
+
+def choose_wgrad_splitk(cap: int, j: int, ptot: int, fast: bool = False, target_blocks: int = 1024, max_split: int = 256) -> int:
+    if fast:
+        # 8-wave kernel: one workgroup per CU (248 VGPRs) -> the grid must not exceed one round of 256 CUs by a few blocks
+        ba = 256 if cap % 256 == 0 else 128
+        tiles = (cap // ba) * ((j + 255) // 256)
+        if tiles >= NUM_CUS:
+            return 1
+        return max(1, min(NUM_CUS // tiles, ptot // 128, max_split))
     ba = 16 if cap <= 16 else (64 if cap <= 64 else 128)
     tiles = ((cap + ba - 1) // ba) * ((j + 127) // 128)
     sk = min(max_split, (target_blocks + tiles - 1) // tiles, max(1, ptot // 64))

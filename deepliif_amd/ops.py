@@ -18,7 +18,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from .geometry import GatherPlan, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc
+from .geometry import GatherPlan, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc, wgrad_fast_path
 
 
 def dl_dtype(t: torch.Tensor) -> int:
@@ -122,7 +122,9 @@ class HipBackend:
         d.CA, d.CB = grad.shape[0], grad.shape[1]
         d.dtype, d.prec = dl_dtype(P), prec
         j = k * k * d.CBp
-        d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp)
+        fast = wgrad_fast_path(d.CAp, j, d.dtype == L.DL_BF16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE,
+                               pad_mode == L.PAD_ZERO)
+        d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
         d.accumulate = 1 if accumulate else 0
         d.p_act, d.q_act = p_act, q_act
         slab = WS.get('wgrad_slab', d.splitk * d.CAp * j, P.device)

@@ -194,6 +194,15 @@ def test_conv_wgrad(case, precname):
     real.conv_wgrad(P.to(prec.dtype).to(DEV), Q.to(prec.dtype).to(DEV), g_got2, *args, prec.prec, False, splitk=1)
     sync()
     assert rel(g_got2, g_exp) < (1e-4 if precname == 'fp32' else 1e-3)
+    # no staged activation: the bf16 policy takes the direct-to-LDS (global_load_lds) kernel where the shape allows it
+    args0 = args[:4] + (L.ACT_NONE, L.ACT_NONE)
+    g_exp0 = torch.zeros(gshape)
+    fake.conv_wgrad(P.to(prec.dtype), Q.to(prec.dtype), g_exp0, *args0, prec.prec, False)
+    for sk in (None, 2):
+        g_got3 = torch.empty(gshape, device=DEV)
+        real.conv_wgrad(P.to(prec.dtype).to(DEV), Q.to(prec.dtype).to(DEV), g_got3, *args0, prec.prec, False, splitk=sk)
+        sync()
+        assert rel(g_got3, g_exp0) < (1e-4 if precname == 'fp32' else 1e-3), ('plain', sk)
 
 
 # ------------------------------------------------------------------------------------------------ norm / elementwise / loss / adam
