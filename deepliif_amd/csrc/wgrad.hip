@@ -419,17 +419,19 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
     return 0;
 }
 
-// grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b]
+// grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b].  Threads walk the slab in its own (contiguous) order so the reads
+// coalesce; the (small) gradient tensor takes the strided writes.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate) {
-    const int total = CA * CB * KK;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int t = i % KK;
-        const int b = (i / KK) % CB;
-        const int ca = i / (KK * CB);
+    const size_t total = (size_t)CA * J;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ca = (int)(i / J), j = (int)(i % J);
+        const int t = j / CBp, b = j % CBp;
+        if (b >= CB || t >= KK) continue;
         float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += slab[((size_t)k * CAp + ca) * J + t * CBp + b];
-        grad[i] = accumulate ? grad[i] + s : s;
+        for (int k = 0; k < splitk; ++k) s += slab[((size_t)k * CAp + ca) * J + j];
+        float *g = grad + ((size_t)ca * CB + b) * KK + t;
+        *g = accumulate ? *g + s : s;
     }
 }
 
@@ -495,8 +497,8 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (rc) return rc;
 
     const int KK = d->KH * d->KW;
-    const int total = d->CA * d->CB * KK;
-    const int blocks = min(2048, (total + 255) / 256);
+    const size_t total = (size_t)d->CA * a.J;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
                        grad, d->accumulate);
     DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");

@@ -75,8 +75,15 @@ class BaseModel:
             self.load_networks(suffix)
         self.print_networks(_get(opt, 'verbose', False))
 
+    def _net(self, name):
+        # 'G_1' -> self.netG[0] (list-valued models: DeepLIIFExt/SDG, base_model.py:96-98), 'G1' -> self.netG1
+        if '_' in name:
+            kind, idx = name.split('_')
+            return getattr(self, 'net' + kind)[int(idx) - 1]
+        return getattr(self, 'net' + name)
+
     def _nets(self):
-        return [(n, getattr(self, 'net' + n)) for n in self.model_names]
+        return [(n, self._net(n)) for n in self.model_names]
 
     def train(self):
         for _, net in self._nets():
@@ -397,7 +404,197 @@ class DeepLIIFModel(BaseModel):
         self.backward_G()
 
 
-_MODEL_CLASSES = {'DeepLIIF': DeepLIIFModel}
+class DeepLIIFExtModel(BaseModel):
+    """deepliif/models/DeepLIIFExt_model.py: M translation generators G_i(real_A); M seg generators
+    GS_i(cat(real_A, fake_B[0], fake_B[i])) (9 channels, :173); discriminators D_i(cat(A, B_i)) and
+    DS_i(cat(real_A, real_B[0], real_B[i], seg_i)) (12 channels, :97,186).  Networks and losses are list-valued
+    (netG[i], loss_G_GAN[i], ...), model names 'G_1', 'GS_1', ...  Quirks kept: the generator-side seg GAN loss uses
+    criterionGAN_mod (:236), seg loss weights are 1/M (:27,30), no VGG term."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        M = self.mod_gen_no = opt.modalities_no
+        self.seg_weights = opt.seg_weights
+        self.loss_G_weights, self.loss_D_weights = list(opt.loss_G_weights), list(opt.loss_D_weights)
+        cin = self._input_channels(opt)
+        self.loss_GS_weights = [1 / M] * M
+        self.loss_DS_weights = [1 / M] * M
+        seg = opt.seg_gen
+        self.loss_names, self.visual_names = [], ['real_A']
+        for i in range(1, M + 1):
+            self.loss_names += [f'G_GAN_{i}', f'G_L1_{i}', f'D_real_{i}', f'D_fake_{i}']
+            self.visual_names += [f'fake_B_{i}', f'real_B_{i}']
+        if seg:
+            for i in range(1, M + 1):
+                self.loss_names += [f'GS_GAN_{i}', f'GS_L1_{i}', f'DS_real_{i}', f'DS_fake_{i}']
+                self.visual_names += [f'fake_BS_{i}', f'real_BS_{i}']
+        self.model_names = []
+        for i in range(1, M + 1):
+            self.model_names += [f'G_{i}'] + ([f'D_{i}'] if self.is_train else [])
+        if seg:
+            for i in range(1, M + 1):
+                self.model_names += [f'GS_{i}'] + ([f'DS_{i}'] if self.is_train else [])
+        net_g = opt.net_g if isinstance(opt.net_g, (list, tuple)) else [opt.net_g] * M
+        net_gs = opt.net_gs if isinstance(opt.net_gs, (list, tuple)) else [opt.net_gs] * M
+        use_dropout = not _get(opt, 'no_dropout', True)
+        gpu = self._net_gpu_ids()
+        self.netG = [networks.define_G(cin, opt.output_nc, opt.ngf, net_g[i], opt.norm, use_dropout, opt.init_type, opt.init_gain, gpu,
+                                       opt.padding) for i in range(M)]
+        self.netGS = [networks.define_G(opt.input_nc * 3, opt.output_nc, opt.ngf, net_gs[i], opt.norm, use_dropout, opt.init_type,
+                                        opt.init_gain, gpu) if seg else None for i in range(M)]
+        self.netD, self.netDS = [], []
+        if self.is_train:
+            nl = _get(opt, 'n_layers_D', 4)
+            self.netD = [networks.define_D(cin + opt.output_nc, opt.ndf, _get(opt, 'net_d', 'n_layers'), nl, opt.norm, opt.init_type,
+                                           opt.init_gain, gpu) for _ in range(M)]
+            self.netDS = [networks.define_D(opt.input_nc * 3 + opt.output_nc, opt.ndf, _get(opt, 'net_ds', 'n_layers'), nl, opt.norm,
+                                            opt.init_type, opt.init_gain, gpu) if seg else None for _ in range(M)]
+        for _, net in self._nets():
+            net.set_precision(self.precision.name)
+        self._loss_index = {n: i for i, n in enumerate(self.loss_names)}
+        self._loss_buf = torch.zeros(max(len(self.loss_names), 1), dtype=torch.float32, device=self.device)
+        for fam in ('G_GAN', 'G_L1', 'D_real', 'D_fake', 'GS_GAN', 'GS_L1', 'DS_real', 'DS_fake'):
+            setattr(self, 'loss_' + fam, [self._loss_buf[self._loss_index[f'{fam}_{i}']] for i in range(1, M + 1) if f'{fam}_{i}' in self._loss_index])
+        if self.is_train:
+            self.criterionGAN_mod = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionGAN_seg = networks.GANLoss(opt.gan_mode_s).to(self.device)
+            self.lambda_L1 = _get(opt, 'lambda_L1', 100.0)
+            params_g = [p for net in self.netG + [n for n in self.netGS if n is not None] for p in net.parameters()]
+            params_d = [p for net in self.netD + [n for n in self.netDS if n is not None] for p in net.parameters()]
+            OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
+            try:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g, betas=(opt.beta1, 0.999))
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d, betas=(opt.beta1, 0.999))
+            except TypeError:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g)
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d)
+            self.optimizers += [self.optimizer_G, self.optimizer_D]
+            self.exchange = GradExchanger()
+        self._tape_G = None
+
+    def _input_channels(self, opt):
+        return opt.input_nc
+
+    def _slot(self, name):
+        return self._loss_buf[self._loss_index[name]].view(1)
+
+    def set_input(self, input):
+        """DeepLIIFExt_model.py:134-158: dict{'A', 'B': list, 'BS': list, 'A_paths'}  (SDG: 'A' is a list of input modalities,
+        concatenated on the channel axis, SDG_model.py:108-110)."""
+        p = self.precision
+        A = input['A']
+        self.real_A = torch.cat([a.to(self.device) for a in A], dim=1) if isinstance(A, (list, tuple)) else A.to(self.device)
+        self.real_B = [b.to(self.device) for b in input['B']]
+        self.real_BS = [b.to(self.device) for b in input.get('BS', [])]
+        self.image_paths = input.get('A_paths', [])
+        self._A = E.to_engine(self.real_A, p)
+        self._B = [E.to_engine(b, p) for b in self.real_B]
+        self._BS = [E.to_engine(b, p) for b in self.real_BS]
+        self._real_cat = None
+
+    def forward(self, record=None):
+        record = self.is_train if record is None else record
+        tape = E.Tape() if record else None
+        ctx = E.Ctx(self.precision, tape, training=record)
+        self._fake = [net.run(ctx, self._A) for net in self.netG]
+        self.fake_B = [E.from_engine(f) for f in self._fake]
+        self._fake_s = []
+        for i, net in enumerate(self.netGS):
+            if net is not None:
+                self._fake_s.append(net.run(ctx, E.concat_channels(ctx, [self._A, self._fake[0], self._fake[i]])))
+        self.fake_BS = [E.from_engine(f) for f in self._fake_s]
+        for i, t in enumerate(self.fake_B):
+            setattr(self, f'fake_B_{i + 1}', t)
+        for i, t in enumerate(self.fake_BS):
+            setattr(self, f'fake_BS_{i + 1}', t)
+        self._tape_G = tape
+
+    def _cat_real(self, ctx):
+        if self._real_cat is None:
+            self._real_cat = [E.concat_channels(ctx, [self._A, self._B[0], self._B[i]]) for i in range(self.mod_gen_no)]
+        return self._real_cat
+
+    def backward_D(self):
+        tape = E.Tape()
+        ctx = E.Ctx(self.precision, tape, training=True)
+        cg, cs, M = self.criterionGAN_mod, self.criterionGAN_seg, self.mod_gen_no
+        rc = self._cat_real(ctx)
+        for i in range(M):
+            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i].detach()]))
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * self.loss_D_weights[i], self._slot(f'D_fake_{i + 1}'))
+        for i in range(len(self._fake_s)):
+            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i].detach()]))
+            E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_fake_{i + 1}'))
+        for i in range(M):
+            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._B[i]]))
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * self.loss_D_weights[i], self._slot(f'D_real_{i + 1}'))
+        for i in range(len(self._fake_s)):
+            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._BS[i]]))
+            E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_real_{i + 1}'))
+        tape.backward()
+
+    def backward_G(self):
+        tape = self._tape_G
+        ctx = E.Ctx(self.precision, tape, training=True)
+        cg, M = self.criterionGAN_mod, self.mod_gen_no
+        rc = self._cat_real(E.Ctx(self.precision, None, training=True))
+        for i in range(M):
+            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i]]))
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_G_weights[i], self._slot(f'G_GAN_{i + 1}'))
+        for i in range(len(self._fake_s)):
+            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i]]))
+            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_GS_weights[i], self._slot(f'GS_GAN_{i + 1}'))   # criterionGAN_mod (:236)
+        for i in range(M):
+            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, self.loss_G_weights[i] * self.lambda_L1, self._slot(f'G_L1_{i + 1}'))
+        for i in range(len(self._fake_s)):
+            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_s[i], self._BS[i], 0.0, self.loss_GS_weights[i] * self.lambda_L1, self._slot(f'GS_L1_{i + 1}'))
+        tape.backward()
+        self._tape_G = None
+        idx = [self._loss_index[n] for n in self.loss_names if '_L1_' in n]
+        self._loss_buf[torch.tensor(idx, dtype=torch.long, device=self.device)] *= self.lambda_L1
+
+    def _d_nets(self):
+        return [n for n in self.netD + self.netDS if n is not None]
+
+    def optimize_parameters(self):
+        self.forward()
+        self.set_requires_grad(self._d_nets(), True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.exchange.all_reduce(self.optimizer_D)
+        self.optimizer_D.step()
+        self.set_requires_grad(self._d_nets(), False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.exchange.all_reduce(self.optimizer_G)
+        self.optimizer_G.step()
+
+    def calculate_losses(self):
+        self.forward()
+        self.set_requires_grad(self._d_nets(), True)
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.set_requires_grad(self._d_nets(), False)
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+
+
+class SDGModel(DeepLIIFExtModel):
+    """deepliif/models/SDG_model.py: DeepLIIFExt's translation branch only, with `input_no` input modalities concatenated on the
+    channel axis (generators take input_nc*input_no channels, discriminators input_nc*input_no + output_nc).  The reference adds
+    a VGG19 perceptual term (SDG_model.py:176-184); like for DeepLIIF it is outside the MI355X hot path (SURVEY 0 #4)."""
+
+    def __init__(self, opt):
+        opt.seg_gen = False
+        if _get(opt, 'lambda_feat', 0):
+            print('deepliif_amd: the VGG19 perceptual loss (lambda_feat) is not part of the MI355X hot path; training uses GAN + SmoothL1')
+        super().__init__(opt)
+
+    def _input_channels(self, opt):
+        return opt.input_nc * _get(opt, 'input_no', 1)
+
+
+_MODEL_CLASSES = {'DeepLIIF': DeepLIIFModel, 'DeepLIIFExt': DeepLIIFExtModel, 'SDG': SDGModel}
 
 
 def create_model(opt):

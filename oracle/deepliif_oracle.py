@@ -499,3 +499,91 @@ class OracleDeepLIIF:
 
     def current_losses(self):
         return OrderedDict((k, float(v.detach())) for k, v in self.losses.items())
+
+
+class OracleDeepLIIFExt:
+    """Functional DeepLIIFExtModel (deepliif/models/DeepLIIFExt_model.py:160-269): M translation generators on real_A, M seg
+    generators on cat(real_A, fake_B[0], fake_B[i]) (9 channels, :173), seg discriminators on
+    cat(real_A, real_B[0], real_B[i], seg) (12 channels, :97,186).  Quirks restated: the generator-side seg GAN loss uses
+    criterionGAN_mod (:236) while the discriminator side uses criterionGAN_seg (:195,213); seg loss weights are 1/M (:27,30);
+    no VGG term (:257-265 commented out)."""
+
+    def __init__(self, cfg: OracleConfig, nets: Dict[str, Dict[str, torch.Tensor]], train_bn_running: bool = True):
+        self.cfg, self.nets, self.train_bn_running = cfg, nets, train_bn_running
+        M = cfg.modalities_no
+        self.g = [f'G_{i + 1}' for i in range(M)]
+        self.gs = [f'GS_{i + 1}' for i in range(M)] if cfg.seg_gen else []
+        self.d = [f'D_{i + 1}' for i in range(M)]
+        self.ds = [f'DS_{i + 1}' for i in range(M)] if cfg.seg_gen else []
+        self.losses: Dict[str, torch.Tensor] = {}
+
+        def trainable(names):
+            ps = []
+            for n in names:
+                for k, v in nets[n].items():
+                    if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
+                        v.requires_grad_(True)
+                        ps.append(v)
+            return ps
+        self.params_g = trainable(self.g + self.gs)
+        self.params_d = trainable(self.d + self.ds)
+        self.adam_g = AdamState(self.params_g, cfg.lr_g, cfg.beta1)
+        self.adam_d = AdamState(self.params_d, cfg.lr_d, cfg.beta1)
+
+    def _G(self, name, x, arch, padding):
+        return run_generator(arch, self.nets[name], x, self.cfg.norm, padding, self.train_bn_running)
+
+    def _D(self, name, x):
+        return nlayer_discriminator(self.nets[name], x, self.cfg.norm, self.cfg.n_layers_D, self.train_bn_running)
+
+    def set_input(self, batch):
+        self.real_A, self.real_B, self.real_BS = batch['A'], list(batch['B']), list(batch.get('BS', []))
+        self.real_cat = [torch.cat([self.real_A, self.real_B[0], self.real_B[i]], 1) for i in range(self.cfg.modalities_no)]
+
+    def forward(self):
+        c = self.cfg
+        self.fake_B = [self._G(n, self.real_A, c.net_g, c.padding) for n in self.g]
+        self.fake_BS = [self._G(n, torch.cat([self.real_A, self.fake_B[0], self.fake_B[i]], 1), c.net_gs, 'reflect')
+                        for i, n in enumerate(self.gs)]
+
+    def loss_D(self):
+        c, L, M = self.cfg, self.losses, self.cfg.modalities_no
+        for i in range(M):
+            L[f'D_fake_{i + 1}'] = gan_loss(self._D(self.d[i], torch.cat((self.real_A, self.fake_B[i]), 1).detach()), False, c.gan_mode)
+        for i in range(len(self.ds)):
+            L[f'DS_fake_{i + 1}'] = gan_loss(self._D(self.ds[i], torch.cat((self.real_cat[i], self.fake_BS[i]), 1).detach()), False, c.gan_mode_s)
+        for i in range(M):
+            L[f'D_real_{i + 1}'] = gan_loss(self._D(self.d[i], torch.cat((self.real_A, self.real_B[i]), 1)), True, c.gan_mode)
+        for i in range(len(self.ds)):
+            L[f'DS_real_{i + 1}'] = gan_loss(self._D(self.ds[i], torch.cat((self.real_cat[i], self.real_BS[i]), 1)), True, c.gan_mode_s)
+        total = 0.0
+        for i in range(M):
+            total = total + (L[f'D_fake_{i + 1}'] + L[f'D_real_{i + 1}']) * 0.5 * c.loss_D_weights[i]
+        for i in range(len(self.ds)):
+            total = total + (L[f'DS_fake_{i + 1}'] + L[f'DS_real_{i + 1}']) * 0.5 * (1.0 / M)
+        return total
+
+    def loss_G(self):
+        c, L, M = self.cfg, self.losses, self.cfg.modalities_no
+        for i in range(M):
+            L[f'G_GAN_{i + 1}'] = gan_loss(self._D(self.d[i], torch.cat((self.real_A, self.fake_B[i]), 1)), True, c.gan_mode)
+        for i in range(len(self.ds)):
+            L[f'GS_GAN_{i + 1}'] = gan_loss(self._D(self.ds[i], torch.cat((self.real_cat[i], self.fake_BS[i]), 1)), True, c.gan_mode)
+        for i in range(M):
+            L[f'G_L1_{i + 1}'] = smooth_l1(self.fake_B[i], self.real_B[i]) * c.lambda_L1
+        for i in range(len(self.gs)):
+            L[f'GS_L1_{i + 1}'] = smooth_l1(self.fake_BS[i], self.real_BS[i]) * c.lambda_L1
+        total = 0.0
+        for i in range(M):
+            total = total + (L[f'G_GAN_{i + 1}'] + L[f'G_L1_{i + 1}']) * c.loss_G_weights[i]
+        for i in range(len(self.gs)):
+            total = total + (L[f'GS_GAN_{i + 1}'] + L[f'GS_L1_{i + 1}']) * (1.0 / M)
+        return total
+
+    def optimize_parameters(self):
+        self.forward()
+        self.adam_d.step(torch.autograd.grad(self.loss_D(), self.params_d))
+        self.adam_g.step(torch.autograd.grad(self.loss_G(), self.params_g))
+
+    def current_losses(self):
+        return OrderedDict((k, float(v.detach())) for k, v in self.losses.items())

@@ -194,6 +194,47 @@ def make_step(tag, modalities_no, seg_gen, norm, padding, net_gs, size, nf=8, ba
     print(f'step_{tag}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def make_step_ext(tag, modalities_no, norm, size, nf=8, batch=1, steps=2):
+    """DeepLIIFExtModel trajectory (DeepLIIFExt_model.py): list-valued nets, GS input 9 ch, DS input 12 ch."""
+    out = {}
+    p = base_params(modalities_no, True, norm, 'zero', 'unet_64', nf)
+    p.update(model='DeepLIIFExt', net_ds='n_layers', seg_weights=[1.0 / modalities_no] * modalities_no,
+             loss_G_weights=[1.0 / modalities_no] * modalities_no, loss_D_weights=[1.0 / modalities_no] * modalities_no)
+    opt = Options(d_params=p)
+    from deepliif.models.DeepLIIFExt_model import DeepLIIFExtModel
+    model = DeepLIIFExtModel(opt)
+    model.setup(opt)
+    seeds = {}
+    for j, n in enumerate(model.model_names):
+        kind, idx = n.split('_')
+        net = getattr(model, 'net' + kind)[int(idx) - 1]
+        arch, cin, pad = {'G': ('resnet_9blocks', 3, 'zero'), 'GS': ('unet_64', 9, 'reflect'), 'D': ('n_layers', 6, 'zero'),
+                          'DS': ('n_layers', 12, 'zero')}[kind]
+        load_seeded(net, arch, cin, nf, norm, pad, 900 + j)
+        seeds[n] = 900 + j
+    A = seeded_uniform((batch, 3, size, size), 22)
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(modalities_no)]
+    BS = [seeded_uniform((batch, 3, size, size), 43 + i) for i in range(modalities_no)]
+    out['meta'] = np.array([str(modalities_no), norm, str(size), str(nf), str(batch), str(steps)])
+    out['model_names'] = np.array(model.model_names)
+    out['net_seeds'] = np.array([seeds[n] for n in model.model_names])
+    out['loss_names'] = np.array(model.loss_names)
+    for s in range(steps):
+        model.set_input({'A': A, 'B': B, 'BS': BS, 'A_paths': ['x']})
+        model.optimize_parameters()
+        losses = model.get_current_losses()
+        out[f'step{s}/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+        for i in range(modalities_no):
+            out[f'step{s}/fake_B_{i + 1}'] = model.fake_B[i].detach().numpy()[:, :, ::2, ::2]
+            out[f'step{s}/fake_BS_{i + 1}'] = model.fake_BS[i].detach().numpy()[:, :, ::2, ::2]
+        for n in model.model_names:
+            kind, idx = n.split('_')
+            sd = getattr(model, 'net' + kind)[int(idx) - 1].state_dict()
+            out[f'step{s}/w_digest/{n}'] = digest(torch.cat([v.reshape(-1).float() for v in sd.values() if v.is_floating_point()]))
+    np.savez_compressed(os.path.join(HERE, f'step_ext_{tag}.npz'), **out)
+    print(f'step_ext_{tag}.npz')
+
+
 def make_inference():
     """run_dask(tensor, nets, opt, use_dask=False, output_tensor=True): the 2-stage generator DAG + weighted seg sum
     (deepliif/models/__init__.py:293-361), one tile per call (SURVEY 0 #5)."""
@@ -236,3 +277,4 @@ if __name__ == '__main__':
     make_step('m4_seg_batch', 4, True, 'batch', 'zero', 'unet_64', 64, batch=2)
     make_step('m2_seg_instance_reflect', 2, True, 'instance', 'reflect', 'unet_64', 64, batch=1)
     make_inference()
+    make_step_ext('m2_batch', 2, 'batch', 64)

@@ -256,3 +256,38 @@ def test_training_step_golden_fixture_from_reference(tag, precname):
                 # bias correction or update direction (>= 100%), tolerates the sign flips of noise-level gradients
                 ok, msg = digest_close(flat, z[f'step{s}/w_digest/{name}'], 6e-3)
                 assert ok, f'step {s} weights of {name}: {msg}'
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_deepliif_ext_step_golden_fixture_from_reference(precname):
+    """DeepLIIFExtModel (9-channel seg generators, 12-channel seg discriminators) against the reference trajectory."""
+    z = np.load(os.path.join(G, 'step_ext_m2_batch.npz'))
+    Mn, norm, size, nf, batch, steps = z['meta']
+    Mn, size, nf, batch = int(Mn), int(size), int(nf), int(batch)
+    opt = make_opt(Mn, True, norm, 'unet_64', nf, precname)
+    opt.model, opt.net_ds = 'DeepLIIFExt', 'n_layers'
+    opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [1.0 / Mn] * Mn
+    model = M.create_model(opt)
+    model.setup(opt)
+    spec = {'G': ('resnet_9blocks', 3, 'zero'), 'GS': ('unet_64', 9, 'reflect'), 'D': ('n_layers', 6, 'zero'), 'DS': ('n_layers', 12, 'zero')}
+    for name, seed in zip(z['model_names'], z['net_seeds']):
+        arch, cin, pad = spec[str(name).split('_')[0]]
+        model._net(str(name)).load_state_dict(O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(int(seed))))
+    A = seeded_uniform((batch, 3, size, size), 22)
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(Mn)]
+    BS = [seeded_uniform((batch, 3, size, size), 43 + i) for i in range(Mn)]
+    ltol = {'fp32': (1e-3, 5e-3), 'bf16': (3e-2, 6e-2)}[precname]
+    otol = {'fp32': (1e-3, 8e-2), 'bf16': (6e-2, 3e-1)}[precname]
+    for s in range(int(steps)):
+        model.set_input({'A': A, 'B': B, 'BS': BS, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        for name, exp in zip(z['loss_names'], z[f'step{s}/losses']):
+            err = abs(got[str(name)] - exp) / max(1.0, abs(exp))
+            ERRLOG[f'step_ext/{precname}/s{s}/{name}'] = err
+            assert err <= ltol[min(s, 1)], (s, name, got[str(name)], exp)
+        for i in range(Mn):
+            for fam, t in (('fake_B', model.fake_B[i]), ('fake_BS', model.fake_BS[i])):
+                e = rel(t[:, :, ::2, ::2], torch.from_numpy(z[f'step{s}/{fam}_{i + 1}']))
+                ERRLOG[f'step_ext/{precname}/s{s}/{fam}_{i + 1}'] = e
+                assert e < otol[min(s, 1)]

@@ -84,3 +84,39 @@ def test_two_steps_follow_oracle(modalities_no, seg_gen, norm):
             a = torch.cat([v.reshape(-1).float() for v in sd.values() if v.is_floating_point()])
             b = torch.cat([v.detach().reshape(-1).float() for v in so.values() if v.is_floating_point()])
             assert float((a - b).norm() / b.norm()) < 1e-3, (step, n)
+
+
+class CpuExtModel(M.DeepLIIFExtModel):
+    def _device_from_opt(self, opt):
+        return torch.device('cpu')
+
+    def _net_gpu_ids(self):
+        return []
+
+
+def test_deepliif_ext_two_steps_follow_oracle():
+    torch.manual_seed(0)
+    opt = make_opt(2, True, 'batch')
+    opt.model, opt.net_ds = 'DeepLIIFExt', 'n_layers'
+    opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
+    model = CpuExtModel(opt)
+    model.setup(opt)
+    cfg = O.OracleConfig(modalities_no=2, seg_gen=True, norm='batch', padding='zero', net_gs='unet_64', ngf=8, ndf=8,
+                         loss_G_weights=[0.5, 0.5], loss_D_weights=[0.5, 0.5])
+    nets = {n: {k: v.detach().clone() for k, v in net.state_dict().items()} for n, net in model._nets()}
+    om = O.OracleDeepLIIFExt(cfg, nets)
+    A = seeded_uniform((1, 3, 64, 64), 22)
+    B = [seeded_uniform((1, 3, 64, 64), 23 + i) for i in range(2)]
+    BS = [seeded_uniform((1, 3, 64, 64), 43 + i) for i in range(2)]
+    for step in range(2):
+        model.set_input({'A': A, 'B': B, 'BS': BS, 'A_paths': ['x']})
+        model.optimize_parameters()
+        om.set_input({'A': A, 'B': B, 'BS': BS})
+        om.optimize_parameters()
+        got, exp = model.get_current_losses(), om.current_losses()
+        tol = 5e-4 if step == 0 else 5e-3
+        for k, v in got.items():
+            assert abs(v - exp[k]) <= tol * max(1.0, abs(exp[k])), (step, k, v, exp[k])
+        for i in range(2):
+            for a, b in ((model.fake_B[i], om.fake_B[i].detach()), (model.fake_BS[i], om.fake_BS[i].detach())):
+                assert float((a - b).abs().max() / b.abs().max()) < (5e-4 if step == 0 else 3e-2)

@@ -155,3 +155,35 @@ def test_inference_dag():
             seg = sum(segs[f'GS{i}'] * float(w[i]) for i in range(5))
             for k, v in {**gens, **segs, 'GS': seg}.items():
                 assert rel_err(v, z[f'tile{t}/{k}']) < RTOL, (t, k)
+
+
+def test_deepliif_ext_two_step_trajectory():
+    """DeepLIIFExtModel (DeepLIIFExt_model.py): list-valued nets, 9-channel seg generators, 12-channel seg discriminators."""
+    z = np.load(os.path.join(G, 'step_ext_m2_batch.npz'))
+    M, norm, size, nf, batch, steps = z['meta']
+    M, size, nf, batch = int(M), int(size), int(nf), int(batch)
+    cfg = O.OracleConfig(modalities_no=M, seg_gen=True, norm=norm, padding='zero', net_gs='unet_64', ngf=nf, ndf=nf,
+                         loss_G_weights=[1.0 / M] * M, loss_D_weights=[1.0 / M] * M)
+    spec = {'G': ('resnet_9blocks', 3, 'zero'), 'GS': ('unet_64', 9, 'reflect'), 'D': ('n_layers', 6, 'zero'), 'DS': ('n_layers', 12, 'zero')}
+    nets = {}
+    for name, seed in zip(z['model_names'], z['net_seeds']):
+        arch, cin, pad = spec[str(name).split('_')[0]]
+        nets[str(name)] = O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(int(seed)))
+    om = O.OracleDeepLIIFExt(cfg, nets)
+    A = seeded_uniform((batch, 3, size, size), 22)
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(M)]
+    BS = [seeded_uniform((batch, 3, size, size), 43 + i) for i in range(M)]
+    for s in range(int(steps)):
+        om.set_input({'A': A, 'B': B, 'BS': BS})
+        om.optimize_parameters()
+        got = om.current_losses()
+        tol = 2e-4 if s == 0 else 3e-3
+        for name, exp in zip(z['loss_names'], z[f'step{s}/losses']):
+            assert abs(got[str(name)] - exp) <= tol * max(1.0, abs(exp)), (s, name, got[str(name)], exp)
+        for i in range(M):
+            assert rel_err(om.fake_B[i].detach()[:, :, ::2, ::2], z[f'step{s}/fake_B_{i + 1}']) < (tol if s == 0 else 2e-2)
+            assert rel_err(om.fake_BS[i].detach()[:, :, ::2, ::2], z[f'step{s}/fake_BS_{i + 1}']) < (tol if s == 0 else 2e-2)
+        for n in z['model_names']:
+            flat = torch.cat([v.detach().reshape(-1).float() for v in nets[str(n)].values() if v.is_floating_point()])
+            ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
+            assert ok, f'step {s} weights of {n}: {msg}'
