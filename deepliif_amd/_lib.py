@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
                 ('tap_dh', C.c_int8 * MAX_TAPS), ('tap_dw', C.c_int8 * MAX_TAPS),
                 ('pad_mode', i32), ('w_kstride', i32), ('w_rows', i32), ('act', i32),
-                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32)]
+                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32)]
 
 
 class WgradDesc(C.Structure):
@@ -35,14 +35,14 @@ class WgradDesc(C.Structure):
                 ('Hq', i32), ('Wq', i32), ('CBp', i32), ('q_pstride', i32),
                 ('KH', i32), ('KW', i32), ('step', i32), ('pad', i32), ('pad_mode', i32),
                 ('CA', i32), ('CB', i32), ('dtype', i32), ('prec', i32), ('splitk', i32), ('accumulate', i32),
-                ('q_act', i32), ('p_act', i32)]
+                ('q_act', i32), ('p_act', i32), ('pad_w', i32), ('stack_kw', i32)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [('A', i32), ('B', i32), ('KH', i32), ('KW', i32), ('row_is_a', i32),
                 ('rows_real', i32), ('rows_pad', i32), ('Cc', i32), ('Cc_pad', i32), ('n_phase', i32),
                 ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
-                ('tap_kh', C.c_int8 * MAX_TAPS), ('tap_kw', C.c_int8 * MAX_TAPS), ('kstride', i32)]
+                ('tap_kh', C.c_int8 * MAX_TAPS), ('tap_kw', C.c_int8 * MAX_TAPS), ('kstride', i32), ('stack_kw', i32)]
 
 
 class NormDesc(C.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     'dl_channel_sum': (_i, [_i, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp]),
     'dl_nchw_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     'dl_nhwc_to_nchw': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    'dl_shift_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    'dl_shift_stack': (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),

@@ -26,7 +26,7 @@ struct ConvArgs {
     int phase_oh[DL_MAX_PHASES], phase_ow[DL_MAX_PHASES];
     int phase_tap_begin[DL_MAX_PHASES + 1];
     int phase_kbase[DL_MAX_PHASES];
-    int pad_mode, w_kstride, act, in_act, bias_n;
+    int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
     int tiles_m, tiles_n, Mtot;
     int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
 };
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
             const int co = tn * BN + wn * PN + i * 16 + fg * 4;
             if (co >= a.Co) continue;
             f32x4_t v = acc[i][j];
-            if (a.splitk > 1) {
+            if (a.splitk > 1 || a.raw_out) {
                 float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
             const int co = tn * BN + wn * PN + i * 16 + fg * 4;
             if (co >= a.Co) continue;
             f32x4_t v = acc[i][j];
-            if (a.splitk > 1) {
+            if (a.splitk > 1 || a.raw_out) {
                 float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -610,7 +610,7 @@ static int dispatch_tile(const ConvArgs &a, hipStream_t stream) {
 extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
                                void *out, float *slab, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!d || !in || !w_hi || !out) DL_FAIL("dl_conv_forward: null argument");
+    if (!d || !in || !w_hi || (!out && !d->raw_out)) DL_FAIL("dl_conv_forward: null argument");
     const int l2 = ilog2_exact(d->Ci);
     if (l2 < 3) DL_FAIL("dl_conv_forward: Ci=%d must be a power of two >= 8", d->Ci);
     if (d->Co % 8 || d->Co <= 0) DL_FAIL("dl_conv_forward: Co=%d must be a positive multiple of 8", d->Co);
@@ -620,7 +620,8 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     if (d->prec == DL_PREC_BF16X3 && !w_lo) DL_FAIL("dl_conv_forward: BF16X3 needs the lo weight plane");
     if (d->prec == DL_PREC_BF16X3 && d->in_dtype != DL_F32) DL_FAIL("dl_conv_forward: BF16X3 needs fp32 activations");
     if (d->in_dtype != d->out_dtype) DL_FAIL("dl_conv_forward: in/out dtype must match");
-    if (d->splitk < 1 || (d->splitk > 1 && !slab)) DL_FAIL("dl_conv_forward: splitk=%d needs a slab", d->splitk);
+    if (d->splitk < 1 || ((d->splitk > 1 || d->raw_out) && !slab)) DL_FAIL("dl_conv_forward: splitk=%d / raw_out needs a slab", d->splitk);
+    if (d->raw_out && d->splitk != 1) DL_FAIL("dl_conv_forward: raw_out requires splitk == 1");
     if (d->pad_mode == DL_PAD_REFLECT && (d->n_phase != 1)) DL_FAIL("dl_conv_forward: reflect padding only for single-phase layers");
     if ((size_t)d->N * d->Hi * d->Wi * (size_t)d->in_pstride >= ((size_t)1 << 40)) DL_FAIL("dl_conv_forward: tensor too large");
     for (int p = 0; p < d->n_phase; ++p)
@@ -636,7 +637,7 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     for (int p = 0; p < DL_MAX_PHASES; ++p) { a.phase_oh[p] = d->phase_oh[p]; a.phase_ow[p] = d->phase_ow[p]; a.phase_kbase[p] = d->phase_kbase[p]; }
     for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
     for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
-    a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n;
+    a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
     a.Mtot = d->N * d->Hq * d->Wq;
 
     int rc;

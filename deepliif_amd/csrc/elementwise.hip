@@ -275,6 +275,94 @@ extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, flo
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- narrow-Cout conv helpers
+__device__ __forceinline__ int reflect_w(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+// y[n,h,w,co] = act(bias[co] + sum_kw T[n,h,w+kw-pad,co*KW+kw]); pad channels of y are zeroed.
+// One block = SS_PIX consecutive pixels of one image row: the T rows (Tc fp32 channels per pixel) of those pixels plus the
+// (KW-1) halo are staged through LDS with coalesced 16-byte loads, then each thread sums its pixel's Cout*KW taps.
+#define SS_PIX 256
+template <typename T>
+__global__ void __launch_bounds__(256) shift_sum_kernel(const float *Tm, int N, int H, int W, int Tc, int Cout, int KW, int pad, int pad_mode,
+                                                        const float *bias, int act, T *out, int o_ps, int oCp) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [(SS_PIX + KW - 1)][Tc + 1]
+    const int segs = (W + SS_PIX - 1) / SS_PIX;
+    const int seg = blockIdx.x % segs;
+    const size_t row = blockIdx.x / segs;                             // (n*H + h)
+    const int w0 = seg * SS_PIX;
+    const int span = min(SS_PIX, W - w0) + KW - 1;
+    const int ld = Tc + 1;
+    // stage: pixel (w0 - pad + i), i in [0, span)
+    const int c4 = Tc / 4;
+    for (int q = threadIdx.x; q < span * c4; q += blockDim.x) {
+        const int i = q / c4, c = (q % c4) * 4;
+        int ws = w0 - pad + i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = (unsigned)ws < (unsigned)W;
+        if (pad_mode == DL_PAD_REFLECT) { ws = reflect_w(ws, W); ok = true; }
+        if (ok) v = *reinterpret_cast<const float4 *>(Tm + (row * W + ws) * Tc + c);
+        float *d = tile + i * ld + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int w = w0 + threadIdx.x;
+    if (threadIdx.x < SS_PIX && w < W) {
+        T *o = out + (row * W + w) * o_ps;
+        for (int co = 0; co < Cout; ++co) {
+            float s = bias ? bias[co] : 0.f;
+            for (int kw = 0; kw < KW; ++kw) s += tile[(threadIdx.x + kw) * ld + co * KW + kw];
+            store1<T>(o + co, apply_act(act, s));
+        }
+        for (int c = Cout; c < oCp; ++c) store1<T>(o + c, 0.f);
+    }
+}
+extern "C" int dl_shift_sum(const float *Tm, int N, int H, int W, int Tc, int Cout, int KW, int pad, int pad_mode, const float *bias, int act,
+                            int out_dtype, void *out, int o_ps, int oCp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!Tm || !out || Cout * KW > Tc || Tc % 4) DL_FAIL("dl_shift_sum: bad argument");
+    const int segs = (W + SS_PIX - 1) / SS_PIX;
+    const size_t blocks = (size_t)N * H * segs;
+    const size_t smem = (size_t)(SS_PIX + KW - 1) * (Tc + 1) * sizeof(float);
+    if (out_dtype == DL_F32) hipLaunchKernelGGL(shift_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), smem, stream, Tm, N, H, W, Tc, Cout, KW, pad, pad_mode, bias, act, (float *)out, o_ps, oCp);
+    else hipLaunchKernelGGL(shift_sum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), smem, stream, Tm, N, H, W, Tc, Cout, KW, pad, pad_mode, bias, act, (bf16_t *)out, o_ps, oCp);
+    DL_CHECK_LAUNCH("dl_shift_sum");
+    return 0;
+}
+// D[n,h,w,co*KW+kw] = dy[n,h,w-(kw-pad),co]  (zero outside; zero padding only).  One thread per pixel builds its whole
+// Dc-channel row in registers and writes it with 16-byte stores.
+template <typename T>
+__global__ void __launch_bounds__(256) shift_stack_kernel(const T *dy, int dy_ps, int N, int H, int W, int Cout, int KW, int pad, T *D, int Dc) {
+    const size_t npix = (size_t)N * H * W;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(p % W);
+        const size_t rowbase = p - w;
+        T *d = D + p * Dc;
+        for (int c0 = 0; c0 < Dc; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k;
+                const int co = c / KW, kw = c - co * KW;
+                const int ws = w - (kw - pad);
+                v[k] = (co < Cout && (unsigned)ws < (unsigned)W) ? load1<T>(dy + (rowbase + ws) * dy_ps + co) : 0.f;
+            }
+            Vec8<T>::store(d + c0, v);
+        }
+    }
+}
+extern "C" int dl_shift_stack(int dtype, const void *dy, int dy_ps, int N, int H, int W, int Cout, int KW, int pad, int pad_mode, void *D, int Dc,
+                              void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !D || Cout * KW > Dc || Dc % 8 || pad_mode != DL_PAD_ZERO) DL_FAIL("dl_shift_stack: bad argument (zero padding only)");
+    const size_t npix = (size_t)N * H * W;
+    if (dtype == DL_F32) hipLaunchKernelGGL(shift_stack_kernel<float>, dim3(EW_BLOCKS(npix)), dim3(256), 0, stream, (const float *)dy, dy_ps, N, H, W, Cout, KW, pad, (float *)D, Dc);
+    else hipLaunchKernelGGL(shift_stack_kernel<bf16_t>, dim3(EW_BLOCKS(npix)), dim3(256), 0, stream, (const bf16_t *)dy, dy_ps, N, H, W, Cout, KW, pad, (bf16_t *)D, Dc);
+    DL_CHECK_LAUNCH("dl_shift_stack");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- probes
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 

@@ -5,7 +5,7 @@
 struct PackArgs {
     const float *src;
     bf16_t *w_hi, *w_lo;
-    int A, B, KH, KW, row_is_a, rows_real, rows_pad, Cc, Cc_pad, log2Cc, n_phase, kstride;
+    int A, B, KH, KW, row_is_a, rows_real, rows_pad, Cc, Cc_pad, log2Cc, n_phase, kstride, stack_kw;
     int phase_tap_begin[DL_MAX_PHASES + 1];
     int phase_kbase[DL_MAX_PHASES];
     int phase_kend[DL_MAX_PHASES];
@@ -26,8 +26,10 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) {
                 const int tl = kl >> a.log2Cc, c = kl & (a.Cc_pad - 1);
                 const int t = a.phase_tap_begin[ph] + tl;
                 if (t < a.phase_tap_begin[ph + 1] && c < a.Cc) {
-                    const int kh = a.tap_kh[t], kw = a.tap_kw[t];
-                    const int ia = a.row_is_a ? row : c, ib = a.row_is_a ? c : row;
+                    const int kh = a.tap_kh[t];
+                    int kw = a.tap_kw[t], r = row;
+                    if (a.stack_kw) { kw = row % a.KW; r = row / a.KW; }      // row = a*KW + kw
+                    const int ia = a.row_is_a ? r : c, ib = a.row_is_a ? c : r;
                     v = a.src[(((size_t)ia * a.B + ib) * a.KH + kh) * a.KW + kw];
                 }
             }
@@ -49,7 +51,7 @@ extern "C" int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_
     a.src = src; a.w_hi = (bf16_t *)w_hi; a.w_lo = (bf16_t *)w_lo;
     a.A = d->A; a.B = d->B; a.KH = d->KH; a.KW = d->KW; a.row_is_a = d->row_is_a;
     a.rows_real = d->rows_real; a.rows_pad = d->rows_pad; a.Cc = d->Cc; a.Cc_pad = d->Cc_pad; a.log2Cc = l2;
-    a.n_phase = d->n_phase; a.kstride = d->kstride;
+    a.n_phase = d->n_phase; a.kstride = d->kstride; a.stack_kw = d->stack_kw;
     for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
     for (int p = 0; p < d->n_phase; ++p) {
         a.phase_kbase[p] = d->phase_kbase[p];

@@ -19,7 +19,7 @@ struct WgradArgs {
     float *slab;
     int N, Hp, Wp, CAp, p_pstride;
     int Hq, Wq, CBp, log2CB, q_pstride;
-    int KH, KW, step, pad, pad_mode;
+    int KH, KW, step, pad, pad_w, pad_mode;
     int J;              // KH*KW*CBp
     int Ptot;           // N*Hp*Wp
     int splitk, pchunk; // pixels per split (multiple of 32)
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < Q_CH; ++i) {
             const int p = pbase + (tid >> 4) + i * 16;
-            int h = qh[i] * a.step - a.pad + kh, w = qw[i] * a.step - a.pad + kw;
+            int h = qh[i] * a.step - a.pad + kh, w = qw[i] * a.step - a.pad_w + kw;
             bool ok = tap_ok && p < p_end;
             if (a.pad_mode == DL_PAD_REFLECT) { h = reflect_idx_w(h, a.Hq); w = reflect_idx_w(w, a.Wq); }
             else ok = ok && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < J_INS; ++i) {
-            const int h = q_h[i] * a.step - a.pad + q_kh[i], w = q_w[i] * a.step - a.pad + q_kw[i];
+            const int h = q_h[i] * a.step - a.pad + q_kh[i], w = q_w[i] * a.step - a.pad_w + q_kw[i];
             const bool ok = q_tap_ok[i] && (pbase + q_row[i] < p_end) && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
             const bf16_t *src = ok ? Q + ((size_t)(q_n[i] * a.Hq + h) * a.Wq + w) * a.q_pstride + q_cb[i] : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -422,7 +422,7 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
 // grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b].  Threads walk the slab in its own (contiguous) order so the reads
 // coalesce; the (small) gradient tensor takes the strided writes.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
-                                                           int KK, float *grad, int accumulate) {
+                                                           int KK, float *grad, int accumulate, int stack_kw) {
     const size_t total = (size_t)CA * J;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ca = (int)(i / J), j = (int)(i % J);
@@ -430,7 +430,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, in
         if (b >= CB || t >= KK) continue;
         float s = 0.f;
         for (int k = 0; k < splitk; ++k) s += slab[((size_t)k * CAp + ca) * J + j];
-        float *g = grad + ((size_t)ca * CB + b) * KK + t;
+        // stacked rows (ca = a*stack_kw + kw, t = kh): grad[a][b][kh][kw]
+        float *g = stack_kw ? grad + (((size_t)(ca / stack_kw) * CB + b) * KK + t) * stack_kw + (ca % stack_kw)
+                            : grad + ((size_t)ca * CB + b) * KK + t;
         *g = accumulate ? *g + s : s;
     }
 }
@@ -456,6 +458,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t stream) {
 template <typename T, int PREC>
 static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
     if (a.CAp <= 16) return launch_wgrad<T, PREC, 16, 1, 4>(a, stream);
+    if (a.CAp <= 32) return launch_wgrad<T, PREC, 32, 1, 4>(a, stream);
     if (a.CAp <= 64) return launch_wgrad<T, PREC, 64, 2, 2>(a, stream);
     return launch_wgrad<T, PREC, 128, 2, 2>(a, stream);
 }
@@ -468,6 +471,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (d->CAp % 8) DL_FAIL("dl_conv_wgrad: CAp=%d must be a multiple of 8", d->CAp);
     if (d->p_pstride % 8 || d->q_pstride % 8) DL_FAIL("dl_conv_wgrad: pixel strides must be multiples of 8");
     if (d->splitk < 1) DL_FAIL("dl_conv_wgrad: splitk=%d", d->splitk);
+    if (d->stack_kw && d->KW != 1) DL_FAIL("dl_conv_wgrad: stack_kw needs KW == 1");
     if (d->prec == DL_PREC_BF16X3 && d->dtype != DL_F32) DL_FAIL("dl_conv_wgrad: BF16X3 needs fp32 activations");
 
     WgradArgs a;
@@ -475,7 +479,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     a.P = P; a.Q = Q; a.slab = slab;
     a.N = d->N; a.Hp = d->Hp; a.Wp = d->Wp; a.CAp = d->CAp; a.p_pstride = d->p_pstride;
     a.Hq = d->Hq; a.Wq = d->Wq; a.CBp = d->CBp; a.log2CB = l2; a.q_pstride = d->q_pstride;
-    a.KH = d->KH; a.KW = d->KW; a.step = d->step; a.pad = d->pad; a.pad_mode = d->pad_mode;
+    a.KH = d->KH; a.KW = d->KW; a.step = d->step; a.pad = d->pad; a.pad_w = d->pad_w < 0 ? d->pad : d->pad_w; a.pad_mode = d->pad_mode;
     a.J = d->KH * d->KW * d->CBp;
     a.Ptot = d->N * d->Hp * d->Wp;
     a.splitk = d->splitk;
@@ -500,7 +504,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     const size_t total = (size_t)d->CA * a.J;
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
-                       grad, d->accumulate);
+                       grad, d->accumulate, d->stack_kw);
     DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");
     return 0;
 }

@@ -103,6 +103,10 @@ class ConvLayer:
         self.packed_dgrad: Optional[ops.PackedWeights] = None
         self.fwd_key = None
         self.dgrad_key = None
+        # narrow-Cout layers (the 7x7, 64 -> 3 ResnetGenerator head): kernel columns folded into the GEMM rows (dl_shift_sum)
+        self.narrow = spec.is_narrow()
+        if self.narrow:
+            self.fwd_plan = spec.narrow_forward_plan()
 
     @property
     def dgrad_plan(self):
@@ -171,7 +175,14 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     hq, wq = (ho, wo) if spec.kind == 'conv' else (hi, wi)
     if spec.kind == 'convT':
         assert (ho, wo) == (2 * hi, 2 * wi)
-    be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act, ctx.prec.prec)
+    if layer.narrow:
+        # T[n,h,w,(co,kw)] by the gather GEMM (vertical taps), then y = act(bias + sum_kw T[.., w+kw-pad, (co,kw)])
+        T = torch.empty((n, ho, wo, cpad(spec.cout * spec.k)), dtype=torch.float32, device=x.t.device)
+        be.conv_forward(layer.packed_fwd, x.t, T, ho, wo, None, L.ACT_NONE, in_act, ctx.prec.prec, raw_out=True)
+        be.shift_sum(T, spec.cout, spec.k, spec.pad, spec.pad_mode, layer.bias.detach() if layer.bias is not None else None, act, out)
+        del T
+    else:
+        be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act, ctx.prec.prec)
     y = Act(out, spec.cout, x_needs or w_needs)
     if not (x_needs or w_needs):
         return y
@@ -188,7 +199,13 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             be.act_backward(act, g, y.t, gp)
             g = gp
         if w_needs:
-            if spec.kind == 'conv':
+            if layer.narrow and spec.pad_mode == L.PAD_ZERO:
+                # D[.., (co,kw)] = dy shifted by kw; the weight gradient becomes a KH x 1 problem with Cout*KW rows
+                D = torch.empty((n, ho, wo, cpad(spec.cout * spec.k)), dtype=g.dtype, device=g.device)
+                be.shift_stack(g, spec.cout, spec.k, spec.pad, D)
+                be.conv_wgrad(D, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec, True, stack_kw=spec.k)
+                del D
+            elif spec.kind == 'conv':
                 be.conv_wgrad(g, x.t, layer.weight.grad, spec.k, spec.stride, spec.pad, spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True)
             else:
                 be.conv_wgrad(x.t, g, layer.weight.grad, spec.k, spec.stride, spec.pad, L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True)

@@ -43,6 +43,7 @@ class GatherPlan:
     cc_pad: int = 0
     kbase: List[int] = field(default_factory=list)
     kstride: int = 0
+    stack_kw: int = 0                           # >0: packed row = a*stack_kw + kw (narrow-Cout path)
 
     def finish(self):
         self.rows_pad = round_up(cpad(self.rows_real), 128)
@@ -101,6 +102,17 @@ class ConvSpec:
                 phases.append(taps)
         return GatherPlan(4, offs, phases, 2, 1, L.PAD_ZERO, False, self.cout, self.cin).finish()
 
+    # ---- narrow-Cout forward (dl_shift_sum): rows = (co, kw), vertical taps only
+    def is_narrow(self) -> bool:
+        return self.kind == 'conv' and self.stride == 1 and self.cout <= 4 and self.k >= 5 and self.cout * self.k <= 32
+
+    def narrow_forward_plan(self) -> GatherPlan:
+        k, p = self.k, self.pad
+        taps = [(kh - p, 0, kh, 0) for kh in range(k)]
+        plan = GatherPlan(1, [(0, 0)], [taps], 1, 1, self.pad_mode, True, self.cout * k, self.cin)
+        plan.stack_kw = k
+        return plan.finish()
+
     # ---- data gradient: dx = layer^T(dy)
     def dgrad_plan(self) -> GatherPlan:
         k, p, s = self.k, self.pad, self.stride
@@ -140,6 +152,9 @@ def fill_pack_desc(plan: GatherPlan, A: int, B: int, k: int) -> L.PackDesc:
     for i, (_, _, kh, kw) in enumerate(plan.taps_flat()):
         d.tap_kh[i], d.tap_kw[i] = kh, kw
     d.kstride = plan.kstride
+    d.stack_kw = 1 if plan.stack_kw else 0
+    if plan.stack_kw:
+        d.KW = plan.stack_kw
     return d
 
 
@@ -163,7 +178,7 @@ def choose_splitk(plan: GatherPlan, n: int, hq: int, wq: int, co_pad: int, targe
 
 
 def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, ho: int, wo: int, out_cp: int, out_pstride: int,
-                   hq: int, wq: int, dtype: int, prec: int, act: int, in_act: int, bias_n: int, splitk: int) -> L.ConvDesc:
+                   hq: int, wq: int, dtype: int, prec: int, act: int, in_act: int, bias_n: int, splitk: int, raw_out: int = 0) -> L.ConvDesc:
     d = L.ConvDesc()
     d.N, d.Hi, d.Wi, d.Ci, d.in_pstride = n, hi, wi, plan.cc_pad, in_pstride
     d.Ho, d.Wo, d.Co, d.out_pstride = ho, wo, out_cp, out_pstride
@@ -178,6 +193,7 @@ def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, 
         d.tap_dh[i], d.tap_dw[i] = dh, dw
     d.pad_mode, d.w_kstride, d.w_rows = plan.pad_mode, plan.kstride, plan.rows_pad
     d.act, d.in_dtype, d.out_dtype, d.prec, d.splitk, d.in_act, d.bias_n = act, dtype, dtype, prec, splitk, in_act, bias_n
+    d.raw_out = raw_out
     return d
 
 

@@ -88,12 +88,23 @@ class HipBackend:
         _need_cuda(src, packed.hi)
         assert src.dtype == torch.float32 and src.is_contiguous()
         d = fill_pack_desc(packed.plan, src.shape[0], src.shape[1], src.shape[2])
+        d.KH = src.shape[2]
         L.check(self.lib.dl_pack_weights(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), _stream()), 'dl_pack_weights')
 
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
-                     act: int, in_act: int, prec: int, splitk: Optional[int] = None):
+                     act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False):
+        """raw_out: `out` is an fp32 [N,Ho,Wo,Co] tensor that receives the raw accumulators (narrow-Cout path)"""
         _need_cuda(x, out, bias)
+        if raw_out:
+            plan = packed.plan
+            n, hi, wi, cp = x.shape
+            _, ho, wo, cop = out.shape
+            assert out.dtype == torch.float32 and out.is_contiguous()
+            d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, cop, hq, wq, dl_dtype(x), prec, L.ACT_NONE, in_act, 0, 1, 1)
+            L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), None, None, _ptr(out), _stream()),
+                    'dl_conv_forward(raw)')
+            return
         plan = packed.plan
         n, hi, wi, cp = x.shape
         assert cp == plan.cc_pad, (cp, plan.cc_pad)
@@ -109,7 +120,8 @@ class HipBackend:
 
     # ---- weight gradient
     def conv_wgrad(self, P: torch.Tensor, Q: torch.Tensor, grad: torch.Tensor, k: int, step: int, pad: int, pad_mode: int,
-                   p_act: int, q_act: int, prec: int, accumulate: bool, splitk: Optional[int] = None):
+                   p_act: int, q_act: int, prec: int, accumulate: bool, splitk: Optional[int] = None, stack_kw: int = 0):
+        """stack_kw > 0: P is a dl_shift_stack image (channel = a*stack_kw + kw); vertical taps only (KH = k, KW = 1)"""
         _need_cuda(P, Q, grad)
         assert grad.dtype == torch.float32 and grad.is_contiguous()
         d = L.WgradDesc()
@@ -120,8 +132,11 @@ class HipBackend:
         d.KH = d.KW = k
         d.step, d.pad, d.pad_mode = step, pad, pad_mode
         d.CA, d.CB = grad.shape[0], grad.shape[1]
+        d.pad_w, d.stack_kw = -1, 0
+        if stack_kw:
+            d.KW, d.pad_w, d.stack_kw, d.CA = 1, 0, stack_kw, grad.shape[0] * stack_kw
         d.dtype, d.prec = dl_dtype(P), prec
-        j = k * k * d.CBp
+        j = d.KH * d.KW * d.CBp
         fast = wgrad_fast_path(d.CAp, j, d.dtype == L.DL_BF16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE,
                                pad_mode == L.PAD_ZERO)
         d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
@@ -200,6 +215,21 @@ class HipBackend:
         assert dst.dtype == torch.float32 and dst.is_contiguous()
         n, c, h, w = dst.shape
         L.check(self.lib.dl_nhwc_to_nchw(dl_dtype(src), _ptr(src), pstride(src), c0, _ptr(dst), n, c, h, w, _stream()), 'dl_nhwc_to_nchw')
+
+    # ---- narrow-Cout helpers
+    def shift_sum(self, T, cout, kw, pad, pad_mode, bias, act, out):
+        _need_cuda(T, out, bias)
+        n, h, w, tc = T.shape
+        assert T.dtype == torch.float32 and T.is_contiguous()
+        L.check(self.lib.dl_shift_sum(_ptr(T), n, h, w, tc, cout, kw, pad, pad_mode, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out),
+                                      out.shape[3], _stream()), 'dl_shift_sum')
+
+    def shift_stack(self, dy, cout, kw, pad, D):
+        _need_cuda(dy, D)
+        n, h, w, _ = dy.shape
+        assert D.is_contiguous() and D.dtype == dy.dtype
+        L.check(self.lib.dl_shift_stack(dl_dtype(dy), _ptr(dy), pstride(dy), n, h, w, cout, kw, pad, L.PAD_ZERO, _ptr(D), D.shape[3], _stream()),
+                'dl_shift_stack')
 
     # ---- losses
     def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):

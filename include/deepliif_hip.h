@@ -74,6 +74,8 @@ typedef struct dl_conv_desc {
     int32_t in_act;                 /* activation applied to the INPUT while it is staged (DL_ACT_NONE/RELU/LRELU):
                                        UnetSkipConnectionBlock's pre-activation (networks.py:578-602)             */
     int32_t bias_n;                 /* valid entries of `bias` (the real channel count; bias may be unaligned)    */
+    int32_t raw_out;                /* 1: write the raw fp32 accumulators to `slab` ([N*Ho*Wo][Co]) and nothing to `out`
+                                       (first half of the narrow-Cout path, see dl_shift_sum)                            */
 } dl_conv_desc;
 
 int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
@@ -98,6 +100,9 @@ typedef struct dl_wgrad_desc {
     int32_t accumulate;                  /* 0: grad = result, 1: grad += result              */
     int32_t q_act;                       /* activation applied to Q while staged (see dl_conv_desc.in_act) */
     int32_t p_act;
+    int32_t pad_w;                       /* horizontal padding; -1 = same as `pad` */
+    int32_t stack_kw;                    /* >0: P's channel a' = a*stack_kw + kw (dl_shift_stack image), KW must be 1; the result goes to
+                                            grad[a][b][kh][kw] with stack_kw kernel columns */
 } dl_wgrad_desc;
 
 int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
@@ -117,9 +122,20 @@ typedef struct dl_pack_desc {
     int32_t phase_kbase[DL_MAX_PHASES];
     int8_t tap_kh[DL_MAX_TAPS], tap_kw[DL_MAX_TAPS];
     int32_t kstride;
+    int32_t stack_kw;                    /* 1: packed row = a*KW + kw (kernel column folded into the row index), taps give kh only */
 } dl_pack_desc;
 
 int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream);
+
+/* Narrow-Cout convolutions (the 7x7 ResnetGenerator head, networks.py:438-443: 64 -> 3 channels): an MFMA tile has at least 16
+ * output rows, so Cout = 3 would waste 13/16 of the matrix pipe.  The kernel column is folded into the GEMM rows instead:
+ *   T[n,h,w,(co,kw)] = sum_{kh,ci} x[n,h+kh-pad,w,ci] * W[co,ci,kh,kw]      (dl_conv_forward, KH vertical taps, Cout*KW rows, raw_out)
+ *   y[n,h,w,co]      = act(bias[co] + sum_kw T[n,h,w+kw-pad,co*KW+kw])      (dl_shift_sum)
+ * and for the weight gradient  D[n,h,w,(co,kw)] = dy[n,h,w-(kw-pad),co]  (dl_shift_stack) feeds dl_conv_wgrad with KH x 1 taps. */
+int dl_shift_sum(const float *T, int N, int H, int W, int Tc, int Cout, int KW, int pad, int pad_mode, const float *bias, int act,
+                 int out_dtype, void *out, int out_pstride, int out_Cp, void *stream);
+int dl_shift_stack(int dtype, const void *dy, int dy_pstride, int N, int H, int W, int Cout, int KW, int pad, int pad_mode,
+                   void *D, int Dc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Normalisation (networks.py:25-44: BatchNorm2d on batch statistics / InstanceNorm2d; eps 1e-5, biased variance)

@@ -62,11 +62,15 @@ class FakeBackend:
         for ph, taps in enumerate(plan.phase_taps):
             for tl, (_, _, kh, kw) in enumerate(taps):
                 k0 = plan.kbase[ph] + tl * plan.cc_pad
+                if plan.stack_kw:            # row = a*KW + kw, taps give kh only
+                    blk = src[:, :, kh, :].float().permute(0, 2, 1).reshape(-1, src.shape[1])      # [(a,kw)][b]
+                    W[:plan.rows_real, k0:k0 + plan.cc_real] = blk
+                    continue
                 blk = src[:, :, kh, kw].float()
                 W[:plan.rows_real, k0:k0 + plan.cc_real] = blk if plan.row_is_a else blk.t()
         packed.fake_w = W
 
-    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None):
+    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False):
         self._count('conv')
         plan = packed.plan
         xv = _act(in_act, x.float())
@@ -83,12 +87,22 @@ class FakeBackend:
             acc[..., :bias.numel()] += bias.float()
         out.copy_(_act(act, acc).to(out.dtype))
 
-    def conv_wgrad(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, accumulate, splitk=None):
+    def conv_wgrad(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, accumulate, splitk=None, stack_kw=0):
         self._count('wgrad')
         Pv, Qv = _act(p_act, P.float()), _act(q_act, Q.float())
         CA, CB = grad.shape[0], grad.shape[1]
         N, Hp, Wp, _ = Pv.shape
         g = torch.zeros_like(grad)
+        if stack_kw:          # P channels = (a, kw); vertical taps only
+            for kh in range(k):
+                qg = _gather(Qv, Hp, Wp, step, kh - pad, 0, pad_mode == L.PAD_REFLECT)
+                r = torch.einsum('nhwa,nhwb->ab', Pv[..., :CA * stack_kw], qg[..., :CB])       # [(a,kw)][b]
+                g[:, :, kh, :] = r.view(CA, stack_kw, CB).permute(0, 2, 1)
+            if accumulate:
+                grad.add_(g)
+            else:
+                grad.copy_(g)
+            return
         for kh in range(k):
             for kw in range(k):
                 qg = _gather(Qv, Hp, Wp, step, kh - pad, kw - pad, pad_mode == L.PAD_REFLECT)
@@ -196,6 +210,34 @@ class FakeBackend:
         self._count('to_nchw')
         C = dst.shape[1]
         dst.copy_(src[..., c0:c0 + C].permute(0, 3, 1, 2).float())
+
+    def shift_sum(self, T, cout, kw, pad, pad_mode, bias, act, out):
+        self._count('shift_sum')
+        n, h, w, _ = T.shape
+        acc = torch.zeros(n, h, w, cout)
+        idx = torch.arange(w)
+        for k in range(kw):
+            ws = idx + k - pad
+            if pad_mode == L.PAD_REFLECT:
+                ws = _reflect(ws, w)
+                acc += T[:, :, ws][..., k:cout * kw:kw]
+            else:
+                m = ((ws >= 0) & (ws < w)).float()
+                acc += T[:, :, ws.clamp(0, w - 1)][..., k:cout * kw:kw] * m[None, None, :, None]
+        if bias is not None:
+            acc += bias.float()
+        out.zero_()
+        out[..., :cout] = _act(act, acc).to(out.dtype)
+
+    def shift_stack(self, dy, cout, kw, pad, D):
+        self._count('shift_stack')
+        n, h, w, _ = dy.shape
+        D.zero_()
+        idx = torch.arange(w)
+        for k in range(kw):
+            ws = idx - (k - pad)
+            m = ((ws >= 0) & (ws < w)).to(dy.dtype)
+            D[..., k:cout * kw:kw] = dy[:, :, ws.clamp(0, w - 1)][..., :cout] * m[None, None, :, None]
 
     def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
         self._count('loss')

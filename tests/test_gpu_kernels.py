@@ -327,3 +327,42 @@ def test_adam_matches_torch():
         real.adam_step(p_r, grad.to(DEV), m, v, 2e-4, 0.5, 0.999, 1e-8, step, 1.0)
     sync()
     assert float((p_r.cpu() - p_t.detach()).abs().max()) < 2e-8
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('pm', [L.PAD_ZERO, L.PAD_REFLECT])
+def test_narrow_cout_head_conv(precname, pm):
+    """7x7, 64 -> 3 head (networks.py:438-443) through the kernel-column-stacked path: dl_pack_weights(stack_kw) +
+    dl_conv_forward(raw_out) + dl_shift_sum, and dl_shift_stack + dl_conv_wgrad(stack_kw); engine-level, both backends."""
+    from deepliif_amd import engine as E
+    prec = Precision.get(precname)
+    spec = ConvSpec('conv', 64, 3, 7, 1, 3, pm)
+    assert spec.is_narrow()
+    w0 = rnd((3, 64, 7, 7), 1, prec, 0.05)
+    b0 = rnd((3,), 2, Precision.get('fp32'), 0.1)
+    x0 = rnd((2, 20, 24, 64), 3, prec)
+    g0 = torch.zeros(2, 20, 24, 8)
+    g0[..., :3] = rnd((2, 20, 24, 3), 4, prec)
+    res = {}
+    for name, dev in (('fake', 'cpu'), ('real', DEV)):
+        ops._impl = fake_backend.FakeBackend() if name == 'fake' else hip()
+        w = torch.nn.Parameter(w0.clone().to(dev)); w.grad = torch.zeros_like(w)
+        b = torch.nn.Parameter(b0.clone().to(dev)); b.grad = torch.zeros_like(b)
+        layer = E.ConvLayer(spec, w, b)
+        tape = E.Tape() if pm == L.PAD_ZERO else None
+        ctx = E.Ctx(prec, tape, training=True)
+        xa = E.Act(x0.to(prec.dtype).to(dev), 64, False)
+        y = E.conv(ctx, xa, layer, act=L.ACT_TANH)
+        out = {'y': y.t.float().cpu()}
+        if tape is not None:
+            y.grad = g0.to(prec.dtype).to(dev)
+            tape.backward()
+            out['dw'], out['db'] = w.grad.cpu(), b.grad.cpu()
+        res[name] = out
+    sync()
+    ops._impl = None
+    t = 1e-4 if precname == 'fp32' else 8e-3
+    assert rel(res['real']['y'], res['fake']['y']) < t
+    if pm == L.PAD_ZERO:
+        assert rel(res['real']['dw'], res['fake']['dw']) < (1e-4 if precname == 'fp32' else 2e-3)
+        assert rel(res['real']['db'], res['fake']['db']) < 1e-3
