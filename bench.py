@@ -9,7 +9,7 @@ One "step" = model.set_input(batch) + model.optimize_parameters() of the DeepLII
 batch of 8 synthetic 512x512x3 tiles per GPU that is already resident in HBM (BASELINE.json configs[2] per GPU; weak
 scaling).  `--workload infer` times the 9-generator inference DAG of configs[1] instead (4 Resnet-9 + 5 UNet-512, batch 8).
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : dominant kernel = conv_gemm 128x128x64 (3x3, 256->256 ch, 8x128x128 pixels: the 18 ResnetBlock convs and
+  roofline     : dominant kernel = conv_gemm_glds 256x256x64 (3x3, 256->256 ch, 8x128x128 pixels: the 18 ResnetBlock convs and
                  their data-gradients), per-launch time from HIP events recorded on the launch stream inside the timed region
   cpu_baseline : the CPU oracle (oracle/deepliif_oracle.py, a port of the reference's PyTorch step) timed on this box's host
                  cores for ONE step at batch 1 (rank 0, N=1 only).
@@ -208,10 +208,16 @@ def main():
     kt = timer.mean_seconds()
     flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * 256 * 256 * 9
     roofline = None
+    traffic = None
+    try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc.sh)
+        with open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_dominant_conv256.json')) as f:
+            traffic = json.load(f)['traffic_bytes'] if (n, s, args.precision) == (8, 512, 'bf16') else None
+    except Exception:
+        traffic = None
     if kt:
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': None, 'kernel': 'conv_gemm_kernel<128x128x64> 3x3 256->256 @ 8x128x128 (ResnetBlock conv fwd + dgrad)',
+                    'traffic': traffic, 'kernel': 'conv_gemm_glds_kernel<256x256x64, 8 waves> 3x3 256->256 @ 8x128x128 (ResnetBlock conv fwd + dgrad)',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
         'metric': '512x512 tiles/s train-step (5G+5D)' if args.workload == 'train' else '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)',

@@ -65,6 +65,7 @@ SIGNATURES = {
     'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'dl_act_forward': (_i, [_i, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_act_backward': (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_dropout': (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _f, C.c_uint64, _vp]),
     'dl_axpby': (_i, [_i, _f, _vp, _i, _f, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_copy_channels': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _vp]),
     'dl_channel_sum': (_i, [_i, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp]),

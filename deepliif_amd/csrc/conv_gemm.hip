@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
-template <int BM, int BN, int BK, int WM, int WN, bool UTAP>
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false>
 __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN;                        // waves per workgroup (4 or 8)
     constexpr int CPR = BK / 8;                        // 16-byte chunks per LDS row
@@ -463,23 +463,58 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
     int foff[BK / 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) foff[kk] = (fr * CPR + swz_chunk<CPR>(fr, kk * 4 + fg)) * 8;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);
-        const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+    auto read_frags = [&](const bf16_t *Xs, const bf16_t *Ws, int kk, bf16x8_t (&wf)[FN], bf16x8_t (&xf)[FM]) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8_t wf[FN], xf[FM];
+        for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t *>(Ws + (wn * PN + i * 16) * BK + foff[kk]);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t *>(Ws + (wn * PN + i * 16) * BK + foff[kk]);
+        for (int j = 0; j < FM; ++j) xf[j] = *reinterpret_cast<const bf16x8_t *>(Xs + (wm * PM + j * 16) * BK + foff[kk]);
+    };
+    auto mma = [&](const bf16x8_t (&wf)[FN], const bf16x8_t (&xf)[FM]) {
 #pragma unroll
-            for (int j = 0; j < FM; ++j) xf[j] = *reinterpret_cast<const bf16x8_t *>(Xs + (wm * PM + j * 16) * BK + foff[kk]);
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+
+    if constexpr (STAG && NW == 8 && BK == 64) {
+        // EXPERIMENT (DL_CONV_STAGGER=1; measured round 1: 0.188 ms vs 0.176 ms for the plain loop on the 3x3 256->256 conv --
+        // the strictly sequential phases lose more intra-wave overlap than the stagger wins; kept for the next tuning pass).
+        // Two waves share each SIMD (wave w and w+4).  The second group runs half a K step behind: it keeps the fragments of
+        // the second K half in registers across the barrier and multiplies them while the first group is fetching its
+        // fragments from LDS (and vice versa), so the LDS reads of one group overlap the MFMAs of the other instead of all
+        // eight waves queueing on the LDS at once after every barrier.
+        const bool late = wave >= 4;
+        bf16x8_t wf[FN], xf[FM];                 // ONE fragment set; for the late group it is carried across the barrier
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);
+            const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+            // phases are kept strictly sequential inside a wave (sched_barrier): the overlap comes from the partner wave
+            if (late && kt > kt_begin) mma(wf, xf);          // second K half of the previous tile, from registers
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(Xs, Ws, 0, wf, xf);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wf, xf);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(Xs, Ws, 1, wf, xf);                   // late group: must land before the barrier (buffer refilled next step)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late) mma(wf, xf);
+            __syncthreads();
         }
-        __syncthreads();
+        if (late && kt_begin < kt_end) mma(wf, xf);
+    } else {
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);
+            const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8_t wf[FN], xf[FM];
+                read_frags(Xs, Ws, kk, wf, xf);
+                mma(wf, xf);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (identical to the register-staged kernel)
@@ -518,13 +553,13 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool UTAP>
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false>
 static int launch_conv_glds_impl(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + BM - 1) / BM;
     a.tiles_n = (a.Co + BN - 1) / BN;
     constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * (sizeof(int16_t) + sizeof(int));
-    auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP>;
+    auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP, STAG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -551,7 +586,11 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     // 256x256x64, 8 waves (each 128 pixels x 64 channels): twice the FLOP per staged byte of the 128x128 tile; needs
     // enough tiles to fill 256 CUs
     if (!no_big && a.Co >= 256 && (a.Co % 256) == 0 && (size_t)((a.Mtot + 255) / 256) * (a.Co / 256) * a.n_phase * a.splitk >= 256)
+    {
+        static const bool stag = getenv("DL_CONV_STAGGER") != nullptr;
+        if (stag && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, true>(a, stream);
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
+    }
     return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
 }
 

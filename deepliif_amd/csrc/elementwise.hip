@@ -275,6 +275,41 @@ extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, flo
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- dropout
+// nn.Dropout(0.5) of ResnetBlock / UnetSkipConnectionBlock (networks.py:493-494, 604-605): y = x * keep / (1 - p).  The keep mask
+// is a counter-based hash of (seed, element index), so the backward pass regenerates it from the same seed instead of storing it.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_kernel(const T *x, int x_ps, T *y, int y_ps, size_t npix, int Cp, uint32_t seed, uint32_t thresh,
+                                                      float scale) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cvec;
+        const int c0 = (int)(i % cvec) * 8;
+        float v[8];
+        Vec8<T>::load(x + p * x_ps + c0, v);
+        const uint32_t base = hash32((uint32_t)(i * 8) ^ (uint32_t)((i * 8) >> 32) * 0x9e3779b9U ^ seed);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (hash32(base + 0x9e3779b9U * (uint32_t)(k + 1)) >= thresh) ? v[k] * scale : 0.f;
+        Vec8<T>::store(y + p * y_ps + c0, v);
+    }
+}
+extern "C" int dl_dropout(int dtype, const void *x, int x_ps, void *y, int y_ps, int64_t npix, int Cp, float p, uint64_t seed, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || Cp % 8 || x_ps % 8 || y_ps % 8 || !(p >= 0.f && p < 1.f)) DL_FAIL("dl_dropout: bad argument");
+    const size_t total = (size_t)npix * (Cp / 8);
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t s32 = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x85ebca6bU;
+    if (dtype == DL_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)x, x_ps, (float *)y, y_ps, (size_t)npix, Cp, s32, thresh, 1.f / (1.f - p));
+    else hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)x, x_ps, (bf16_t *)y, y_ps, (size_t)npix, Cp, s32, thresh, 1.f / (1.f - p));
+    DL_CHECK_LAUNCH("dl_dropout");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- narrow-Cout conv helpers
 __device__ __forceinline__ int reflect_w(int i, int n) {
     i = i < 0 ? -i : i;

@@ -423,17 +423,26 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
 // coalesce; the (small) gradient tensor takes the strided writes.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate, int stack_kw) {
-    const size_t total = (size_t)CA * J;
+    const int J4 = J / 4;
+    const size_t total = (size_t)CA * J4;
+    const size_t kstride = (size_t)CAp * J;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ca = (int)(i / J), j = (int)(i % J);
-        const int t = j / CBp, b = j % CBp;
-        if (b >= CB || t >= KK) continue;
-        float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += slab[((size_t)k * CAp + ca) * J + j];
-        // stacked rows (ca = a*stack_kw + kw, t = kh): grad[a][b][kh][kw]
-        float *g = stack_kw ? grad + (((size_t)(ca / stack_kw) * CB + b) * KK + t) * stack_kw + (ca % stack_kw)
-                            : grad + ((size_t)ca * CB + b) * KK + t;
-        *g = accumulate ? *g + s : s;
+        const int ca = (int)(i / J4), j = (int)(i % J4) * 4;
+        const float *src = slab + (size_t)ca * J + j;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < splitk; ++k) s += *reinterpret_cast<const f32x4_t *>(src + k * kstride);
+        const int t = j / CBp, b0 = j % CBp;            // 4 consecutive j share the tap (CBp is a multiple of 8)
+        if (t >= KK) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = b0 + e;
+            if (b >= CB) continue;
+            // stacked rows (ca = a*stack_kw + kw, t = kh): grad[a][b][kh][kw]
+            float *g = stack_kw ? grad + (((size_t)(ca / stack_kw) * CB + b) * KK + t) * stack_kw + (ca % stack_kw)
+                                : grad + ((size_t)ca * CB + b) * KK + t;
+            *g = accumulate ? *g + s[e] : s[e];
+        }
     }
 }
 
@@ -501,7 +510,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (rc) return rc;
 
     const int KK = d->KH * d->KW;
-    const size_t total = (size_t)d->CA * a.J;
+    const size_t total = (size_t)d->CA * (a.J / 4);
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
                        grad, d->accumulate, d->stack_kw);

@@ -291,6 +291,32 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
     return z
 
 
+_DROPOUT_COUNTER = [0]
+
+
+def dropout(ctx: Ctx, x: Act, p: float, in_place: bool = False) -> Act:
+    """nn.Dropout(p) in training mode.  The mask is a function of a per-call seed (torch's CPU RNG seeds the stream, so
+    torch.manual_seed() makes runs repeatable); backward re-applies the same mask to the gradient."""
+    be = ops.impl()
+    _DROPOUT_COUNTER[0] += 1
+    seed = (int(torch.initial_seed()) * 1000003 + _DROPOUT_COUNTER[0]) & (2 ** 63 - 1)
+    out = x.t if in_place else empty_like_act(x.t)
+    be.dropout(x.t, out, p, seed)
+    needs = ctx.tape is not None and x.needs_grad
+    z = x if in_place else Act(out, x.C, needs)
+    if needs and not in_place:
+        def backward():
+            g = z.grad
+            z.grad = None
+            if g is None:
+                return
+            dx = empty_like_act(g)
+            be.dropout(g, dx, p, seed)
+            x.add_grad(dx)
+        ctx.tape.record(backward)
+    return z
+
+
 def concat_channels(ctx: Ctx, parts: List[Act]) -> Act:
     """torch.cat(parts, 1) for small channel counts (D inputs: cat(cond, image), DeepLIIF_model.py:223)."""
     be = ops.impl()

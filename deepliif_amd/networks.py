@@ -190,11 +190,10 @@ class ResnetGenerator(EngineNet):
         for c, n in b['down']:
             h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
         for ent, blk in b['blocks']:
-            if blk.use_dropout and blk.training and ctx.tape is not None:
-                raise NotImplementedError('dropout inside the training graph is not implemented yet (use no_dropout=True); '
-                                          'all parity vectors are dropout-free (SURVEY 0)')
             (c1, n1), (c2, n2) = ent
             r = E.norm_act(ctx, E.conv(ctx, h, c1), n1, L.ACT_RELU)
+            if blk.use_dropout and blk.training:       # nn.Dropout(0.5) after the first norm+ReLU (networks.py:493-494)
+                r = E.dropout(ctx, r, 0.5)
             h = E.norm_act(ctx, E.conv(ctx, r, c2), n2, L.ACT_NONE, residual=h)
         for c, n in b['up']:
             h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
@@ -279,9 +278,6 @@ class UnetGenerator(EngineNet):
         D = len(lv)
         dev, dt = x.t.device, ctx.prec.dtype
         n = x.t.shape[0]
-        for l in lv:
-            if l['block'].use_dropout and l['block'].training and ctx.tape is not None:
-                raise NotImplementedError('dropout inside the training graph is not implemented yet (use no_dropout=True)')
         # ---- down path.  cat[d] (d = 1..D-1) = [h_d | u_d] at the resolution of block d's input
         cats: List[Optional[torch.Tensor]] = [None] * D
         firsts: List[Optional[E.Act]] = [None] * D
@@ -315,10 +311,21 @@ class UnetGenerator(EngineNet):
             cout = l['up'].spec.cout
             second = cat[..., cout:]
             y = E.conv(ctx, u_in, l['up'], in_act=L.ACT_RELU)
-            if l['upnorm'] is not None:
-                u = E.norm_act(ctx, y, l['upnorm'], L.ACT_NONE, out=second)
-            else:
-                u = E.norm_act(ctx, y, None, L.ACT_NONE, out=second)
+            drop = l['block'].use_dropout and l['block'].training      # nn.Dropout(0.5) on the block output (networks.py:604-605)
+            u = E.norm_act(ctx, y, l['upnorm'], L.ACT_NONE, out=None if drop else second)
+            if drop:
+                ud = E.dropout(ctx, u, 0.5)
+                ops_impl = E.ops.impl()
+                ops_impl.axpby(1.0, ud.t, 0.0, None, second)           # place the dropped tensor into the concat buffer
+                placed = E.Act(second, ud.C, ud.needs_grad)
+                if ctx.tape is not None and ud.needs_grad:
+                    def _route(ud=ud, placed=placed):
+                        g = placed.grad
+                        placed.grad = None
+                        if g is not None:
+                            ud.add_grad(g)
+                    ctx.tape.record(_route)
+                u = placed
             u_in = _JoinedAct(cat, 2 * cout, firsts[d], u, ctx)
         return E.conv(ctx, u_in, lv[0]['up'], act=L.ACT_TANH, in_act=L.ACT_RELU)
 

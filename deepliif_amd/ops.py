@@ -184,6 +184,12 @@ class HipBackend:
         L.check(self.lib.dl_act_backward(act, dl_dtype(y), _ptr(dy), pstride(dy), _ptr(y), pstride(y), _ptr(dx), pstride(dx), npix,
                                          y.shape[3], _stream()), 'dl_act_backward')
 
+    def dropout(self, x, y, p, seed):
+        _need_cuda(x, y)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        L.check(self.lib.dl_dropout(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], float(p), int(seed) & (2 ** 64 - 1),
+                                    _stream()), 'dl_dropout')
+
     def axpby(self, alpha, a, beta, b, out):
         _need_cuda(a, b, out)
         npix = a.shape[0] * a.shape[1] * a.shape[2]

@@ -179,6 +179,9 @@ int dl_act_forward(int act, int dtype, const void *x, int x_pstride, void *y, in
 /* dx = dy * act'(.) evaluated from the activation OUTPUT y (relu/lrelu: sign, tanh: 1-y^2) */
 int dl_act_backward(int act, int dtype, const void *dy, int dy_pstride, const void *y, int y_pstride,
                     void *dx, int dx_pstride, int64_t npix, int Cp, void *stream);
+/* nn.Dropout(p) in training mode (networks.py:493-494, 604-605): y = x * keep / (1-p), keep = hash(seed, element) >= p.
+ * Calling it again with the same seed on the gradient reproduces the same mask (backward); y may alias x. */
+int dl_dropout(int dtype, const void *x, int x_pstride, void *y, int y_pstride, int64_t npix, int Cp, float p, uint64_t seed, void *stream);
 /* out = alpha*a + beta*b   (b may be NULL; out may alias a or b) */
 int dl_axpby(int dtype, float alpha, const void *a, int a_pstride, float beta, const void *b, int b_pstride,
              void *out, int out_pstride, int64_t npix, int Cp, void *stream);

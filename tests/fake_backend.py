@@ -177,6 +177,12 @@ class FakeBackend:
         self._count('act_bwd')
         dx.copy_((dy.float() * _act_grad_from_output(act, y.float())).to(dx.dtype))
 
+    def dropout(self, x, y, p, seed):
+        self._count('dropout')
+        g = torch.Generator().manual_seed(int(seed) % (2 ** 63))
+        keep = (torch.rand(x.shape, generator=g) >= p).float()
+        y.copy_((x.float() * keep / (1.0 - p)).to(y.dtype))
+
     def axpby(self, alpha, a, beta, b, out):
         self._count('axpby')
         v = alpha * a.float()

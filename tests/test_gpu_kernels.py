@@ -366,3 +366,35 @@ def test_narrow_cout_head_conv(precname, pm):
     if pm == L.PAD_ZERO:
         assert rel(res['real']['dw'], res['fake']['dw']) < (1e-4 if precname == 'fp32' else 2e-3)
         assert rel(res['real']['db'], res['fake']['db']) < 1e-3
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_dropout_mask_properties(precname):
+    """nn.Dropout(0.5) (networks.py:493-494, 604-605): the RNG stream cannot match torch's, so the test pins the properties the
+    training graph relies on: keep probability, 1/(1-p) scaling, same seed -> same mask (backward), different seed -> different."""
+    prec = Precision.get(precname)
+    real = hip()
+    if DRY:
+        pytest.skip('statistical test of the device hash RNG')
+    x = torch.ones(2, 64, 64, 64, dtype=prec.dtype, device=DEV)
+    y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    real.dropout(x, y1, 0.5, 1234)
+    real.dropout(x, y2, 0.5, 1234)
+    real.dropout(x, y3, 0.5, 1235)
+    sync()
+    y1f = y1.float()
+    assert set(torch.unique(y1f).tolist()) == {0.0, 2.0}
+    keep = float((y1f > 0).float().mean())
+    assert abs(keep - 0.5) < 0.01, keep
+    assert torch.equal(y1, y2)
+    assert float((y1f != y3.float()).float().mean()) > 0.4
+    # no visible structure along channels / pixels
+    per_c = (y1f > 0).float().mean(dim=(0, 1, 2))
+    assert float((per_c - 0.5).abs().max()) < 0.03
+    # p = 0.25 on a strided (channel-slice) view, in place
+    buf = torch.ones(2, 16, 16, 64, dtype=prec.dtype, device=DEV)
+    real.dropout(buf[..., 32:], buf[..., 32:], 0.25, 7)
+    sync()
+    assert torch.all(buf[..., :32] == 1)
+    k = float((buf[..., 32:].float() > 0).float().mean())
+    assert abs(k - 0.75) < 0.02 and abs(float(buf[..., 32:].float().max()) - 1 / 0.75) < 1e-2

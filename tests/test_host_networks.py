@@ -116,3 +116,36 @@ def test_seeded_init_matches_reference_rng_order():
         asums = np.array([v.double().abs().sum().item() for v in sd.values()])
         assert np.allclose(sums, z[f'{tag}/sums'], rtol=1e-9, atol=1e-9), tag
         assert np.allclose(asums, z[f'{tag}/abs_sums'], rtol=1e-9, atol=1e-9), tag
+
+
+def test_dropout_backward_reuses_the_forward_mask():
+    """E.dropout: the gradient is masked/scaled with exactly the mask of the forward pass."""
+    torch.manual_seed(3)
+    prec = E.Precision.get('fp32')
+    tape = E.Tape()
+    ctx = E.Ctx(prec, tape, training=True)
+    x = E.Act(torch.rand(1, 8, 8, 16) + 0.5, 16, True)
+    y = E.dropout(ctx, x, 0.5)
+    y.grad = torch.ones_like(y.t)
+    tape.backward()
+    mask = (y.t > 0).float()
+    assert 0.3 < float(mask.mean()) < 0.7
+    assert torch.allclose(y.t, x.t * mask * 2)
+    assert torch.allclose(x.grad, mask * 2)
+
+
+def test_networks_with_dropout_train_and_eval():
+    """use_dropout=True keeps the reference's Sequential indices (state_dict keys) and is the identity in eval mode."""
+    sd_ref_keys = list(O.random_state_dict('resnet_2blocks', 3, 3, 8, 'batch', 'zero').keys())
+    net = N.define_G(3, 3, 8, 'resnet_2blocks', 'batch', True, 'normal', 0.02, [], 'zero').set_precision('fp32')
+    keys = [k for k in net.state_dict().keys()]
+    # with dropout the second conv of a block moves from index 3 to 4 (networks.py:493-506)
+    assert 'model.10.conv_block.4.weight' in keys and 'model.10.conv_block.3.weight' not in keys
+    assert len(keys) == len(sd_ref_keys)
+    x = seeded_uniform((1, 3, 16, 16), 1)
+    net.eval()
+    a, b = net(x), net(x)
+    assert torch.equal(a, b)
+    net.train()
+    c, d = net(x), net(x)
+    assert not torch.equal(c, d)          # two different dropout draws
