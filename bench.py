@@ -57,10 +57,11 @@ class KernelTimer:
         if hit:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-        self._orig(packed, x, out, *args, **kwargs)
+        ret = self._orig(packed, x, out, *args, **kwargs)
         if hit:
             e.record()
             self.pairs.append((s, e))
+        return ret
 
     def mean_seconds(self):
         if not self.pairs:

@@ -48,7 +48,7 @@ class PackDesc(C.Structure):
 class NormDesc(C.Structure):
     _fields_ = [('N', i32), ('H', i32), ('W', i32), ('Cp', i32), ('C', i32),
                 ('y_pstride', i32), ('z_pstride', i32), ('r_pstride', i32),
-                ('dtype', i32), ('scope', i32), ('act', i32), ('eps', C.c_float), ('momentum', C.c_float)]
+                ('dtype', i32), ('scope', i32), ('act', i32), ('eps', C.c_float), ('momentum', C.c_float), ('ext_nchunks', i32)]
 
 
 _vp, _f, _i, _i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
@@ -57,7 +57,8 @@ _vp, _f, _i, _i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
 SIGNATURES = {
     'dl_version': (_i, []),
     'dl_last_error': (C.c_char_p, []),
-    'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),

@@ -28,6 +28,8 @@ struct ConvArgs {
     int phase_kbase[DL_MAX_PHASES];
     int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
     int tiles_m, tiles_n, Mtot;
+    float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
+    int stats_nchunks;
     int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
 };
 
@@ -317,7 +319,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
-template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false>
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false, int ABL = 0>
 __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN;                        // waves per workgroup (4 or 8)
     constexpr int CPR = BK / 8;                        // 16-byte chunks per LDS row
@@ -446,6 +448,34 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
         }
     };
 
+    // one DMA instruction of tile kt (UTAP only): pieces 0..X_INS-1 = activation slabs, X_INS.. = weight slabs.  Lets the
+    // main loop spread the 8 issues between MFMA groups instead of paying their issue latency up front.
+    ptrdiff_t piece_delta = 0;
+    int piece_tl = 0;
+    auto piece_prepare = [&](int kt) {
+        const int kb = kt * BK;
+        piece_tl = kb >> a.log2Ci;
+        piece_delta = (ptrdiff_t)tapd_next + (kb & (a.Ci - 1));
+        tapd_next = tapd_lds[tap0 + min((kb + BK) >> a.log2Ci, ntaps - 1)];
+    };
+    auto issue_piece = [&](int kt, int buf, int idx) {
+        bf16_t *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < X_INS; ++i)
+            if (idx == i) {
+                const bool ok = (x_mask[i] >> piece_tl) & 1ull;
+                const bf16_t *src = ok ? x_ptr[i] + piece_delta : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(base + (wave * X_INS + i) * RPI * BK), 16, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < W_INS; ++i)
+            if (idx == X_INS + i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[i] + (size_t)(kt - kt_begin) * BK),
+                                                 (__attribute__((address_space(3))) void *)(base + XT + (wave * W_INS + i) * RPI * BK), 16, 0, 0);
+            }
+    };
+
     f32x4_t acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -502,23 +532,51 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
             __syncthreads();
         }
         if (late && kt_begin < kt_end) mma(wf, xf);
+    } else if constexpr (ABL == 3 && UTAP && NW == 8 && BK == 64 && X_INS + W_INS == 2 * FN) {
+        // interleaved issue: after each group of FM MFMAs (one weight fragment row) one DMA instruction of the next tile
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) piece_prepare(kt + 1);
+            const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t wf[FN], xf[FM];
+                read_frags(Xs, Ws, kk, wf, xf);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    if (more) issue_piece(kt + 1, cur ^ 1, kk * FN + i);
+                }
+            }
+            __syncthreads();
+        }
     } else {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);
+            if (ABL != 1 && kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);      // ABL: profiling ablations (tools/ablate.sh)
             const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
+            if (ABL != 2) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk) {
-                bf16x8_t wf[FN], xf[FM];
-                read_frags(Xs, Ws, kk, wf, xf);
-                mma(wf, xf);
+                for (int kk = 0; kk < BK / 32; ++kk) {
+                    bf16x8_t wf[FN], xf[FM];
+                    read_frags(Xs, Ws, kk, wf, xf);
+                    mma(wf, xf);
+                }
             }
             __syncthreads();
         }
     }
 
-    // ---- epilogue (identical to the register-staged kernel)
+    // ---- epilogue (as the register-staged kernel) + optional fused per-channel statistics of the stored values
     const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+    const bool want_stats = a.stats_part != nullptr;
+    float st1[FN][4], st2[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[i][r] = st2[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = tm * BM + wm * PM + j * 16 + fr;
@@ -548,18 +606,61 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
                 p[0] = pack2_bf16(v[0], v[1]);
                 p[1] = pack2_bf16(v[2], v[3]);
                 *reinterpret_cast<u32x2_t *>(dst) = p;
+                if (want_stats) {      // statistics of exactly what was stored (bf16-rounded), like the stand-alone kernel sees
+                    const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
+                    const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                    st1[i][0] += q0; st2[i][0] += q0 * q0; st1[i][1] += q1; st2[i][1] += q1 * q1;
+                    st1[i][2] += q2; st2[i][2] += q2 * q2; st1[i][3] += q3; st2[i][3] += q3 * q3;
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // lanes fr = 0..15 of one fg hold different pixels of the same 4 channels: butterfly over lane bits 0..3
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { st1[i][r] += __shfl_xor(st1[i][r], o, 64); st2[i][r] += __shfl_xor(st2[i][r], o, 64); }
+            }
+        float *red = reinterpret_cast<float *>(smem_raw);          // [WM][2][BN]; the tile buffers are dead after the K loop
+        if (fr == 0) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = wn * PN + i * 16 + fg * 4 + r;
+                    red[(wm * 2 + 0) * BN + c] = st1[i][r];
+                    red[(wm * 2 + 1) * BN + c] = st2[i][r];
+                }
+        }
+        __syncthreads();
+        // every pixel of this tile lies in ONE image (host guarantees HWq % BM == 0): chunk = (tile in image, phase)
+        const int m0 = tm * BM;
+        const int n = m0 / HWq;
+        const int chunk = ((m0 - n * HWq) / BM) * a.n_phase + phase;
+        for (int c = tid; c < BN; c += NW * 64) {
+            const int co = tn * BN + c;
+            if (co < a.Co) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
+                float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + co;
+                o[0] = s1;
+                o[a.Co] = s2;
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false>
+template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false, int ABL = 0>
 static int launch_conv_glds_impl(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + BM - 1) / BM;
     a.tiles_n = (a.Co + BN - 1) / BN;
     constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * (sizeof(int16_t) + sizeof(int));
-    auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP, STAG>;
+    auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP, STAG, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -588,6 +689,10 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (!no_big && a.Co >= 256 && (a.Co % 256) == 0 && (size_t)((a.Mtot + 255) / 256) * (a.Co / 256) * a.n_phase * a.splitk >= 256)
     {
         static const bool stag = getenv("DL_CONV_STAGGER") != nullptr;
+        static const char *abl = getenv("DL_CONV_ABLATE");       // "1": no DMA in the loop, "2": no LDS reads / MFMAs (timing only!)
+        if (abl && abl[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 1>(a, stream);
+        if (abl && abl[0] == '2' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 2>(a, stream);
+        if (abl && abl[0] == '3' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 3>(a, stream);
         if (stag && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, true>(a, stream);
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
@@ -646,8 +751,28 @@ static int dispatch_tile(const ConvArgs &a, hipStream_t stream) {
     return launch_conv<TIn, TOut, PREC, 128, 128, BK, 2, 2>(a, stream);
 }
 
+// tile height (pixels) the dispatch picks for the bf16 direct-to-LDS path; 0 when that path is not taken
+static int glds_tile_bm(const dl_conv_desc *d) {
+    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    if (no_glds || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE) return 0;
+    if (d->Co <= 16) return 256;
+    if (d->Co <= 64) return 128;
+    static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
+    const int mtot = d->N * d->Hq * d->Wq;
+    if (!no_big && d->Co >= 256 && (d->Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (d->Co / 256) * d->n_phase * d->splitk >= 256) return 256;
+    return 128;
+}
+
+extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
+    if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
+    const int bm = glds_tile_bm(d);
+    const int hw = d->Hq * d->Wq;
+    if (bm == 0 || hw % bm) return 0;
+    return (hw / bm) * d->n_phase;
+}
+
 extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
-                               void *out, float *slab, void *stream_) {
+                               void *out, float *slab, float *stats_part, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !in || !w_hi || (!out && !d->raw_out)) DL_FAIL("dl_conv_forward: null argument");
     const int l2 = ilog2_exact(d->Ci);
@@ -678,6 +803,13 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
     a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
     a.Mtot = d->N * d->Hq * d->Wq;
+    a.stats_part = nullptr;
+    a.stats_nchunks = 0;
+    if (stats_part) {
+        a.stats_nchunks = dl_conv_stats_chunks(d);
+        if (a.stats_nchunks == 0) DL_FAIL("dl_conv_forward: fused statistics are not available for this descriptor (ask dl_conv_stats_chunks first)");
+        a.stats_part = stats_part;
+    }
 
     int rc;
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths

@@ -21,8 +21,16 @@ static NormGeom make_geom(const dl_norm_desc *d) {
     return g;
 }
 
+// forward with externally produced partials (dl_conv_forward's fused statistics): only the chunk count changes
+static NormGeom make_geom_fwd(const dl_norm_desc *d) {
+    NormGeom g = make_geom(d);
+    if (d->ext_nchunks > 0) { g.nchunks = d->ext_nchunks; g.ppc = 0; }
+    return g;
+}
+
 extern "C" size_t dl_norm_ws_floats(const dl_norm_desc *d) {
     NormGeom g = make_geom(d);
+    if (d->ext_nchunks > g.nchunks) g.nchunks = d->ext_nchunks;
     return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)4 * g.N * g.Cp + (size_t)2048 * g.Cp + 64;    // partials | chunk sums | c1 | c2 | dy channel-sum partials
 }
 
@@ -333,9 +341,11 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_forward")) return -1;
     if (!y || !z || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_forward: null argument");
-    const NormGeom g = make_geom(d);
+    const NormGeom g = make_geom_fwd(d);
     const int pblocks = g.N * g.nchunks;
-    if (d->dtype == DL_F32)
+    if (d->ext_nchunks > 0) {
+        // partial sums were produced by the convolution that wrote y
+    } else if (d->dtype == DL_F32)
         hipLaunchKernelGGL((norm_partial_kernel<float, 0>), dim3(pblocks), dim3(256), 0, stream, (const float *)y, d->y_pstride,
                            (const float *)nullptr, 0, g, 0, nullptr, nullptr, nullptr, nullptr, ws);
     else

@@ -37,7 +37,7 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -46,6 +46,7 @@ class Act:
         self.needs_grad = needs_grad
         self.bias_grad: Optional[torch.Tensor] = None     # conv output: where the producer's bias gradient accumulates
         self.bias_done = False                            # set when a consumer's backward already added sum(dy) to it
+        self.stats = None                                 # conv output: (chunks, workspace token) of fused norm statistics
 
     @property
     def shape(self):
@@ -161,8 +162,10 @@ class Ctx:
         self.per_sample_norm = per_sample_norm
 
 
-def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None) -> Act:
-    """y = act(conv(in_act(x)) + bias).  `out` may be a channel-slice view of a concat buffer."""
+def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
+         stats: bool = False) -> Act:
+    """y = act(conv(in_act(x)) + bias).  `out` may be a channel-slice view of a concat buffer.
+    stats: the caller feeds y straight into norm_act -- let the conv epilogue produce the norm statistics when it can."""
     be = ops.impl()
     spec = layer.spec
     n, hi, wi, _ = x.t.shape
@@ -181,9 +184,13 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
         be.conv_forward(layer.packed_fwd, x.t, T, ho, wo, None, L.ACT_NONE, in_act, ctx.prec.prec, raw_out=True)
         be.shift_sum(T, spec.cout, spec.k, spec.pad, spec.pad_mode, layer.bias.detach() if layer.bias is not None else None, act, out)
         del T
+        nch = 0
     else:
-        be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act, ctx.prec.prec)
+        nch = be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act,
+                              ctx.prec.prec, want_stats=stats and act == L.ACT_NONE)
     y = Act(out, spec.cout, x_needs or w_needs)
+    if nch:
+        y.stats = (nch, be.norm_ws_token())
     if not (x_needs or w_needs):
         return y
     if w_needs and act == L.ACT_NONE and layer.bias is not None and layer.bias.requires_grad:
@@ -264,7 +271,9 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
     if m is not None and ctx.training and m.training and m.track_running_stats and m.running_mean is not None and scope == L.NORM_BATCH:
         rm, rv, momentum = m.running_mean, m.running_var, (m.momentum if m.momentum is not None else 0.1)
         m.num_batches_tracked += 1
-    stats = be.norm_forward(y.t, out, norm.C, scope, act, gamma, beta, rm, rv, momentum, residual.t if residual is not None else None)
+    ext = y.stats[0] if (y.stats is not None and y.stats[1] == be.norm_ws_token()) else 0
+    stats = be.norm_forward(y.t, out, norm.C, scope, act, gamma, beta, rm, rv, momentum, residual.t if residual is not None else None,
+                            ext_nchunks=ext)
     z = Act(out, y.C, needs)
     if not needs:
         return z

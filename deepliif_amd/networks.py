@@ -186,17 +186,17 @@ class ResnetGenerator(EngineNet):
     def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
         b = self._layers()
         c, n = b['stem']
-        h = E.norm_act(ctx, E.conv(ctx, x, c), n, L.ACT_RELU)
+        h = E.norm_act(ctx, E.conv(ctx, x, c, stats=n is not None), n, L.ACT_RELU)
         for c, n in b['down']:
-            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU)
         for ent, blk in b['blocks']:
             (c1, n1), (c2, n2) = ent
-            r = E.norm_act(ctx, E.conv(ctx, h, c1), n1, L.ACT_RELU)
+            r = E.norm_act(ctx, E.conv(ctx, h, c1, stats=n1 is not None), n1, L.ACT_RELU)
             if blk.use_dropout and blk.training:       # nn.Dropout(0.5) after the first norm+ReLU (networks.py:493-494)
                 r = E.dropout(ctx, r, 0.5)
-            h = E.norm_act(ctx, E.conv(ctx, r, c2), n2, L.ACT_NONE, residual=h)
+            h = E.norm_act(ctx, E.conv(ctx, r, c2, stats=n2 is not None), n2, L.ACT_NONE, residual=h)
         for c, n in b['up']:
-            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_RELU)
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU)
         return E.conv(ctx, h, b['head'], act=L.ACT_TANH)
 
 
@@ -295,7 +295,7 @@ class UnetGenerator(EngineNet):
                 buf = torch.empty((n, ho, wo, 2 * cin), dtype=dt, device=dev)
                 first = buf[..., :cin]
                 if l['has_downnorm'] and l['downnorm'] is not None:
-                    y = E.conv(ctx, h, l['down'], in_act=cin_act)
+                    y = E.conv(ctx, h, l['down'], in_act=cin_act, stats=True)
                     hn = E.norm_act(ctx, y, l['downnorm'], L.ACT_NONE, out=first)
                 else:
                     hn = E.conv(ctx, h, l['down'], in_act=cin_act, out=first)
@@ -310,7 +310,7 @@ class UnetGenerator(EngineNet):
             cat = cats[d]
             cout = l['up'].spec.cout
             second = cat[..., cout:]
-            y = E.conv(ctx, u_in, l['up'], in_act=L.ACT_RELU)
+            y = E.conv(ctx, u_in, l['up'], in_act=L.ACT_RELU, stats=True)
             drop = l['block'].use_dropout and l['block'].training      # nn.Dropout(0.5) on the block output (networks.py:604-605)
             u = E.norm_act(ctx, y, l['upnorm'], L.ACT_NONE, out=None if drop else second)
             if drop:
@@ -385,7 +385,7 @@ class NLayerDiscriminator(EngineNet):
         b = self._layers()
         h = E.conv(ctx, x, b['first'], act=L.ACT_LRELU)
         for c, n in b['mid']:
-            h = E.norm_act(ctx, E.conv(ctx, h, c), n, L.ACT_LRELU)
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_LRELU)
         return E.conv(ctx, h, b['last'])
 
     def forward(self, x):

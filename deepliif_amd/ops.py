@@ -82,6 +82,10 @@ class HipBackend:
 
     def __init__(self):
         self.lib = L.load()
+        self._norm_ws_token = 0          # bumped whenever the shared 'norm_ws' workspace is overwritten
+
+    def norm_ws_token(self) -> int:
+        return self._norm_ws_token
 
     # ---- weights
     def pack_weights(self, packed: PackedWeights, src: torch.Tensor):
@@ -93,8 +97,11 @@ class HipBackend:
 
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
-                     act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False):
-        """raw_out: `out` is an fp32 [N,Ho,Wo,Co] tensor that receives the raw accumulators (narrow-Cout path)"""
+                     act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False, want_stats: bool = False):
+        """raw_out: `out` is an fp32 [N,Ho,Wo,Co] tensor that receives the raw accumulators (narrow-Cout path).
+        want_stats: ask the kernel to also leave the per-(image, channel) partial sums of `out` at the start of the shared
+        normalisation workspace; returns the chunk count to hand to norm_forward(ext_nchunks=...) -- 0 when the dispatch for
+        this layer cannot produce them (the caller then runs the stand-alone statistics pass)."""
         _need_cuda(x, out, bias)
         if raw_out:
             plan = packed.plan
@@ -102,9 +109,9 @@ class HipBackend:
             _, ho, wo, cop = out.shape
             assert out.dtype == torch.float32 and out.is_contiguous()
             d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, cop, hq, wq, dl_dtype(x), prec, L.ACT_NONE, in_act, 0, 1, 1)
-            L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), None, None, _ptr(out), _stream()),
+            L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), None, None, _ptr(out), None, _stream()),
                     'dl_conv_forward(raw)')
-            return
+            return 0
         plan = packed.plan
         n, hi, wi, cp = x.shape
         assert cp == plan.cc_pad, (cp, plan.cc_pad)
@@ -115,8 +122,17 @@ class HipBackend:
                            0 if bias is None else bias.numel(), splitk)
         assert dl_dtype(out) == d.in_dtype
         slab = WS.get('conv_slab', splitk * n * ho * wo * cop, x.device) if splitk > 1 else None
+        nch, part = 0, None
+        if want_stats:
+            nch = int(self.lib.dl_conv_stats_chunks(C.byref(d)))
+            if nch > 0:
+                nd = self._norm_desc(out, cop, L.NORM_BATCH, L.ACT_NONE, -1.0, 8, 8)     # only N/H/W/Cp matter for the size
+                nd.ext_nchunks = nch
+                part = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(nd)), x.device)
+                self._norm_ws_token += 1
         L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
-                                         _stream()), 'dl_conv_forward')
+                                         _ptr(part), _stream()), 'dl_conv_forward')
+        return nch
 
     # ---- weight gradient
     def conv_wgrad(self, P: torch.Tensor, Q: torch.Tensor, grad: torch.Tensor, k: int, step: int, pad: int, pad_mode: int,
@@ -155,9 +171,13 @@ class HipBackend:
         d.eps, d.momentum = 1e-5, momentum
         return d
 
-    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual):
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0):
+        """ext_nchunks > 0: the convolution that produced y already left its partial sums in the 'norm_ws' workspace"""
         _need_cuda(y, z, gamma, beta, residual)
         d = self._norm_desc(y, C_real, scope, act, momentum, pstride(z), pstride(residual) if residual is not None else 8)
+        d.ext_nchunks = ext_nchunks
+        if not ext_nchunks:
+            self._norm_ws_token += 1            # the stand-alone statistics pass overwrites the shared workspace
         stats = torch.empty(4, y.shape[0], y.shape[3], dtype=torch.float32, device=y.device)   # mean, rstd, scale, shift
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
@@ -168,6 +188,7 @@ class HipBackend:
     def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
         _need_cuda(dz, y, dy, dy_chansum)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
+        self._norm_ws_token += 1
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
                                           _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _stream()), 'dl_norm_backward')

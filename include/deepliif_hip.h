@@ -79,7 +79,12 @@ typedef struct dl_conv_desc {
 } dl_conv_desc;
 
 int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
-                    void *out, float *slab, void *stream);
+                    void *out, float *slab, float *stats_part, void *stream);
+/* Fused normalisation statistics: when > 0, dl_conv_forward can also emit the per-(image, channel) partial sums / sums of
+ * squares of the values it stores (stats_part = fp32 [N][chunks][2][Co], chunks = the returned value) so that dl_norm_forward
+ * (dl_norm_desc.ext_nchunks = chunks, partials at the start of its `ws`) skips its own statistics pass over y.  0 = not
+ * available for this descriptor (pass stats_part = NULL). */
+int dl_conv_stats_chunks(const dl_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight gradient:  grad[a, b, kh, kw] (+)= sum_{n,hp,wp} P[n,hp,wp,a] * Q[n, hp*step - pad + kh, wp*step - pad + kw, b]
@@ -154,6 +159,7 @@ typedef struct dl_norm_desc {
     int32_t act;
     float eps;
     float momentum;                  /* <0: do not touch running stats                    */
+    int32_t ext_nchunks;             /* >0: `ws` already starts with [N][ext_nchunks][2][Cp] partial sums (dl_conv_forward) */
 } dl_norm_desc;
 
 size_t dl_norm_ws_floats(const dl_norm_desc *d);     /* scratch needed by forward and backward (floats) */

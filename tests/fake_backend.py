@@ -70,7 +70,10 @@ class FakeBackend:
                 W[:plan.rows_real, k0:k0 + plan.cc_real] = blk if plan.row_is_a else blk.t()
         packed.fake_w = W
 
-    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False):
+    def norm_ws_token(self):
+        return 0
+
+    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False, want_stats=False):
         self._count('conv')
         plan = packed.plan
         xv = _act(in_act, x.float())
@@ -112,7 +115,8 @@ class FakeBackend:
         else:
             grad.copy_(g)
 
-    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual):
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0):
+        assert ext_nchunks == 0
         self._count('norm_fwd')
         yv = y.float()
         dims = (0, 1, 2) if scope == L.NORM_BATCH else (1, 2)

@@ -254,6 +254,59 @@ def test_norm_forward_backward(shape, C, scope, precname):
             assert rel(dg_r, dg_f) < 1e-3 and rel(db_r, db_f) < 1e-3
 
 
+STATS_CASES = [
+    # kind, cin, cout, k, s, p, N, H, W      (bf16 direct-to-LDS dispatch: 256x16 / 128x64 / 128x128 / 256x256 tiles, 4-phase convT)
+    ('conv', 3, 64, 7, 1, 3, 2, 32, 32),
+    ('conv', 64, 128, 3, 2, 1, 2, 32, 32),
+    ('conv', 256, 256, 3, 1, 1, 2, 32, 32),
+    ('conv', 256, 256, 3, 1, 1, 8, 128, 128),
+    ('convT', 256, 128, 3, 2, 1, 2, 16, 16),
+    ('conv', 6, 64, 4, 2, 1, 2, 64, 64),
+    ('conv', 64, 8, 3, 1, 1, 1, 32, 32),
+]
+
+
+@pytest.mark.parametrize('scope', [L.NORM_INSTANCE, L.NORM_BATCH])
+@pytest.mark.parametrize('case', STATS_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}n{c[6]}')
+def test_conv_fused_norm_statistics(case, scope):
+    """dl_conv_forward(stats_part) + dl_norm_forward(ext_nchunks) must give the statistics / output of the stand-alone pass over
+    the same stored y (the sums are taken over the bf16-rounded values in both)."""
+    kind, cin, cout, k, s, p, N, H, W_ = case
+    prec = Precision.get('bf16')
+    spec = ConvSpec(kind, cin, cout, k, s, p, L.PAD_ZERO, 1 if kind == 'convT' else 0)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd(wshape, 1, prec, 0.05).to(DEV)
+    bias = rnd((cout,), 2, Precision.get('fp32'), 0.1).to(DEV)
+    x = torch.zeros(N, H, W_, cpad(cin))
+    x[..., :cin] = rnd((N, H, W_, cin), 3, prec)
+    x = x.to(prec.dtype).to(DEV)
+    be = hip()
+    plan = spec.forward_plan()
+    packed = ops.PackedWeights(plan, DEV, False)
+    be.pack_weights(packed, w)
+    ho, wo = spec.out_hw(H, W_)
+    hq, wq = (ho, wo) if kind == 'conv' else (H, W_)
+    y = torch.empty((N, ho, wo, cpad(cout)), dtype=prec.dtype, device=DEV)
+    nch = be.conv_forward(packed, x, y, hq, wq, bias, L.ACT_NONE, L.ACT_NONE, prec.prec, splitk=1, want_stats=True)
+    assert nch > 0, 'this case is expected to take the fused-statistics path'
+    affine = scope == L.NORM_BATCH
+    g = (1 + 0.1 * torch.randn(cout, generator=torch.Generator().manual_seed(4))).to(DEV) if affine else None
+    b = (0.1 * torch.randn(cout, generator=torch.Generator().manual_seed(5))).to(DEV) if affine else None
+    z1 = torch.empty_like(y)
+    st1 = be.norm_forward(y, z1, cout, scope, L.ACT_RELU, g, b, None, None, -1.0, None, ext_nchunks=nch)
+    y2 = torch.empty_like(y)
+    assert be.conv_forward(packed, x, y2, hq, wq, bias, L.ACT_NONE, L.ACT_NONE, prec.prec, splitk=1) == 0
+    z2 = torch.empty_like(y)
+    st2 = be.norm_forward(y2, z2, cout, scope, L.ACT_RELU, g, b, None, None, -1.0, None)
+    sync()
+    assert torch.equal(y, y2)
+    assert rel(st1[0][:, :cout], st2[0][:, :cout]) < 1e-5 and rel(st1[1][:, :cout], st2[1][:, :cout]) < 1e-5
+    # same scale/shift up to fp32 summation order -> identical up to rare one-ulp bf16 rounding flips
+    assert rel(z1, z2) <= 2.0 ** -7
+    assert float((z1 != z2).float().mean()) < 1e-3
+    assert float(z1[..., cout:].float().abs().max()) == 0.0 if cpad(cout) > cout else True
+
+
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])
 def test_elementwise_family(precname):
     prec = Precision.get(precname)
