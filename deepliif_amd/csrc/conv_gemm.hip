@@ -28,6 +28,7 @@ struct ConvArgs {
     int phase_kbase[DL_MAX_PHASES];
     int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
     int tiles_m, tiles_n, Mtot;
+    int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
     float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
     int stats_nchunks;
     int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
@@ -394,19 +395,25 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
         const int row = (wave * W_INS + i) * RPI + lrow;
         const int c = swz_chunk<CPR>(row, lcp);
         // rows beyond the tile (narrow-N configs) re-read row 0: their LDS slots are never consumed
-        w_ptr[i] = a.w_hi + (size_t)(tn * BN + (row < BN ? row : 0)) * a.w_kstride + kbase + c * 8 + (size_t)kt_begin * BK;
+        w_ptr[i] = a.w_hi + (size_t)(tn * BN + (row < BN ? row : 0)) * a.w_kstride + kbase + c * 8;
     }
 
-    int tapd_next = 0;                   // pixel offset of the tap of the NEXT tile to issue (read from LDS one step ahead)
+    // UTAP K-step sequencer (wave-uniform): the step being issued covers channels [is_ch, is_ch + BK) of tap is_tl.
+    //   k_order 0: tap-major (all channel chunks of a tap, then the next tap) -- the packed K order
+    //   k_order 1: channel-chunk-major (all taps of a 64-channel chunk back to back): the taps re-read the SAME halo slab
+    //              chunk from L2 within a few steps instead of after a full pass over Ci, which is what keeps the slab L2-resident
+    int is_tl = 0, is_ch = 0;
+    int tapd_next = 0;                   // pixel offset of tap is_tl (read from LDS one step ahead of its use)
     auto issue_tile = [&](int kt, int buf) {
         bf16_t *base = smem + buf * BUF;
+        size_t wk;
         if constexpr (UTAP) {
-            // every chunk of this K step belongs to ONE tap (Ci >= BK): the tap and the channel base are wave-uniform
-            const int kb = kt * BK;
-            const int tl = kb >> a.log2Ci;
-            const ptrdiff_t delta = (ptrdiff_t)tapd_next + (kb & (a.Ci - 1));
-            const int tl2 = min((kb + BK) >> a.log2Ci, ntaps - 1);
-            tapd_next = tapd_lds[tap0 + tl2];    // consumed by the next call: its LDS latency hides behind this step's MFMAs
+            const int tl = is_tl;
+            const ptrdiff_t delta = (ptrdiff_t)tapd_next + is_ch;
+            wk = (size_t)tl * a.Ci + is_ch;
+            if (a.k_order) { if (++is_tl == ntaps) { is_tl = 0; is_ch += BK; } }
+            else { is_ch += BK; if (is_ch == a.Ci) { is_ch = 0; ++is_tl; } }
+            tapd_next = tapd_lds[tap0 + min(is_tl, ntaps - 1)];    // for the next call: latency hides behind this step's MFMAs
 #pragma unroll
             for (int i = 0; i < X_INS; ++i) {
                 const int row0 = (wave * X_INS + i) * RPI;
@@ -418,6 +425,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
                 }
             }
         } else {
+            wk = (size_t)kt * BK;
 #pragma unroll
             for (int i = 0; i < X_INS; ++i) {
                 const int row0 = (wave * X_INS + i) * RPI;
@@ -442,38 +450,10 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
         for (int i = 0; i < W_INS; ++i) {
             const int row0 = (wave * W_INS + i) * RPI;
             if (row0 < BN) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[i] + (size_t)(kt - kt_begin) * BK),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[i] + wk),
                                                  (__attribute__((address_space(3))) void *)(base + XT + row0 * BK), 16, 0, 0);
             }
         }
-    };
-
-    // one DMA instruction of tile kt (UTAP only): pieces 0..X_INS-1 = activation slabs, X_INS.. = weight slabs.  Lets the
-    // main loop spread the 8 issues between MFMA groups instead of paying their issue latency up front.
-    ptrdiff_t piece_delta = 0;
-    int piece_tl = 0;
-    auto piece_prepare = [&](int kt) {
-        const int kb = kt * BK;
-        piece_tl = kb >> a.log2Ci;
-        piece_delta = (ptrdiff_t)tapd_next + (kb & (a.Ci - 1));
-        tapd_next = tapd_lds[tap0 + min((kb + BK) >> a.log2Ci, ntaps - 1)];
-    };
-    auto issue_piece = [&](int kt, int buf, int idx) {
-        bf16_t *base = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < X_INS; ++i)
-            if (idx == i) {
-                const bool ok = (x_mask[i] >> piece_tl) & 1ull;
-                const bf16_t *src = ok ? x_ptr[i] + piece_delta : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(base + (wave * X_INS + i) * RPI * BK), 16, 0, 0);
-            }
-#pragma unroll
-        for (int i = 0; i < W_INS; ++i)
-            if (idx == X_INS + i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[i] + (size_t)(kt - kt_begin) * BK),
-                                                 (__attribute__((address_space(3))) void *)(base + XT + (wave * W_INS + i) * RPI * BK), 16, 0, 0);
-            }
     };
 
     f32x4_t acc[FN][FM];
@@ -483,7 +463,11 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();     // tap tables visible
-    if constexpr (UTAP) tapd_next = tapd_lds[tap0 + min((kt_begin * BK) >> a.log2Ci, ntaps - 1)];
+    if constexpr (UTAP) {
+        if (a.k_order) { is_tl = kt_begin % ntaps; is_ch = (kt_begin / ntaps) * BK; }
+        else { is_tl = (kt_begin * BK) >> a.log2Ci; is_ch = (kt_begin * BK) & (a.Ci - 1); }
+        tapd_next = tapd_lds[tap0 + min(is_tl, ntaps - 1)];
+    }
     if (kt_begin < kt_end) issue_tile(kt_begin, 0);
     __syncthreads();     // drains the DMA (vmcnt(0)) + barrier
 
@@ -532,26 +516,6 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
             __syncthreads();
         }
         if (late && kt_begin < kt_end) mma(wf, xf);
-    } else if constexpr (ABL == 3 && UTAP && NW == 8 && BK == 64 && X_INS + W_INS == 2 * FN) {
-        // interleaved issue: after each group of FM MFMAs (one weight fragment row) one DMA instruction of the next tile
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int cur = (kt - kt_begin) & 1;
-            const bool more = kt + 1 < kt_end;
-            if (more) piece_prepare(kt + 1);
-            const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t wf[FN], xf[FM];
-                read_frags(Xs, Ws, kk, wf, xf);
-#pragma unroll
-                for (int i = 0; i < FN; ++i) {
-#pragma unroll
-                    for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    if (more) issue_piece(kt + 1, cur ^ 1, kk * FN + i);
-                }
-            }
-            __syncthreads();
-        }
     } else {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
@@ -692,7 +656,6 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
         static const char *abl = getenv("DL_CONV_ABLATE");       // "1": no DMA in the loop, "2": no LDS reads / MFMAs (timing only!)
         if (abl && abl[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 1>(a, stream);
         if (abl && abl[0] == '2' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 2>(a, stream);
-        if (abl && abl[0] == '3' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 3>(a, stream);
         if (stag && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, true>(a, stream);
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
@@ -803,6 +766,11 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
     a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
     a.Mtot = d->N * d->Hq * d->Wq;
+    // A/B switch: "1" = channel-chunk-major K steps.  Measured on MI355X (r01): 4-7% faster in an isolated loop over one layer
+    // (tools/ab_order.sh) but 3-12% SLOWER inside the training step (profiles/r01: 162.9 -> 168.7 us on the 256x256 tile),
+    // so tap-major stays the default.
+    static const char *korder_env = getenv("DL_CONV_KORDER");
+    a.k_order = (korder_env && korder_env[0] == '1') ? 1 : 0;
     a.stats_part = nullptr;
     a.stats_nchunks = 0;
     if (stats_part) {

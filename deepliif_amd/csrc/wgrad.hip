@@ -26,6 +26,7 @@ struct WgradArgs {
     int tiles_a, tiles_j;
     int dn, dh, dw;     // 32 pixels in mixed radix (Hp*Wp, Wp, 1)
     int p_act, q_act;
+    int xcd_group;      // 1: tiles of one pixel range share an XCD (see the kernels)
 };
 
 __device__ __forceinline__ int reflect_idx_w(int i, int n) {
@@ -103,9 +104,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave % WA, wj = wave / WA;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // All (tap, channel) tiles of ONE pixel range read the same P / Q pixels: keep them on one XCD (shared L2) by remapping the
+    // flattened workgroup id (hardware deals consecutive ids round-robin over the 8 XCDs); a.xcd_group = 0 keeps the 2-D order.
+    int bid, ks;
+    if (a.xcd_group) {
+        const int ntile = gridDim.x;
+        const int logical = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
+        ks = logical / ntile;
+        bid = logical - ks * ntile;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+        ks = blockIdx.y;
+    }
     const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
-    const int ks = blockIdx.y;
     const int p_begin = ks * a.pchunk;
     const int p_end = min(a.Ptot, p_begin + a.pchunk);
     const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
@@ -284,9 +295,19 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave % WA, wj = wave / WA;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // All (tap, channel) tiles of ONE pixel range read the same P / Q pixels: keep them on one XCD (shared L2) by remapping the
+    // flattened workgroup id (hardware deals consecutive ids round-robin over the 8 XCDs); a.xcd_group = 0 keeps the 2-D order.
+    int bid, ks;
+    if (a.xcd_group) {
+        const int ntile = gridDim.x;
+        const int logical = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
+        ks = logical / ntile;
+        bid = logical - ks * ntile;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+        ks = blockIdx.y;
+    }
     const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
-    const int ks = blockIdx.y;
     const int p_begin = ks * a.pchunk;
     const int p_end = min(a.Ptot, p_begin + a.pchunk);
     const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
@@ -496,6 +517,8 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     const int hw = d->Hp * d->Wp;
     a.dn = 32 / hw; a.dh = (32 % hw) / d->Wp; a.dw = (32 % hw) % d->Wp;
     a.p_act = d->p_act; a.q_act = d->q_act;
+    static const char *xg_env = getenv("DL_WGRAD_XCDGROUP");          // A/B switch: "0" keeps the plain 2-D block order
+    a.xcd_group = (xg_env && xg_env[0] == '0') ? 0 : 1;
 
     int rc;
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
