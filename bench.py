@@ -49,6 +49,7 @@ class KernelTimer:
 
     def __init__(self, backend, shape):
         self.backend, self.shape, self.pairs, self.enabled = backend, tuple(shape), [], False
+        self.kernel = '?'
         self._orig = backend.conv_forward
         backend.conv_forward = self._wrapped
 
@@ -61,6 +62,7 @@ class KernelTimer:
         if hit:
             e.record()
             self.pairs.append((s, e))
+            self.kernel = getattr(self.backend, 'last_conv_kernel', '') or self.kernel      # what the library dispatched
         return ret
 
     def mean_seconds(self):
@@ -212,13 +214,16 @@ def main():
     traffic = None
     try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc.sh)
         with open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_dominant_conv256.json')) as f:
-            traffic = json.load(f)['traffic_bytes'] if (n, s, args.precision) == (8, 512, 'bf16') else None
+            pmc = json.load(f)
+            # counters belong to ONE kernel at ONE shape: report them only when that is what this run dispatched
+            same = (n, s, args.precision) == (8, 512, 'bf16') and timer.kernel != '?' and timer.kernel.split('<')[0] in pmc.get('kernel', '')
+            traffic = pmc['traffic_bytes'] if same else None
     except Exception:
         traffic = None
     if kt:
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': traffic, 'kernel': 'conv_gemm_glds_kernel<256x256x64, 8 waves> 3x3 256->256 @ 8x128x128 (ResnetBlock conv fwd + dgrad)',
+                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv fwd + dgrad; timed by events around the host call',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
         'metric': '512x512 tiles/s train-step (5G+5D)' if args.workload == 'train' else '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)',

@@ -59,6 +59,7 @@ SIGNATURES = {
     'dl_last_error': (C.c_char_p, []),
     'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
+    'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),

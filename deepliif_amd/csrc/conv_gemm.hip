@@ -320,6 +320,102 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
+// Epilogue shared by the direct-to-LDS kernels: bias + activation + bf16 store (or raw fp32 slabs for split-K / raw_out) and the
+// optional fused per-(image, channel) statistics of the stored values.  `smem_raw` must be dead (all tile reads done, no DMA
+// in flight) when this is entered with statistics requested.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void glds_epilogue(const ConvArgs &a, f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], int tm, int tn, int phase, int ks,
+                                              int wm, int wn, int lane, int tid, char *smem_raw) {
+    constexpr int NW = WM * WN;
+    constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int HWq = a.Hq * a.Wq;
+    // ---- epilogue (as the register-staged kernel) + optional fused per-channel statistics of the stored values
+    const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+    const bool want_stats = a.stats_part != nullptr;
+    float st1[FN][4], st2[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[i][r] = st2[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = tm * BM + wm * PM + j * 16 + fr;
+        if (m >= a.Mtot) continue;
+        const int n = m / HWq, rem = m - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int co = tn * BN + wn * PN + i * 16 + fg * 4;
+            if (co >= a.Co) continue;
+            f32x4_t v = acc[i][j];
+            if (a.splitk > 1 || a.raw_out) {
+                float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
+                }
+                if (a.act != DL_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(a.act, v[r]);
+                }
+                bf16_t *dst = reinterpret_cast<bf16_t *>(a.out) + opix * a.out_pstride + co;
+                u32x2_t p;
+                p[0] = pack2_bf16(v[0], v[1]);
+                p[1] = pack2_bf16(v[2], v[3]);
+                *reinterpret_cast<u32x2_t *>(dst) = p;
+                if (want_stats) {      // statistics of exactly what was stored (bf16-rounded), like the stand-alone kernel sees
+                    const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
+                    const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                    st1[i][0] += q0; st2[i][0] += q0 * q0; st1[i][1] += q1; st2[i][1] += q1 * q1;
+                    st1[i][2] += q2; st2[i][2] += q2 * q2; st1[i][3] += q3; st2[i][3] += q3 * q3;
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // lanes fr = 0..15 of one fg hold different pixels of the same 4 channels: butterfly over lane bits 0..3
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { st1[i][r] += __shfl_xor(st1[i][r], o, 64); st2[i][r] += __shfl_xor(st2[i][r], o, 64); }
+            }
+        float *red = reinterpret_cast<float *>(smem_raw);          // [WM][2][BN]; the tile buffers are dead after the K loop
+        if (fr == 0) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = wn * PN + i * 16 + fg * 4 + r;
+                    red[(wm * 2 + 0) * BN + c] = st1[i][r];
+                    red[(wm * 2 + 1) * BN + c] = st2[i][r];
+                }
+        }
+        __syncthreads();
+        // every pixel of this tile lies in ONE image (host guarantees HWq % BM == 0): chunk = (tile in image, phase)
+        const int m0 = tm * BM;
+        const int n = m0 / HWq;
+        const int chunk = ((m0 - n * HWq) / BM) * a.n_phase + phase;
+        for (int c = tid; c < BN; c += NW * 64) {
+            const int co = tn * BN + c;
+            if (co < a.Co) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
+                float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + co;
+                o[0] = s1;
+                o[a.Co] = s2;
+            }
+        }
+    }
+}
+
+
 template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false, int ABL = 0>
 __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const ConvArgs a) {
     constexpr int NW = WM * WN;                        // waves per workgroup (4 or 8)
@@ -370,7 +466,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < X_INS; ++i) {
         const int row = (wave * X_INS + i) * RPI + lrow;
-        const int m = tm * BM + row;
+        const int m = (ABL == 5 ? (tm & 1) : tm) * BM + row;      // ABL 5: every block gathers the same two slabs (all L2 hits)
         x_ok[i] = (row < BM) && (m < a.Mtot);
         const int mm = x_ok[i] ? m : 0;
         const int n = mm / HWq, rem = mm - n * HWq;
@@ -521,7 +617,12 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
             const int cur = (kt - kt_begin) & 1;
             if (ABL != 1 && kt + 1 < kt_end) issue_tile(kt + 1, cur ^ 1);      // ABL: profiling ablations (tools/ablate.sh)
             const bf16_t *Xs = smem + cur * BUF, *Ws = Xs + XT;
-            if (ABL != 2) {
+            if constexpr (ABL == 4) {        // DMA only, TWO tiles in flight (nothing reads LDS, so the buffers may alias):
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // separates a latency bound from a throughput bound
+                __builtin_amdgcn_s_barrier();
+                continue;
+            }
+            if (ABL != 2 && ABL != 4 && ABL != 5) {
 #pragma unroll
                 for (int kk = 0; kk < BK / 32; ++kk) {
                     bf16x8_t wf[FN], xf[FM];
@@ -533,89 +634,655 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
         }
     }
 
-    // ---- epilogue (as the register-staged kernel) + optional fused per-channel statistics of the stored values
-    const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
-    const bool want_stats = a.stats_part != nullptr;
-    float st1[FN][4], st2[FN][4];
+    glds_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane, tid, smem_raw);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 8-phase kernel for the dominant layers (3x3 / 4x4 taps over >= 64 channels, Co a multiple of 256, zero padding, bf16).
+// Same tile as the 256x256x64 direct-to-LDS kernel above (8 waves = 2 x 4, each 128 pixels x 64 channels), different schedule:
+//   * a K step is split into FOUR phases, one 64-pixel x 32-channel accumulator quadrant x K=64 (16 MFMAs) each, with two raw
+//     s_barriers per phase; waves 4-7 run ONE barrier behind waves 0-3 (wave w and w+4 share a SIMD), so on every SIMD one
+//     wave is in its MFMA section while the other one issues its ds_reads / DMA: the LDS phase and the MFMA phase of the
+//     plain kernel (which run back to back because the barrier keeps all 8 waves in lock step) overlap instead.
+//   * the operands of a K step live in four 16 KB half-tile slots ordered by USE, not by position: WB_b = the b-th 32-channel
+//     half of every wave's 64 channels, XA_a = the a-th 64-pixel half of every wave's 128 pixels.  A slot is therefore dead
+//     as soon as its phase has read it and is refilled (global_load_lds) one or two phases later, three half-tiles ahead of
+//     their use:        phase q of step t   reads                stages (2 DMA instructions per wave)
+//                             0             WB_0(t), XA_0(t)      XA_1(t+1)
+//                             1             WB_1(t)               WB_0(t+2)
+//                             2             XA_1(t)               XA_0(t+2)
+//                             3             -                     WB_1(t+2)      + s_waitcnt vmcnt(6): step t+1 has landed
+//     vmcnt is never 0 in the steady state (the three newest half-tiles stay in flight across the barriers).
+//   Ordering rules the table obeys (MI355X guide, "256^2 8-phase template"): a staged slot is read at the earliest one phase
+//   after the counted vmcnt + barrier that retires it; a slot is restaged two phases after its last ds_read, or one phase
+//   after when those reads were retired (lgkmcnt) before the reading phase's first barrier (WB_0: the lgkmcnt(8) in phase 0).
+// ------------------------------------------------------------------------------------------------------------------
+#define DL_BAR() asm volatile("s_barrier" ::: "memory")
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int ABL>      // ABL != 0: timing-only ablations (tools/ablate.sh): 1 = no DMA in the loop, 2 = no ds_reads / MFMAs, 3 = MFMAs only
+__global__ void __launch_bounds__(512) conv_gemm_8ph_kernel(const ConvArgs a) {
+    constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4, CPR = 8;
+    constexpr int FM = 8, FN = 4;
+    constexpr int HALF = 128 * BK;                 // elements of one half-tile slot (16 KB)
+    constexpr int S_W = 0, S_X = 2;                // slot order inside a buffer: WB_0, WB_1, XA_0, XA_1
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+    int *tapd_lds = reinterpret_cast<int *>(smem + 8 * HALF);          // element offset (dh*Wi + dw)*pstride of every tap
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const bool grp1 = wave >= 4;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
+    const int phase = blockIdx.y / a.splitk, ks = blockIdx.y % a.splitk;
+    const int tap0 = a.phase_tap_begin[phase];
+    const int ntaps = a.phase_tap_begin[phase + 1] - tap0;
+    const int kbase = a.phase_kbase[phase];
+    const int nk_total = ntaps * a.Ci / BK;
+    const int nk_per = (nk_total + a.splitk - 1) / a.splitk;
+    const int kt_begin = ks * nk_per;
+    const int T = max(min(nk_total, kt_begin + nk_per) - kt_begin, 0);
+
+    if (tid < DL_MAX_TAPS) {
+        const int16_t tp = a.taps[tid];
+        tapd_lds[tid] = ((int)(int8_t)(tp & 0xff) * a.Wi + (int)(int8_t)((tp >> 8) & 0xff)) * a.in_pstride;
+    }
+
+    const bf16_t *in = reinterpret_cast<const bf16_t *>(a.in);
+    const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_zero_page);
+    const int HWq = a.Hq * a.Wq;
+    const int lrow = lane >> 3, lcp = lane & 7;    // row inside one DMA instruction's 8-row slab, 16-byte position in the row
+
+    // ---- staging geometry: instruction i of this wave fills slot rows s = (wave*2 + i)*8 + lrow of a half-tile
+    const bf16_t *x_ptr[2][2];
+    unsigned long long x_mask[2][2];               // bit t: tap (tap0 + t) of this pixel is inside the image
+    const bf16_t *w_ptr[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = (wave * 2 + i) * 8 + lrow;
+            const int c8 = swz_chunk<CPR>(s, lcp) * 8;
+            {   // XA_h: slot row s = pixel (s>>6)*128 + h*64 + (s&63) of the tile
+                const int m = tm * BM + (s >> 6) * 128 + h * 64 + (s & 63);
+                const bool ok = m < a.Mtot;
+                const int mm = ok ? m : 0;
+                const int n = mm / HWq, rem = mm - n * HWq;
+                const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+                const int hi0 = hq * a.in_step, wi0 = wq * a.in_step;
+                x_ptr[h][i] = in + ((size_t)(n * a.Hi + hi0) * a.Wi + wi0) * (size_t)a.in_pstride + c8;
+                unsigned long long mk = 0;
+                if (ok)
+                    for (int t = 0; t < ntaps; ++t) {
+                        const int16_t tp = a.taps[tap0 + t];
+                        const int hi = hi0 + (int)(int8_t)(tp & 0xff), wi = wi0 + (int)(int8_t)((tp >> 8) & 0xff);
+                        if (((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi)) mk |= 1ull << t;
+                    }
+                x_mask[h][i] = mk;
+            }
+            {   // WB_h: slot row s = channel (s>>5)*64 + h*32 + (s&31) of the tile
+                const int row = (s >> 5) * 64 + h * 32 + (s & 31);
+                w_ptr[h][i] = a.w_hi + (size_t)(tn * BN + row) * a.w_kstride + kbase + c8;
+            }
+        }
+
+    auto stage_x = [&](auto BUF, auto H, ptrdiff_t delta, int tl) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value, h = decltype(H)::value;
+        bf16_t *dst = smem + (buf * 4 + S_X + h) * HALF + wave * (16 * BK);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = (x_mask[h][i] >> tl) & 1ull;
+            const bf16_t *src = ok ? x_ptr[h][i] + delta : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + i * 8 * BK), 16, 0, 0);
+        }
+    };
+    auto stage_w = [&](auto BUF, auto H, size_t wk) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value, h = decltype(H)::value;
+        bf16_t *dst = smem + (buf * 4 + S_W + h) * HALF + wave * (16 * BK);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[h][i] + wk),
+                                             (__attribute__((address_space(3))) void *)(dst + i * 8 * BK), 16, 0, 0);
+    };
+
+    // K step u (counted from kt_begin) covers channels [ch, ch + BK) of tap tl: tap-major order, stateless (wave-uniform SALU)
+#define DL_STEP_TL(u) ((((kt_begin + (u)) * BK) >> a.log2Ci))
+#define DL_STEP_CH(u) ((((kt_begin + (u)) * BK) & (a.Ci - 1)))
+
+    f32x4_t acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st1[i][r] = st2[i][r] = 0.f;
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();     // tap table visible
+
+    // per-step scalars of the steps whose half-tiles are still to be staged: step t+1 (x only) and t+2
+    int tl1, tl2;
+    ptrdiff_t d1, d2;
+    size_t wk2;
+    {
+        const int tl0 = DL_STEP_TL(0), ch0 = DL_STEP_CH(0);
+        tl1 = DL_STEP_TL(1); const int ch1 = DL_STEP_CH(1);
+        tl2 = DL_STEP_TL(2); const int ch2 = DL_STEP_CH(2);
+        const ptrdiff_t d0 = (ptrdiff_t)tapd_lds[tap0 + min(tl0, ntaps - 1)] + ch0;
+        d1 = (ptrdiff_t)tapd_lds[tap0 + min(tl1, ntaps - 1)] + ch1;
+        d2 = (ptrdiff_t)tapd_lds[tap0 + min(tl2, ntaps - 1)] + ch2;
+        const size_t wk0 = (size_t)tl0 * a.Ci + ch0, wk1 = (size_t)tl1 * a.Ci + ch1;
+        wk2 = (size_t)tl2 * a.Ci + ch2;
+        // prologue: step 0 completely, step 1 without XA_1 (phase 0 of step 0 stages it)
+        if (T > 0) {
+            stage_w(IC<0>{}, IC<0>{}, wk0);
+            stage_x(IC<0>{}, IC<0>{}, d0, tl0);
+            stage_w(IC<0>{}, IC<1>{}, wk0);
+            stage_x(IC<0>{}, IC<1>{}, d0, tl0);
+        }
+        if (T > 1) {
+            stage_w(IC<1>{}, IC<0>{}, wk1);
+            stage_x(IC<1>{}, IC<0>{}, d1, tl1);
+            stage_w(IC<1>{}, IC<1>{}, wk1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    DL_BAR();
+    if (grp1) DL_BAR();          // stagger: waves 4-7 run one barrier behind
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int foff[2];
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = tm * BM + wm * PM + j * 16 + fr;
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = (fr * CPR + swz_chunk<CPR>(fr, kk * 4 + fg)) * 8;
+
+    bf16x8_t xf[2][4], wf0[2][2], wf1[2][2];
+    if constexpr (ABL >= 2) {           // ablations that skip the ds_reads still multiply something non-trivial
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[kk][j] = bf16x8_t{(short)(0x3f80 + lane), (short)(0x3f00 + j), 0x3e80, 0x3f81, (short)(0xbf80 + kk), 0x3f10, 0x3e90, 0x3f91};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { wf0[kk][i] = xf[kk][i]; wf1[kk][i] = xf[kk][i + 2]; }
+        }
+    }
+    auto read_x = [&](auto BUF, auto H) __attribute__((always_inline)) {
+        if (ABL >= 2) return;
+        constexpr int buf = decltype(BUF)::value, h = decltype(H)::value;
+        const bf16_t *base = smem + (buf * 4 + S_X + h) * HALF + wm * (64 * BK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[kk][j] = *reinterpret_cast<const bf16x8_t *>(base + j * 16 * BK + foff[kk]);
+    };
+    auto read_w = [&](auto BUF, auto H, bf16x8_t (&wf)[2][2]) {
+        if (ABL >= 2) return;
+        constexpr int buf = decltype(BUF)::value, h = decltype(H)::value;
+        const bf16_t *base = smem + (buf * 4 + S_W + h) * HALF + wn * (32 * BK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[kk][i] = *reinterpret_cast<const bf16x8_t *>(base + i * 16 * BK + foff[kk]);
+    };
+    auto mma_q = [&](auto IB, auto JA, const bf16x8_t (&wf)[2][2]) {
+        if (ABL == 2) return;
+        constexpr int ib = decltype(IB)::value * 2, ja = decltype(JA)::value * 4;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[ib + i][ja + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[ib + i][ja + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    auto step = [&](int t, auto BUF) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value;
+        const bool more1 = t + 1 < T, more2 = t + 2 < T;
+        // ---- phase 0
+        read_w(IC<buf>{}, IC<0>{}, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(IC<buf>{}, IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1 && ABL != 1 && ABL != 3) stage_x(IC<buf ^ 1>{}, IC<1>{}, d1, tl1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 4 WB_0 reads (issued first) are done: WB_0 is restaged next phase
+        DL_BAR();
+        mma_q(IC<0>{}, IC<0>{}, wf0);
+        DL_BAR();
+        // ---- phase 1
+        read_w(IC<buf>{}, IC<1>{}, wf1);
+        if (more2 && ABL != 1 && ABL != 3) stage_w(IC<buf>{}, IC<0>{}, wk2);
+        DL_BAR();
+        mma_q(IC<1>{}, IC<0>{}, wf1);
+        DL_BAR();
+        // ---- phase 2
+        read_x(IC<buf>{}, IC<1>{});
+        if (more2 && ABL != 1 && ABL != 3) stage_x(IC<buf>{}, IC<0>{}, d2, tl2);
+        DL_BAR();
+        mma_q(IC<1>{}, IC<1>{}, wf1);
+        DL_BAR();
+        // ---- phase 3
+        const int tl3 = DL_STEP_TL(t + 3), ch3 = DL_STEP_CH(t + 3);
+        const ptrdiff_t d3 = (ptrdiff_t)tapd_lds[tap0 + min(tl3, ntaps - 1)] + ch3;
+        if (more2 && ABL != 1 && ABL != 3) {
+            stage_w(IC<buf>{}, IC<1>{}, wk2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // everything of step t+1 has landed; step t+2's three stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        DL_BAR();
+        mma_q(IC<0>{}, IC<1>{}, wf0);
+        DL_BAR();
+        tl1 = tl2; d1 = d2;
+        tl2 = tl3; d2 = d3; wk2 = (size_t)tl3 * a.Ci + ch3;
+    };
+
+    for (int t = 0; t < T; t += 2) {
+        step(t, IC<0>{});
+        if (t + 1 < T) step(t + 1, IC<1>{});
+    }
+    if (!grp1) DL_BAR();         // pairs with the last barrier of the trailing group
+    __syncthreads();             // LDS is dead from here on (the epilogue reuses it for the statistics)
+
+    glds_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane, tid, smem_raw);
+}
+
+template <int ABL>
+static int launch_conv_8ph(const ConvArgs &a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.Mtot + 255) / 256;
+    a.tiles_n = a.Co / 256;
+    constexpr size_t smem = (size_t)8 * 128 * 64 * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_8ph_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_forward: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.n_phase * a.splitk);
+    hipLaunchKernelGGL(conv_gemm_8ph_kernel<ABL>, grid, dim3(512), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_forward(8-phase)");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Software-pipelined kernel (v_mfma_f32_32x32x16_bf16): 256 pixels x 256 channels x 64 K per tile, 8 waves (2 x 4, each 128
+// pixels x 64 channels = 2 x 4 blocks of 32 x 32).  One K=16 sub-step needs only 6 fragments (2 weight + 4 activation = 24
+// VGPRs) for 8 MFMAs (256 matrix-pipe cycles), so the fragments are DOUBLE-BUFFERED in registers: every wave issues the
+// ds_reads of sub-step s+1 before the MFMAs of sub-step s and overlaps its own LDS traffic with its own MFMAs -- the overlap
+// the 16x16x32 kernels can only get from the partner wave (their 12 fragments per K=32 do not fit twice next to 128
+// accumulators).  One barrier per 64-wide K tile; the DMA of tile t+2 starts right after the barrier that retires tile t.
+//   KWR (kernel-column reuse, 3x3 stride-1 layers whose image rows are 128 pixels wide): the three kw taps of one
+//   (kh, 64-channel chunk) read the SAME two image rows shifted by -1/0/+1 pixels.  The slab is staged once as
+//   2 x (1 + 128 + 1) pixel rows (the pad columns are zeroed once) and the fragment reads of tap kw start dw+1 rows further
+//   down: 32 KB of activation DMA per THREE K tiles instead of per tile (-33% of all staged bytes; the DMA path, ~18 B/clk/CU
+//   whatever the depth, is what bounds these kernels).  K tiles run in (kh, chunk, kw) order.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <bool KWR, int ABL>
+__global__ void __launch_bounds__(512) conv_gemm_p32_kernel(const ConvArgs a) {
+    constexpr int BM = 256, BN = 256, BK = 64, CPR = 8;
+    constexpr int XROWS = KWR ? 2 * 130 : 256;
+    constexpr int XB = XROWS * 128, WB = 256 * 128;            // bytes of one activation / weight buffer
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *xs = smem_raw;                                       // [2][XB]
+    char *ws = smem_raw + 2 * XB;                              // [2][WB]
+    int *tapd_lds = reinterpret_cast<int *>(ws + 2 * WB);      // element offset (dh*Wi + dw)*pstride of every tap
+    int *tapw_lds = tapd_lds + DL_MAX_TAPS;                    // dw + 1 of every tap (KWR)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
+    const int phase = blockIdx.y / a.splitk, ks = blockIdx.y % a.splitk;
+    const int tap0 = a.phase_tap_begin[phase];
+    const int ntaps = a.phase_tap_begin[phase + 1] - tap0;
+    const int kbase = a.phase_kbase[phase];
+    const int nk_total = ntaps * a.Ci / BK;
+    const int nk_per = (nk_total + a.splitk - 1) / a.splitk;
+    const int kt_begin = ks * nk_per;
+    const int T = max(min(nk_total, kt_begin + nk_per) - kt_begin, 0);
+    const int log2nch = a.log2Ci - 6;                          // channel chunks per tap = Ci / 64
+
+    if (tid < DL_MAX_TAPS) {
+        const int16_t tp = a.taps[tid];
+        const int dh = (int)(int8_t)(tp & 0xff), dw = (int)(int8_t)((tp >> 8) & 0xff);
+        tapd_lds[tid] = (dh * a.Wi + (KWR ? 0 : dw)) * a.in_pstride;
+        tapw_lds[tid] = dw + 1;
+    }
+    if (KWR && tid < 2 * 2 * 2 * 8) {          // zero the 2 x 2 pad rows of both slabs (16 bytes per thread)
+        const int c = tid & 7, r = (tid >> 3) & 1, e = (tid >> 4) & 1, b = tid >> 5;
+        *reinterpret_cast<u32x4_t *>(xs + b * XB + (r * 130 + e * 129) * 128 + c * 16) = u32x4_t{0, 0, 0, 0};
+    }
+
+    // K tile u (counted from kt_begin):  plain: tap-major (tap, chunk);  KWR: (kh, chunk, kw) with kw fastest
+    auto tile_tap = [&](int u) __attribute__((always_inline)) {
+        const int kt = kt_begin + u;
+        if (KWR) { const int g = kt / 3; return (g >> log2nch) * 3 + (kt - g * 3); }
+        return kt >> log2nch;
+    };
+    auto tile_ch = [&](int u) __attribute__((always_inline)) {
+        const int kt = kt_begin + u;
+        if (KWR) return ((kt / 3) & ((1 << log2nch) - 1)) * BK;
+        return (kt & ((1 << log2nch) - 1)) * BK;
+    };
+
+    const bf16_t *in = reinterpret_cast<const bf16_t *>(a.in);
+    const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_zero_page);
+    const int HWq = a.Hq * a.Wq;
+    const int lrow = lane >> 3, lcp = lane & 7;
+
+    // ---- staging geometry: instruction i of this wave fills tile rows s = (wave*4 + i)*8 + lrow
+    const bf16_t *x_ptr[4];
+    unsigned long long x_mask[4];
+    const bf16_t *w_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = (wave * 4 + i) * 8 + lrow;
+        const int xrow = KWR ? (s >> 7) * 130 + 1 + (s & 127) : s;          // LDS row of this pixel
+        const int m = tm * BM + s;
+        const bool ok = m < a.Mtot;
+        const int mm = ok ? m : 0;
+        const int n = mm / HWq, rem = mm - n * HWq;
+        const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        const int hi0 = hq * a.in_step, wi0 = wq * a.in_step;
+        x_ptr[i] = in + ((size_t)(n * a.Hi + hi0) * a.Wi + wi0) * (size_t)a.in_pstride + swz_chunk<CPR>(xrow, lcp) * 8;
+        unsigned long long mk = 0;
+        if (ok)
+            for (int t = 0; t < ntaps; ++t) {
+                const int16_t tp = a.taps[tap0 + t];
+                const int hi = hi0 + (int)(int8_t)(tp & 0xff), wi = wi0 + (KWR ? 0 : (int)(int8_t)((tp >> 8) & 0xff));
+                if (((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi)) mk |= 1ull << t;
+            }
+        x_mask[i] = mk;
+        w_ptr[i] = a.w_hi + (size_t)(tn * BN + s) * a.w_kstride + kbase + swz_chunk<CPR>(s, lcp) * 8;
+    }
+    // destination of instruction i inside a buffer (wave-uniform byte offset)
+    auto x_dst = [&](int i) __attribute__((always_inline)) {
+        const int s0 = (wave * 4 + i) * 8;
+        return (KWR ? (s0 >> 7) * 130 + 1 + (s0 & 127) : s0) * 128;
+    };
+
+    // one DMA instruction of K tile u: pieces 0..3 = weights, 4..7 = activations
+    auto stage_piece = [&](auto PIECE, int u, int tl, ptrdiff_t xdelta, size_t wk) __attribute__((always_inline)) {
+        constexpr int pc = decltype(PIECE)::value;
+        if constexpr (pc < 4) {
+            char *dst = ws + (u & 1) * WB + (wave * 4 + pc) * 8 * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_ptr[pc] + wk),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {
+            constexpr int i = pc - 4;
+            const int xb = KWR ? (((kt_begin + u) / 3) & 1) : (u & 1);
+            char *dst = xs + xb * XB + x_dst(i);
+            const bool ok = (x_mask[i] >> tl) & 1ull;
+            const bf16_t *src = ok ? x_ptr[i] + xdelta : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();     // tap tables + pad rows visible
+
+    // scalars of the tile being staged
+    auto tile_xdelta = [&](int u) __attribute__((always_inline)) { return (ptrdiff_t)tapd_lds[tap0 + min(tile_tap(u), ntaps - 1)] + tile_ch(u); };
+    auto tile_wk = [&](int u) __attribute__((always_inline)) { return (size_t)tile_tap(u) * a.Ci + tile_ch(u); };
+    auto tile_has_x = [&](int u) __attribute__((always_inline)) { return !KWR || ((kt_begin + u) % 3) == 0; };
+
+    // ---- prologue: tiles 0 and 1
+#define DL_STAGE_ALL(u)                                                                                  \
+    do {                                                                                                 \
+        const int tl_ = tile_tap(u);                                                                     \
+        const ptrdiff_t xd_ = tile_xdelta(u);                                                            \
+        const size_t wk_ = tile_wk(u);                                                                   \
+        stage_piece(IC<0>{}, u, tl_, xd_, wk_); stage_piece(IC<1>{}, u, tl_, xd_, wk_);                  \
+        stage_piece(IC<2>{}, u, tl_, xd_, wk_); stage_piece(IC<3>{}, u, tl_, xd_, wk_);                  \
+        if (tile_has_x(u)) {                                                                             \
+            stage_piece(IC<4>{}, u, tl_, xd_, wk_); stage_piece(IC<5>{}, u, tl_, xd_, wk_);              \
+            stage_piece(IC<6>{}, u, tl_, xd_, wk_); stage_piece(IC<7>{}, u, tl_, xd_, wk_);              \
+        }                                                                                                \
+    } while (0)
+    if (T > 0) DL_STAGE_ALL(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (T > 1) DL_STAGE_ALL(1);
+    __syncthreads();
+
+    // ---- fragment addressing (bytes): lane = (row lr of a 32-row block, K half h of a 16-wide sub-step)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int aw = (wn * 64 + lr) * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);             // weight fragment, sub-step 0, block 0
+    int ax[KWR ? 3 : 1];                                                            // activation fragment per kw shift
+#pragma unroll
+    for (int sh = 0; sh < (KWR ? 3 : 1); ++sh) {
+        const int row = KWR ? wm * 130 + sh + lr : wm * 128 + lr;
+        ax[sh] = row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
+    }
+
+    bf16x8_t F[2][6];
+    if constexpr (ABL >= 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int f = 0; f < 6; ++f) F[q][f] = bf16x8_t{(short)(0x3f80 + lane), (short)(0x3f00 + f), 0x3e80, 0x3f81, (short)(0xbf80 + q), 0x3f10, 0x3e90, 0x3f91};
+    }
+    // fragments of sub-step s of the tile held in buffers (xbuf, wbuf), activation rows shifted by `axs`
+    auto read_frags = [&](const char *xbuf, const char *wbuf, int axs, auto S, bf16x8_t (&f)[6]) __attribute__((always_inline)) {
+        if (ABL >= 2) return;
+        constexpr int sx = decltype(S)::value << 5;
+        const char *wp = wbuf + (aw ^ sx);
+        const char *xp = xbuf + (axs ^ sx);
+        f[0] = *reinterpret_cast<const bf16x8_t *>(wp);
+        f[1] = *reinterpret_cast<const bf16x8_t *>(wp + 32 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[2 + j] = *reinterpret_cast<const bf16x8_t *>(xp + j * 32 * 128);
+    };
+    auto mma = [&](const bf16x8_t (&f)[6]) __attribute__((always_inline)) {
+        if (ABL == 2) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+    };
+    auto tile_bufs = [&](int u, const char *&xbuf, const char *&wbuf, int &axs) __attribute__((always_inline)) {
+        wbuf = ws + (u & 1) * WB;
+        if (KWR) {
+            xbuf = xs + (((kt_begin + u) / 3) & 1) * XB;
+            const int sh = tapw_lds[tap0 + min(tile_tap(u), ntaps - 1)];
+            axs = sh == 0 ? ax[0] : (sh == 1 ? ax[KWR ? 1 : 0] : ax[KWR ? 2 : 0]);
+        } else {
+            xbuf = xs + (u & 1) * XB;
+            axs = ax[0];
+        }
+    };
+
+    const char *xb_cur, *wb_cur;
+    int ax_cur;
+    if (T > 0) {
+        tile_bufs(0, xb_cur, wb_cur, ax_cur);
+        read_frags(xb_cur, wb_cur, ax_cur, IC<0>{}, F[0]);
+    }
+    for (int t = 0; t < T; ++t) {
+        const bool st1 = (t + 1 < T) && t > 0 && ABL != 1 && ABL != 3;          // tile t+1 is being staged (tile 1: by the prologue)
+        const bool st2 = (t + 2 < T) && ABL != 1 && ABL != 3;
+        int tl_n = 0; ptrdiff_t xd_n = 0; size_t wk_n = 0; bool hx_n = false;
+        if (st1) { tl_n = tile_tap(t + 1); xd_n = tile_xdelta(t + 1); wk_n = tile_wk(t + 1); hx_n = tile_has_x(t + 1); }
+        // ---- sub-step 0
+        read_frags(xb_cur, wb_cur, ax_cur, IC<1>{}, F[1]);
+        mma(F[0]);
+        if (st1) {
+            stage_piece(IC<3>{}, t + 1, tl_n, xd_n, wk_n);
+            if (hx_n) { stage_piece(IC<4>{}, t + 1, tl_n, xd_n, wk_n); stage_piece(IC<5>{}, t + 1, tl_n, xd_n, wk_n); }
+        }
+        // ---- sub-step 1
+        read_frags(xb_cur, wb_cur, ax_cur, IC<2>{}, F[0]);
+        mma(F[1]);
+        if (st1 && hx_n) { stage_piece(IC<6>{}, t + 1, tl_n, xd_n, wk_n); stage_piece(IC<7>{}, t + 1, tl_n, xd_n, wk_n); }
+        // ---- sub-step 2
+        read_frags(xb_cur, wb_cur, ax_cur, IC<3>{}, F[1]);
+        mma(F[0]);
+        // tile t is completely in registers / accumulators, tile t+1 has landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        DL_BAR();
+        // ---- sub-step 3: first fragments of tile t+1, first DMA pieces of tile t+2 (into tile t's buffers)
+        if (t + 1 < T) {
+            tile_bufs(t + 1, xb_cur, wb_cur, ax_cur);
+            read_frags(xb_cur, wb_cur, ax_cur, IC<0>{}, F[0]);
+        }
+        mma(F[1]);
+        if (st2) {
+            const int tl2 = tile_tap(t + 2); const ptrdiff_t xd2 = tile_xdelta(t + 2); const size_t wk2 = tile_wk(t + 2);
+            stage_piece(IC<0>{}, t + 2, tl2, xd2, wk2); stage_piece(IC<1>{}, t + 2, tl2, xd2, wk2); stage_piece(IC<2>{}, t + 2, tl2, xd2, wk2);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: acc[i][j][r] = out[pixel = wm*128 + j*32 + (lane & 31)][channel = wn*64 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+    const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+    const bool want_stats = a.stats_part != nullptr;
+    float s1[2][4][4], s2[2][4][4];          // [i][quad][e]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[i][q][e] = s2[i][q][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = tm * BM + wm * 128 + j * 32 + lr;
         if (m >= a.Mtot) continue;
         const int n = m / HWq, rem = m - n * HWq;
         const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
         const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int co = tn * BN + wn * PN + i * 16 + fg * 4;
-            if (co >= a.Co) continue;
-            f32x4_t v = acc[i][j];
-            if (a.splitk > 1 || a.raw_out) {
-                float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
-                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                if (a.bias) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
-                }
-                if (a.act != DL_ACT_NONE) {
+            for (int q = 0; q < 4; ++q) {
+                const int co = tn * BN + wn * 64 + i * 32 + q * 8 + lh * 4;
+                if (co >= a.Co) continue;
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                if (a.splitk > 1 || a.raw_out) {
+                    float *dst = a.slab + ((size_t)ks * ((size_t)a.N * a.Ho * a.Wo) + opix) * a.Co + co;
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    if (a.bias) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act(a.act, v[r]);
-                }
-                bf16_t *dst = reinterpret_cast<bf16_t *>(a.out) + opix * a.out_pstride + co;
-                u32x2_t p;
-                p[0] = pack2_bf16(v[0], v[1]);
-                p[1] = pack2_bf16(v[2], v[3]);
-                *reinterpret_cast<u32x2_t *>(dst) = p;
-                if (want_stats) {      // statistics of exactly what was stored (bf16-rounded), like the stand-alone kernel sees
-                    const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                    const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
-                    st1[i][0] += q0; st2[i][0] += q0 * q0; st1[i][1] += q1; st2[i][1] += q1 * q1;
-                    st1[i][2] += q2; st2[i][2] += q2 * q2; st1[i][3] += q3; st2[i][3] += q3 * q3;
+                        for (int e = 0; e < 4; ++e) v[e] += (co + e < a.bias_n) ? a.bias[co + e] : 0.f;
+                    }
+                    if (a.act != DL_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(a.act, v[e]);
+                    }
+                    bf16_t *dst = reinterpret_cast<bf16_t *>(a.out) + opix * a.out_pstride + co;
+                    u32x2_t pk;
+                    pk[0] = pack2_bf16(v[0], v[1]);
+                    pk[1] = pack2_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2_t *>(dst) = pk;
+                    if (want_stats) {
+                        const float q0 = __uint_as_float(pk[0] << 16), q1 = __uint_as_float(pk[0] & 0xffff0000u);
+                        const float q2 = __uint_as_float(pk[1] << 16), q3 = __uint_as_float(pk[1] & 0xffff0000u);
+                        s1[i][q][0] += q0; s2[i][q][0] += q0 * q0; s1[i][q][1] += q1; s2[i][q][1] += q1 * q1;
+                        s1[i][q][2] += q2; s2[i][q][2] += q2 * q2; s1[i][q][3] += q3; s2[i][q][3] += q3 * q3;
+                    }
                 }
             }
-        }
     }
     if (want_stats) {
-        // lanes fr = 0..15 of one fg hold different pixels of the same 4 channels: butterfly over lane bits 0..3
+        // the 32 lanes with equal lane>>5 hold 32 pixels of the same channels: butterfly over lane bits 0..4
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { st1[i][r] += __shfl_xor(st1[i][r], o, 64); st2[i][r] += __shfl_xor(st2[i][r], o, 64); }
-            }
-        float *red = reinterpret_cast<float *>(smem_raw);          // [WM][2][BN]; the tile buffers are dead after the K loop
-        if (fr == 0) {
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = wn * PN + i * 16 + fg * 4 + r;
-                    red[(wm * 2 + 0) * BN + c] = st1[i][r];
-                    red[(wm * 2 + 1) * BN + c] = st2[i][r];
+                    for (int o = 16; o > 0; o >>= 1) { s1[i][q][e] += __shfl_xor(s1[i][q][e], o, 64); s2[i][q][e] += __shfl_xor(s2[i][q][e], o, 64); }
                 }
+        float *red = reinterpret_cast<float *>(smem_raw);          // [wm][2][BN]
+        if (lr == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = wn * 64 + i * 32 + q * 8 + lh * 4 + e;
+                        red[(wm * 2 + 0) * BN + c] = s1[i][q][e];
+                        red[(wm * 2 + 1) * BN + c] = s2[i][q][e];
+                    }
         }
         __syncthreads();
-        // every pixel of this tile lies in ONE image (host guarantees HWq % BM == 0): chunk = (tile in image, phase)
         const int m0 = tm * BM;
         const int n = m0 / HWq;
         const int chunk = ((m0 - n * HWq) / BM) * a.n_phase + phase;
-        for (int c = tid; c < BN; c += NW * 64) {
+        for (int c = tid; c < BN; c += 512) {
             const int co = tn * BN + c;
             if (co < a.Co) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
                 float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + co;
-                o[0] = s1;
-                o[a.Co] = s2;
+                o[0] = red[0 * BN + c] + red[2 * BN + c];
+                o[a.Co] = red[1 * BN + c] + red[3 * BN + c];
             }
         }
     }
+}
+
+template <bool KWR, int ABL>
+static int launch_conv_p32(const ConvArgs &a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    a.tiles_m = (a.Mtot + 255) / 256;
+    a.tiles_n = a.Co / 256;
+    constexpr size_t smem = (size_t)2 * (KWR ? 260 : 256) * 128 + (size_t)2 * 256 * 128 + 2 * DL_MAX_TAPS * sizeof(int);
+    auto kern = conv_gemm_p32_kernel<KWR, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_forward: hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.n_phase * a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_forward(p32)");
+    return 0;
+}
+
+// kernel-column reuse applies to: one phase of 9 taps ordered (kh, kw) with dh constant per kh and dw = -1/0/+1 (either
+// direction), stride 1, image rows exactly 128 pixels wide (a 256-pixel tile = two whole rows), no split-K
+static bool kwr_eligible(const ConvArgs &a) {
+    if (a.n_phase != 1 || a.splitk != 1 || a.in_step != 1 || a.out_step != 1 || a.Wq != 128 || a.Wi != 128 || (a.Hq & 1)) return false;
+    if (a.phase_tap_begin[1] - a.phase_tap_begin[0] != 9 || a.Ci < 64) return false;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int dh0 = (int8_t)(a.taps[kh * 3] & 0xff);
+        int seen = 0;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int16_t tp = a.taps[kh * 3 + kw];
+            const int dh = (int8_t)(tp & 0xff), dw = (int8_t)((tp >> 8) & 0xff);
+            if (dh != dh0 || dw < -1 || dw > 1) return false;
+            seen |= 1 << (dw + 1);
+        }
+        if (seen != 7) return false;
+    }
+    return true;
+}
+
+template <int ABL>
+static int dispatch_p32(const ConvArgs &a, hipStream_t stream) {
+    static const char *kwr_env = getenv("DL_CONV_KWR");          // "0": stage every K tile's activations separately
+    if (!(kwr_env && kwr_env[0] == '0') && kwr_eligible(a)) return launch_conv_p32<true, ABL>(a, stream);
+    return launch_conv_p32<false, ABL>(a, stream);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool UTAP, bool STAG = false, int ABL = 0>
@@ -652,10 +1319,32 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     // enough tiles to fill 256 CUs
     if (!no_big && a.Co >= 256 && (a.Co % 256) == 0 && (size_t)((a.Mtot + 255) / 256) * (a.Co / 256) * a.n_phase * a.splitk >= 256)
     {
+        // "1": software-pipelined 32x32x16 kernel (+ kernel-column reuse).  Same-box A/B of the whole training step (r01,
+        // tools/ab_bench.sh): 121.7-122.0 ms vs 121.4-122.1 ms for the 8-phase kernel, 123.4-123.6 ms for the one-barrier kernel;
+        // launch time 175 vs 168 vs 183 us.  The step is power-capped (profiles/r01/clock_probe.txt), so the 8-phase kernel
+        // stays the default and this one is kept for the next tuning pass (it moves 33% fewer bytes into LDS).
+        static const char *p32 = getenv("DL_CONV_P32");
+        if (p32 && p32[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) {
+            static const char *ablp = getenv("DL_CONV_ABLATE");
+            if (ablp && ablp[0] == '1') return dispatch_p32<1>(a, stream);
+            if (ablp && ablp[0] == '2') return dispatch_p32<2>(a, stream);
+            if (ablp && ablp[0] == '3') return dispatch_p32<3>(a, stream);
+            return dispatch_p32<0>(a, stream);
+        }
+        static const char *ph8 = getenv("DL_CONV_8PH");            // "0": fall back to the one-barrier-per-step kernel
+        if (!(ph8 && ph8[0] == '0') && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) {
+            static const char *abl8 = getenv("DL_CONV_ABLATE");
+            if (abl8 && abl8[0] == '1') return launch_conv_8ph<1>(a, stream);
+            if (abl8 && abl8[0] == '2') return launch_conv_8ph<2>(a, stream);
+            if (abl8 && abl8[0] == '3') return launch_conv_8ph<3>(a, stream);
+            return launch_conv_8ph<0>(a, stream);
+        }
         static const bool stag = getenv("DL_CONV_STAGGER") != nullptr;
         static const char *abl = getenv("DL_CONV_ABLATE");       // "1": no DMA in the loop, "2": no LDS reads / MFMAs (timing only!)
         if (abl && abl[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 1>(a, stream);
         if (abl && abl[0] == '2' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 2>(a, stream);
+        if (abl && abl[0] == '4' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 4>(a, stream);
+        if (abl && abl[0] == '5' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 5>(a, stream);
         if (stag && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, true>(a, stream);
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
@@ -724,6 +1413,25 @@ static int glds_tile_bm(const dl_conv_desc *d) {
     const int mtot = d->N * d->Hq * d->Wq;
     if (!no_big && d->Co >= 256 && (d->Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (d->Co / 256) * d->n_phase * d->splitk >= 256) return 256;
     return 128;
+}
+
+// Name of the kernel dl_conv_forward launches for this descriptor (as rocprofv3 prints it, without template noise); lets the
+// benchmark label its roofline line from the dispatch itself instead of a string that goes stale when a default changes.
+extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
+    if (!d) return "(null)";
+    const int bm = glds_tile_bm(d);
+    if (bm == 0) return (d->in_dtype == DL_BF16) ? "conv_gemm_kernel<bf16>" : "conv_gemm_kernel<f32>";
+    if (d->Co <= 16) return "conv_gemm_glds_kernel<256,16,32>";
+    if (d->Co <= 64) return "conv_gemm_glds_kernel<128,64,64>";
+    if (bm != 256) return "conv_gemm_glds_kernel<128,128,64>";
+    const bool utap = d->Ci >= 64 && d->pad_mode == DL_PAD_ZERO;
+    static const char *korder_env = getenv("DL_CONV_KORDER");
+    const bool korder = korder_env && korder_env[0] == '1';
+    static const char *p32 = getenv("DL_CONV_P32");
+    static const char *ph8 = getenv("DL_CONV_8PH");
+    if (utap && !korder && p32 && p32[0] == '1') return "conv_gemm_p32_kernel";
+    if (utap && !korder && !(ph8 && ph8[0] == '0')) return "conv_gemm_8ph_kernel";
+    return "conv_gemm_glds_kernel<256,256,64>";
 }
 
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {

@@ -83,6 +83,7 @@ class HipBackend:
     def __init__(self):
         self.lib = L.load()
         self._norm_ws_token = 0          # bumped whenever the shared 'norm_ws' workspace is overwritten
+        self.last_conv_kernel = ''
 
     def norm_ws_token(self) -> int:
         return self._norm_ws_token
@@ -121,6 +122,7 @@ class HipBackend:
         d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, pstride(out), hq, wq, dl_dtype(x), prec, act, in_act,
                            0 if bias is None else bias.numel(), splitk)
         assert dl_dtype(out) == d.in_dtype
+        self.last_conv_kernel = self.lib.dl_conv_kernel_name(C.byref(d)).decode()      # diagnostic (bench.py roofline label)
         slab = WS.get('conv_slab', splitk * n * ho * wo * cop, x.device) if splitk > 1 else None
         nch, part = 0, None
         if want_stats:

@@ -85,6 +85,9 @@ int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, con
  * (dl_norm_desc.ext_nchunks = chunks, partials at the start of its `ws`) skips its own statistics pass over y.  0 = not
  * available for this descriptor (pass stats_part = NULL). */
 int dl_conv_stats_chunks(const dl_conv_desc *d);
+/* Name of the kernel dl_conv_forward would launch for `d` (static string, matches the rocprofv3 kernel name up to template
+ * arguments).  Diagnostic only: bench.py labels its roofline line with it. */
+const char *dl_conv_kernel_name(const dl_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight gradient:  grad[a, b, kh, kw] (+)= sum_{n,hp,wp} P[n,hp,wp,a] * Q[n, hp*step - pad + kh, wp*step - pad + kw, b]

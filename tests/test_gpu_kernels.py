@@ -254,6 +254,52 @@ def test_norm_forward_backward(shape, C, scope, precname):
             assert rel(dg_r, dg_f) < 1e-3 and rel(db_r, db_f) < 1e-3
 
 
+BIG_CASES = [
+    # shapes large enough for the 256x256 tiles (>= 256 tiles): the 8-phase kernel (and DL_CONV_8PH=0: the one-barrier kernel)
+    ('conv', 256, 256, 3, 1, 1, 8, 128, 128),        # ResnetBlock conv at the 512x512 training shape: forward + data gradient
+    ('conv', 128, 256, 3, 2, 1, 8, 256, 256),        # second down conv: forward (9 taps x 128 ch) + 4-phase stride-2 data gradient
+    ('convT', 256, 128, 3, 2, 1, 8, 128, 128),       # first up conv: 4-phase forward (Co = 128: plain tiles), data gradient 128 -> 256
+    ('conv', 64, 256, 1, 1, 0, 4, 128, 128),         # odd number of K steps (1 tap x 64 channels = 1 step)
+    ('conv', 192, 256, 3, 1, 1, 4, 128, 128),        # Cin padded to 256 (zero channels), 36 steps
+    ('conv', 64, 256, 3, 1, 1, 16, 64, 128),         # kernel-column reuse with ONE channel chunk per tap (9 steps), 64-row images
+    ('conv', 128, 256, 3, 1, 1, 4, 128, 256),        # 256-pixel rows: no kernel-column reuse
+]
+
+
+@pytest.mark.parametrize('case', BIG_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}n{c[6]}')
+def test_conv_big_tiles(case):
+    kind, cin, cout, k, s_, p, N, H, W_ = case
+    prec = Precision.get('bf16')
+    spec = ConvSpec(kind, cin, cout, k, s_, p, L.PAD_ZERO, 1 if kind == 'convT' else 0)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd(wshape, 1, prec, 0.05)
+    bias = rnd((cout,), 2, Precision.get('fp32'), 0.1)
+    x = torch.zeros(N, H, W_, cpad(cin))
+    x[..., :cin] = rnd((N, H, W_, cin), 3, prec)
+    fake, real = fake_backend.FakeBackend(), hip()
+    exp = _run_conv(fake, 'fwd', spec, prec, x.to(prec.dtype), w, bias, L.ACT_NONE, L.ACT_NONE, H, W_)
+    for rep in range(3):            # repeated: a staging race would show up as run-to-run differences
+        got = _run_conv(real, 'fwd', spec, prec, x.to(prec.dtype).to(DEV), w.to(DEV), bias.to(DEV), L.ACT_NONE, L.ACT_NONE, H, W_)
+        sync()
+        assert rel(got, exp) < tol(prec), ('fwd', rep)
+        if rep == 0:
+            first = got.clone()
+        else:
+            assert torch.equal(got, first), 'run-to-run difference'
+    ho, wo = spec.out_hw(H, W_)
+    dy = torch.zeros(N, ho, wo, cpad(cout))
+    dy[..., :cout] = rnd((N, ho, wo, cout), 4, prec)
+    exp = _run_conv(fake, 'dgrad', spec, prec, dy.to(prec.dtype), w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+    for rep in range(3):
+        got = _run_conv(real, 'dgrad', spec, prec, dy.to(prec.dtype).to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+        sync()
+        assert rel(got, exp) < tol(prec), ('dgrad', rep)
+        if rep == 0:
+            first = got.clone()
+        else:
+            assert torch.equal(got, first), 'run-to-run difference (dgrad)'
+
+
 STATS_CASES = [
     # kind, cin, cout, k, s, p, N, H, W      (bf16 direct-to-LDS dispatch: 256x16 / 128x64 / 128x128 / 256x256 tiles, 4-phase convT)
     ('conv', 3, 64, 7, 1, 3, 2, 32, 32),
