@@ -110,18 +110,34 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const T *y, int y_ps,
 // With FUSE != 0 (instance scope) the per-(n,c) statistics / backward constants are finalised right here:
 //   FUSE 1 (forward) : mean, rstd, scale, shift           FUSE 2 (backward): c1 = S1/HW, c2 = S2/HW
 template <int FUSE>
-__global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums, float eps, float *o0, float *o1,
-                                                             float *o2, float *o3) {
-    __shared__ float red[2][8][33];
+__global__ void __launch_bounds__(1024) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums, float eps, float *o0, float *o1,
+                                                              float *o2, float *o3) {
+    // block = 32 channels x 32 chunk lanes: every thread owns at most nchunks/32 partials and loads them with independent
+    // accumulators (the 8-lane version was a chain of 8-16 dependent L2 round trips: 11 us for < 2 MB)
+    constexpr int KL = 32;
+    __shared__ float red[2][KL][33];
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
     float s1 = 0.f, s2 = 0.f;
     if (c < g.Cp) {
-        for (int k = kl; k < g.nchunks; k += 8) {
-            const float *o = part + ((size_t)(n * g.nchunks + k) * 2) * g.Cp + c;
-            s1 += o[0];
-            s2 += o[g.Cp];
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *base = part + ((size_t)n * g.nchunks * 2) * g.Cp + c;
+        int k = kl;
+        for (; k + 3 * KL < g.nchunks; k += 4 * KL) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *o = base + (size_t)(k + u * KL) * 2 * g.Cp;
+                a1[u] += o[0];
+                a2[u] += o[g.Cp];
+            }
         }
+        for (int u = 0; k < g.nchunks; k += KL, ++u) {
+            const float *o = base + (size_t)k * 2 * g.Cp;
+            a1[u & 3] += o[0];
+            a2[u & 3] += o[g.Cp];
+        }
+        s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+        s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     }
     red[0][kl][cl] = s1;
     red[1][kl][cl] = s2;
@@ -129,7 +145,7 @@ __global__ void __launch_bounds__(256) norm_chunk_sum_kernel(const float *part, 
     if (kl == 0 && c < g.Cp) {
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { a1 += (double)red[0][r][cl]; a2 += (double)red[1][r][cl]; }
+        for (int r = 0; r < KL; ++r) { a1 += (double)red[0][r][cl]; a2 += (double)red[1][r][cl]; }
         sums[((size_t)n * 2) * g.Cp + c] = (float)a1;
         sums[((size_t)n * 2 + 1) * g.Cp + c] = (float)a2;
         if (FUSE == 1) {           // InstanceNorm2d: no affine (networks.py:36-37)
@@ -304,8 +320,16 @@ __global__ void __launch_bounds__(1024) norm_bias_final_kernel(const float *part
     const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    if (c < C)
-        for (int b = kl; b < nparts; b += 32) s += part[(size_t)b * Cp + c];
+    if (c < C) {     // 8 independent accumulators: 64 dependent L2 round trips (nparts = 2048) become 8
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = kl;
+        for (; b + 7 * 32 < nparts; b += 8 * 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(b + u * 32) * Cp + c];
+        }
+        for (int u = 0; b < nparts; b += 32, ++u) acc[u & 7] += part[(size_t)b * Cp + c];
+        s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
     red[kl][cl] = s;
     __syncthreads();
     if (kl == 0 && c < C) {
@@ -354,10 +378,10 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
     DL_CHECK_LAUNCH("dl_norm_forward(stats)");
     float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
     if (d->scope == DL_NORM_INSTANCE && !gamma && !beta) {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<1>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums, d->eps, mean, rstd, scale, shift);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<1>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, mean, rstd, scale, shift);
         DL_CHECK_LAUNCH("dl_norm_forward(chunk sums + finalize)");
     } else {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, ws, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_forward(chunk sums)");
         const int ftotal = (d->scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
         hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, d->eps, gamma, beta,
@@ -397,10 +421,10 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
                            (const bf16_t *)dz, dz_ps, g, d->act, mean, rstd, scale, shift, part);
     DL_CHECK_LAUNCH("dl_norm_backward(reduce)");
     if (d->scope == DL_NORM_INSTANCE && !dgamma) {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<2>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums, d->eps, c1, c2, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<2>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, c1, c2, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_backward(chunk sums + finalize)");
     } else {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(256), 0, stream, part, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_backward(chunk sums)");
         hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, c1, c2, dgamma, dbeta,
                            accumulate_affine);
