@@ -62,6 +62,9 @@ SIGNATURES = {
     'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
+    'dl_pack_job_bytes': (C.c_size_t, []),
+    'dl_pack_job_fill': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
+    'dl_pack_weights_batch': (_i, [_vp, _i, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),
     'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

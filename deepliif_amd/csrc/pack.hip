@@ -12,9 +12,10 @@ struct PackArgs {
     int8_t tap_kh[DL_MAX_TAPS], tap_kw[DL_MAX_TAPS];
 };
 
-__global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) {
+// one image: element i of the K-contiguous GEMM image <- the OIHW/IOHW master weight it comes from (0 in the padding)
+__device__ __forceinline__ void pack_image(const PackArgs &a, int block, int nblocks) {
     const size_t total = (size_t)a.rows_pad * a.kstride;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = block * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nblocks * blockDim.x) {
         const int row = (int)(i / a.kstride), k = (int)(i % a.kstride);
         float v = 0.f;
         if (row < a.rows_real) {
@@ -40,13 +41,23 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) {
     }
 }
 
-extern "C" int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!d || !src || !w_hi) DL_FAIL("dl_pack_weights: null argument");
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) { pack_image(a, blockIdx.x, gridDim.x); }
+
+// every image of an optimizer's layers in ONE launch: blockIdx.y picks the job record (device memory, filled by dl_pack_job_fill)
+__global__ void __launch_bounds__(256) pack_weights_batch_kernel(const char *jobs, size_t job_stride) {
+    __shared__ PackArgs a;
+    const int *src = reinterpret_cast<const int *>(jobs + (size_t)blockIdx.y * job_stride);      // stride = dl_pack_job_bytes()
+    int *dst = reinterpret_cast<int *>(&a);
+    for (int i = threadIdx.x; i < (int)(sizeof(PackArgs) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    pack_image(a, blockIdx.x, gridDim.x);
+}
+
+static int fill_pack_args(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, PackArgs &a, const char *who) {
+    if (!d || !src || !w_hi) DL_FAIL("%s: null argument", who);
     const int l2 = ilog2_exact(d->Cc_pad);
-    if (l2 < 3) DL_FAIL("dl_pack_weights: Cc_pad=%d must be a power of two >= 8", d->Cc_pad);
-    if (d->n_phase < 1 || d->n_phase > DL_MAX_PHASES) DL_FAIL("dl_pack_weights: n_phase=%d", d->n_phase);
-    PackArgs a;
+    if (l2 < 3) DL_FAIL("%s: Cc_pad=%d must be a power of two >= 8", who, d->Cc_pad);
+    if (d->n_phase < 1 || d->n_phase > DL_MAX_PHASES) DL_FAIL("%s: n_phase=%d", who, d->n_phase);
     memset(&a, 0, sizeof(a));
     a.src = src; a.w_hi = (bf16_t *)w_hi; a.w_lo = (bf16_t *)w_lo;
     a.A = d->A; a.B = d->B; a.KH = d->KH; a.KW = d->KW; a.row_is_a = d->row_is_a;
@@ -56,13 +67,45 @@ extern "C" int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_
     for (int p = 0; p < d->n_phase; ++p) {
         a.phase_kbase[p] = d->phase_kbase[p];
         a.phase_kend[p] = d->phase_kbase[p] + (d->phase_tap_begin[p + 1] - d->phase_tap_begin[p]) * d->Cc_pad;
-        if (a.phase_kend[p] > d->kstride) DL_FAIL("dl_pack_weights: phase %d exceeds kstride", p);
+        if (a.phase_kend[p] > d->kstride) DL_FAIL("%s: phase %d exceeds kstride", who, p);
     }
     for (int t = 0; t < DL_MAX_TAPS; ++t) { a.tap_kh[t] = d->tap_kh[t]; a.tap_kw[t] = d->tap_kw[t]; }
+    return 0;
+}
+
+extern "C" int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PackArgs a;
+    if (fill_pack_args(d, src, w_hi, w_lo, a, "dl_pack_weights")) return -1;
     const size_t total = (size_t)d->rows_pad * d->kstride;
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, a);
     DL_CHECK_LAUNCH("dl_pack_weights");
+    return 0;
+}
+
+extern "C" size_t dl_pack_job_bytes(void) { return (sizeof(PackArgs) + 15) / 16 * 16; }
+
+extern "C" int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *job_host) {
+    if (!job_host) DL_FAIL("dl_pack_job_fill: null job record");
+    PackArgs a;
+    if (fill_pack_args(d, src, w_hi, w_lo, a, "dl_pack_job_fill")) return -1;
+    memset(job_host, 0, dl_pack_job_bytes());
+    memcpy(job_host, &a, sizeof(a));
+    return 0;
+}
+
+extern "C" int dl_pack_weights_batch(const void *jobs_dev, int count, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count <= 0) return 0;
+    if (!jobs_dev) DL_FAIL("dl_pack_weights_batch: null job table");
+    if (count > 65535) DL_FAIL("dl_pack_weights_batch: %d jobs (max 65535 per launch)", count);
+    static_assert(sizeof(PackArgs) % sizeof(int) == 0, "job records are copied to LDS as ints");
+    // 32 grid-stride blocks per image: the largest image (512 x 8192) gets 512 elements per thread, the table of a whole
+    // generator set (~250 images) still fills the chip
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, count), dim3(256), 0, stream,
+                       reinterpret_cast<const char *>(jobs_dev), dl_pack_job_bytes());
+    DL_CHECK_LAUNCH("dl_pack_weights_batch");
     return 0;
 }
 

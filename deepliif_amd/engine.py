@@ -8,6 +8,8 @@ Precision policies:
 """
 from __future__ import annotations
 
+import weakref
+
 from dataclasses import dataclass
 from typing import Callable, List, Optional
 
@@ -91,6 +93,10 @@ def empty_like_act(a: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------
 # layers (parameter holders are the nn.Modules in networks.py; these classes own geometry + packed weight images)
 # ---------------------------------------------------------------------------------------------------------------
+# nn.Parameter (by identity) -> the ConvLayer bound to it: lets an optimizer find the GEMM images of the weights it updates
+LAYER_OF_WEIGHT: 'weakref.WeakValueDictionary[int, ConvLayer]' = weakref.WeakValueDictionary()
+
+
 class ConvLayer:
     """One Conv2d / ConvTranspose2d of the reference networks bound to its nn.Parameter(s)."""
 
@@ -104,6 +110,7 @@ class ConvLayer:
         self.packed_dgrad: Optional[ops.PackedWeights] = None
         self.fwd_key = None
         self.dgrad_key = None
+        LAYER_OF_WEIGHT[id(weight)] = self
         # narrow-Cout layers (the 7x7, 64 -> 3 ResnetGenerator head): kernel columns folded into the GEMM rows (dl_shift_sum)
         self.narrow = spec.is_narrow()
         if self.narrow:
@@ -132,6 +139,37 @@ class ConvLayer:
                 self.packed_dgrad = ops.PackedWeights(self.dgrad_plan, w.device, with_lo)
             be.pack_weights(self.packed_dgrad, w.detach())
             self.dgrad_key = key
+
+
+class PackBatch:
+    """Repacks, in ONE launch, every GEMM image that already exists for the conv weights of a parameter set (called by the fused
+    Adam right after it changed them).  ConvLayer.ensure_packed stays the source of truth: images that do not exist yet, or whose
+    weights were changed some other way (load_state_dict, a torch optimizer), are (re)built lazily there as before."""
+
+    def __init__(self, params):
+        self.layers = [LAYER_OF_WEIGHT[id(p)] for p in params if id(p) in LAYER_OF_WEIGHT]
+        self.table, self.sig = None, None
+
+    def run(self):
+        be = ops.impl()
+        jobs, stamps = [], []
+        for layer in self.layers:
+            w = layer.weight
+            for packed, attr in ((layer.packed_fwd, 'fwd_key'), (layer.packed_dgrad, 'dgrad_key')):
+                key = getattr(layer, attr)
+                if packed is None or key is None or key[1] != w.data_ptr() or packed.hi.device != w.device:
+                    continue            # never packed / storage moved: the lazy path handles it
+                jobs.append((packed, w.detach()))
+                stamps.append((layer, attr, (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), key[3], key[4])))
+        if not jobs:
+            return 0
+        sig = tuple((pk.hi.data_ptr(), pk.lo.data_ptr() if pk.lo is not None else 0, w.data_ptr()) for pk, w in jobs)
+        if sig != self.sig:
+            self.table, self.sig = be.pack_batch_build(jobs), sig
+        be.pack_batch_run(self.table, len(jobs))
+        for layer, attr, key in stamps:
+            setattr(layer, attr, key)
+        return len(jobs)
 
 
 class NormLayer:

@@ -96,6 +96,24 @@ class HipBackend:
         d.KH = src.shape[2]
         L.check(self.lib.dl_pack_weights(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), _stream()), 'dl_pack_weights')
 
+    def pack_batch_build(self, jobs):
+        """jobs: [(PackedWeights, fp32 master weight)] -> device table of dl_pack_job records (built once, see dl_pack_weights_batch)"""
+        jb = int(self.lib.dl_pack_job_bytes())
+        host = (C.c_ubyte * (jb * len(jobs)))()
+        base = C.addressof(host)
+        for i, (packed, src) in enumerate(jobs):
+            _need_cuda(src, packed.hi)
+            assert src.dtype == torch.float32 and src.is_contiguous()
+            d = fill_pack_desc(packed.plan, src.shape[0], src.shape[1], src.shape[2])
+            d.KH = src.shape[2]
+            L.check(self.lib.dl_pack_job_fill(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), C.c_void_p(base + i * jb)),
+                    'dl_pack_job_fill')
+        return torch.frombuffer(host, dtype=torch.uint8).clone().to(jobs[0][1].device)
+
+    def pack_batch_run(self, table: torch.Tensor, count: int):
+        _need_cuda(table)
+        L.check(self.lib.dl_pack_weights_batch(_ptr(table), count, _stream()), 'dl_pack_weights_batch')
+
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
                      act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False, want_stats: bool = False):

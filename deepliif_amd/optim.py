@@ -8,6 +8,7 @@ optimizer keep working on them.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
@@ -61,6 +62,9 @@ class FlatParams:
         return self.offsets[idx[0]], end
 
 
+_PACK_BATCH = os.environ.get('DL_PACK_BATCH', '0') == '1'
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0, amsgrad=False) semantics on a FlatParams set, one kernel per
     step.  A torch lr_scheduler drives param_groups[0]['lr'] as usual (networks.py:55-81, base_model.py:132-141)."""
@@ -73,6 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.step_count = 0
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel driver (sum all-reduce)
+        self._pack_batch = None        # engine.PackBatch over this set's conv weights, built at the first step
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
@@ -87,3 +92,14 @@ class FusedAdam(torch.optim.Optimizer):
         ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
                              self.step_count, self.grad_scale)
         self.flat.bump_epoch()         # packed bf16 weight images are stale now (engine.ConvLayer.ensure_packed)
+        # ... optionally rebuild the ones that exist in one launch instead of one launch per image at their next use.
+        # OFF by default (DL_PACK_BATCH=1 enables).  Measured in round 1, profiles/r01/bench_train_kernel_stats_v16_packbatch.csv,
+        # 3 steps x 2 optimizers: the 6 batched launches took 765.7 us each = 4.59 ms; they replaced 645 single-image launches
+        # (940 -> 295) of 6.2 us = 4.0 ms.  A small LOSS: the kernel decodes (div/mod, phase search) per element and stores 2 bytes
+        # per thread, and with 32 blocks per image a launch lasts as long as its largest image (512 x 8192 elements).
+        if not _PACK_BATCH:
+            return
+        if self._pack_batch is None:
+            from . import engine            # (engine does not import optim: no cycle, but keep the import local to the hot path's owner)
+            self._pack_batch = engine.PackBatch(self.flat.params)
+        self._pack_batch.run()

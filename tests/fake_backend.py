@@ -55,6 +55,16 @@ class FakeBackend:
     def _count(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1
 
+    def pack_batch_build(self, jobs):
+        self._count('pack_batch_build')
+        return list(jobs)
+
+    def pack_batch_run(self, table, count):
+        self._count('pack_batch')
+        assert len(table) == count
+        for packed, src in table:
+            self.pack_weights(packed, src)
+
     def pack_weights(self, packed, src):
         self._count('pack')
         plan = packed.plan

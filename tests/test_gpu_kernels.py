@@ -300,6 +300,40 @@ def test_conv_big_tiles(case):
             assert torch.equal(got, first), 'run-to-run difference (dgrad)'
 
 
+def test_pack_weights_batch_matches_single_packs():
+    """dl_pack_weights_batch over a table of job records must write exactly what dl_pack_weights writes image by image
+    (forward / 4-phase data-gradient / transposed / kernel-column-stacked layouts, with and without the lo image)."""
+    be = hip()
+    specs = [ConvSpec('conv', 3, 64, 7, 1, 3), ConvSpec('conv', 64, 128, 3, 2, 1), ConvSpec('conv', 256, 256, 3, 1, 1),
+             ConvSpec('convT', 256, 128, 3, 2, 1, L.PAD_ZERO, 1), ConvSpec('conv', 6, 64, 4, 2, 1), ConvSpec('conv', 512, 1, 4, 1, 1),
+             ConvSpec('conv', 64, 3, 7, 1, 3)]
+    jobs, refs = [], []
+    for i, spec in enumerate(specs):
+        wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == 'conv' else (spec.cin, spec.cout, spec.k, spec.k)
+        w = rnd(wshape, 10 + i, Precision.get('fp32'), 0.05).to(DEV)
+        plans = [spec.forward_plan(), spec.dgrad_plan()]
+        if spec.is_narrow():
+            plans.append(spec.narrow_forward_plan())
+        for plan in plans:
+            for with_lo in (False, True):
+                single = ops.PackedWeights(plan, DEV, with_lo)
+                be.pack_weights(single, w)
+                batched = ops.PackedWeights(plan, DEV, with_lo)
+                batched.hi.fill_(float('nan'))
+                if with_lo:
+                    batched.lo.fill_(float('nan'))
+                jobs.append((batched, w))
+                refs.append(single)
+    table = be.pack_batch_build(jobs)
+    assert table.numel() == len(jobs) * int(be.lib.dl_pack_job_bytes())
+    be.pack_batch_run(table, len(jobs))
+    sync()
+    for (batched, _), single in zip(jobs, refs):
+        assert torch.equal(batched.hi.view(torch.int16), single.hi.view(torch.int16))
+        if single.lo is not None:
+            assert torch.equal(batched.lo.view(torch.int16), single.lo.view(torch.int16))
+
+
 STATS_CASES = [
     # kind, cin, cout, k, s, p, N, H, W      (bf16 direct-to-LDS dispatch: 256x16 / 128x64 / 128x128 / 256x256 tiles, 4-phase convT)
     ('conv', 3, 64, 7, 1, 3, 2, 32, 32),

@@ -120,3 +120,49 @@ def test_deepliif_ext_two_steps_follow_oracle():
         for i in range(2):
             for a, b in ((model.fake_B[i], om.fake_B[i].detach()), (model.fake_BS[i], om.fake_BS[i].detach())):
                 assert float((a - b).abs().max() / b.abs().max()) < (5e-4 if step == 0 else 3e-2)
+
+
+def test_fused_adam_repacks_existing_images_in_one_batch():
+    """After FusedAdam.step the GEMM images that already exist are rebuilt by ONE batched call and ensure_packed finds them
+    current (no per-layer repack at the next forward); images that never existed are left to the lazy path."""
+    import fake_backend
+    from deepliif_amd import engine as E, ops, optim, networks
+    fb = fake_backend.FakeBackend()
+    old, old_flag = ops._impl, optim._PACK_BATCH
+    ops._impl = fb
+    optim._PACK_BATCH = True            # the hook is opt-in (DL_PACK_BATCH=1) until the batched kernel beats the single launches
+    try:
+        torch.manual_seed(0)
+        net = networks.define_D(6, 8, 'n_layers', n_layers_D=2, norm='instance', init_type='normal', init_gain=0.02, gpu_ids=[])
+        net.train()
+        opt = optim.FusedAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+        prec = E.Precision.get('fp32')
+        x = torch.randn(1, 6, 32, 32)
+
+        def fwd_bwd():                              # the engine's own reverse mode (explicit tape), not torch.autograd
+            opt.zero_grad()                         # keeps p.grad attached to the optimizer's flat gradient buffer
+            tape = E.Tape()
+            ctx = E.Ctx(prec, tape, training=True)
+            xa = E.to_engine(x, prec)
+            xa.needs_grad = True                    # so the data-gradient images are built as well
+            ya = net.run(ctx, xa)
+            ya.grad = torch.ones_like(ya.t)
+            tape.backward()
+
+        fwd_bwd()                                   # builds forward (+ data-gradient) images lazily
+        n_images = fb.calls.get('pack', 0)
+        assert n_images > 0
+        opt.step()
+        assert fb.calls.get('pack_batch', 0) == 1 and fb.calls.get('pack_batch_build', 0) == 1
+        assert fb.calls['pack'] == 2 * n_images    # every existing image repacked exactly once, inside the batch
+        fwd_bwd()
+        assert fb.calls['pack'] == 2 * n_images, 'ensure_packed repacked an image the batch had already rebuilt'
+        opt.step()
+        assert fb.calls['pack_batch'] == 2 and fb.calls['pack_batch_build'] == 1, 'the job table must be reused'
+        # weights changed behind the optimizer's back (load_state_dict): the lazy path must still notice
+        net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+        before = fb.calls['pack']
+        fwd_bwd()
+        assert fb.calls['pack'] > before
+    finally:
+        ops._impl, optim._PACK_BATCH = old, old_flag
