@@ -64,7 +64,8 @@ SIGNATURES = {
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_pack_job_bytes': (C.c_size_t, []),
     'dl_pack_job_fill': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
-    'dl_pack_weights_batch': (_i, [_vp, _i, _vp]),
+    'dl_pack_batch_blocks': (_i, [_vp, _i, _vp]),
+    'dl_pack_weights_batch': (_i, [_vp, _vp, _i, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),
     'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

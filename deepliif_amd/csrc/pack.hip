@@ -43,14 +43,61 @@ __device__ __forceinline__ void pack_image(const PackArgs &a, int block, int nbl
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs a) { pack_image(a, blockIdx.x, gridDim.x); }
 
-// every image of an optimizer's layers in ONE launch: blockIdx.y picks the job record (device memory, filled by dl_pack_job_fill)
-__global__ void __launch_bounds__(256) pack_weights_batch_kernel(const char *jobs, size_t job_stride) {
+// ---- batched form: every image of an optimizer's layers in ONE launch.
+// Work unit = one 16-byte output chunk = 8 consecutive k of one row.  kstride and every phase base are multiples of 64 and a tap
+// spans Cc_pad (a power of two >= 8) elements, so a chunk never straddles a row, a phase or a tap: ONE decode + one 16-byte
+// store per 8 outputs instead of a 64-bit div/mod, a phase search and a 2-byte store per output.  Blocks are handed out by a
+// host-built table {job, first chunk}, i.e. in proportion to image SIZE -- a launch no longer lasts as long as its largest image.
+constexpr int PACK_CHUNKS_PER_BLOCK = 256 * 4;       // 256 threads x 4 chunks = 8192 elements
+
+__global__ void __launch_bounds__(256) pack_weights_batch_kernel(const char *jobs, size_t job_stride, const int2 *block_tab) {
     __shared__ PackArgs a;
-    const int *src = reinterpret_cast<const int *>(jobs + (size_t)blockIdx.y * job_stride);      // stride = dl_pack_job_bytes()
+    const int2 bt = block_tab[blockIdx.x];           // x = job, y = first chunk of this block inside the job's image
+    const int *src = reinterpret_cast<const int *>(jobs + (size_t)bt.x * job_stride);      // stride = dl_pack_job_bytes()
     int *dst = reinterpret_cast<int *>(&a);
     for (int i = threadIdx.x; i < (int)(sizeof(PackArgs) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    pack_image(a, blockIdx.x, gridDim.x);
+    const int cpr = a.kstride >> 3;                  // chunks per row
+    const int nchunks = a.rows_pad * cpr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ch = bt.y + u * 256 + threadIdx.x;
+        if (ch >= nchunks) break;
+        const int row = ch / cpr, k0 = (ch - row * cpr) << 3;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row < a.rows_real) {
+            int ph = -1;
+            for (int p = 0; p < a.n_phase; ++p)
+                if (k0 >= a.phase_kbase[p] && k0 < a.phase_kend[p]) ph = p;
+            if (ph >= 0) {
+                const int kl = k0 - a.phase_kbase[ph];
+                const int tl = kl >> a.log2Cc, c0 = kl & (a.Cc_pad - 1);
+                const int t = a.phase_tap_begin[ph] + tl;
+                if (t < a.phase_tap_begin[ph + 1]) {
+                    const int kh = a.tap_kh[t];
+                    int kw = a.tap_kw[t], r = row;
+                    if (a.stack_kw) { kw = row % a.KW; r = row / a.KW; }      // row = a*KW + kw
+                    const size_t khw = (size_t)a.KH * a.KW;
+                    // consecutive c: stride KH*KW floats when the row is the A index, B*KH*KW when it is the B index
+                    const size_t base = a.row_is_a ? ((size_t)r * a.B + c0) * khw : ((size_t)c0 * a.B + r) * khw;
+                    const size_t cstride = a.row_is_a ? khw : (size_t)a.B * khw;
+                    const float *sp = a.src + base + (size_t)kh * a.KW + kw;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + e < a.Cc) v[e] = sp[e * cstride];
+                }
+            }
+        }
+        u32x4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16_t h0 = f32_to_bf16(v[2 * e]), h1 = f32_to_bf16(v[2 * e + 1]);
+            hi[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            lo[e] = (uint32_t)f32_to_bf16(v[2 * e] - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v[2 * e + 1] - bf16_to_f32(h1)) << 16);
+        }
+        *reinterpret_cast<u32x4_t *>(a.w_hi + (size_t)ch * 8) = hi;
+        if (a.w_lo) *reinterpret_cast<u32x4_t *>(a.w_lo + (size_t)ch * 8) = lo;
+    }
 }
 
 static int fill_pack_args(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, PackArgs &a, const char *who) {
@@ -95,16 +142,32 @@ extern "C" int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w
     return 0;
 }
 
-extern "C" int dl_pack_weights_batch(const void *jobs_dev, int count, void *stream_) {
+// Block table of a batch: entry = {job index, first 16-byte chunk} per workgroup of PACK_CHUNKS_PER_BLOCK chunks.  Call with
+// block_tab_host = NULL to get the number of entries, then again to fill them (host memory; the caller copies it to the device).
+extern "C" int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *block_tab_host) {
+    if (!jobs_host || count < 0) DL_FAIL("dl_pack_batch_blocks: bad arguments");
+    const size_t jb = dl_pack_job_bytes();
+    long n = 0;
+    for (int j = 0; j < count; ++j) {
+        PackArgs a;
+        memcpy(&a, (const char *)jobs_host + (size_t)j * jb, sizeof(a));
+        if (a.kstride % 8) DL_FAIL("dl_pack_batch_blocks: job %d: kstride %d is not a multiple of 8", j, a.kstride);
+        const long chunks = (long)a.rows_pad * (a.kstride / 8);
+        if (chunks > 0x7fffffffL) DL_FAIL("dl_pack_batch_blocks: job %d is too large", j);
+        for (long c = 0; c < chunks; c += PACK_CHUNKS_PER_BLOCK, ++n)
+            if (block_tab_host) { block_tab_host[2 * n] = j; block_tab_host[2 * n + 1] = (int32_t)c; }
+    }
+    if (n > 0x7fffffffL) DL_FAIL("dl_pack_batch_blocks: too many blocks");
+    return (int)n;
+}
+
+extern "C" int dl_pack_weights_batch(const void *jobs_dev, const int32_t *block_tab_dev, int nblocks, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (count <= 0) return 0;
-    if (!jobs_dev) DL_FAIL("dl_pack_weights_batch: null job table");
-    if (count > 65535) DL_FAIL("dl_pack_weights_batch: %d jobs (max 65535 per launch)", count);
+    if (nblocks <= 0) return 0;
+    if (!jobs_dev || !block_tab_dev) DL_FAIL("dl_pack_weights_batch: null table");
     static_assert(sizeof(PackArgs) % sizeof(int) == 0, "job records are copied to LDS as ints");
-    // 32 grid-stride blocks per image: the largest image (512 x 8192) gets 512 elements per thread, the table of a whole
-    // generator set (~250 images) still fills the chip
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, count), dim3(256), 0, stream,
-                       reinterpret_cast<const char *>(jobs_dev), dl_pack_job_bytes());
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(nblocks), dim3(256), 0, stream, reinterpret_cast<const char *>(jobs_dev),
+                       dl_pack_job_bytes(), reinterpret_cast<const int2 *>(block_tab_dev));
     DL_CHECK_LAUNCH("dl_pack_weights_batch");
     return 0;
 }

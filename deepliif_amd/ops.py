@@ -108,11 +108,18 @@ class HipBackend:
             d.KH = src.shape[2]
             L.check(self.lib.dl_pack_job_fill(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), C.c_void_p(base + i * jb)),
                     'dl_pack_job_fill')
-        return torch.frombuffer(host, dtype=torch.uint8).clone().to(jobs[0][1].device)
+        nblocks = int(self.lib.dl_pack_batch_blocks(C.c_void_p(base), len(jobs), None))
+        if nblocks < 0:
+            L.check(nblocks, 'dl_pack_batch_blocks')
+        tab = (C.c_int32 * (2 * max(nblocks, 1)))()
+        L.check(min(int(self.lib.dl_pack_batch_blocks(C.c_void_p(base), len(jobs), C.c_void_p(C.addressof(tab)))), 0), 'dl_pack_batch_blocks')
+        dev = jobs[0][1].device
+        return (torch.frombuffer(host, dtype=torch.uint8).clone().to(dev), torch.frombuffer(tab, dtype=torch.int32).clone().to(dev), nblocks)
 
-    def pack_batch_run(self, table: torch.Tensor, count: int):
-        _need_cuda(table)
-        L.check(self.lib.dl_pack_weights_batch(_ptr(table), count, _stream()), 'dl_pack_weights_batch')
+    def pack_batch_run(self, table, count: int):
+        jobs_dev, tab_dev, nblocks = table
+        _need_cuda(jobs_dev, tab_dev)
+        L.check(self.lib.dl_pack_weights_batch(_ptr(jobs_dev), _ptr(tab_dev), nblocks, _stream()), 'dl_pack_weights_batch')
 
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],

@@ -62,7 +62,7 @@ class FlatParams:
         return self.offsets[idx[0]], end
 
 
-_PACK_BATCH = os.environ.get('DL_PACK_BATCH', '0') == '1'
+_PACK_BATCH = os.environ.get('DL_PACK_BATCH', '1') != '0'
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -92,11 +92,12 @@ class FusedAdam(torch.optim.Optimizer):
         ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
                              self.step_count, self.grad_scale)
         self.flat.bump_epoch()         # packed bf16 weight images are stale now (engine.ConvLayer.ensure_packed)
-        # ... optionally rebuild the ones that exist in one launch instead of one launch per image at their next use.
-        # OFF by default (DL_PACK_BATCH=1 enables).  Measured in round 1, profiles/r01/bench_train_kernel_stats_v16_packbatch.csv,
-        # 3 steps x 2 optimizers: the 6 batched launches took 765.7 us each = 4.59 ms; they replaced 645 single-image launches
-        # (940 -> 295) of 6.2 us = 4.0 ms.  A small LOSS: the kernel decodes (div/mod, phase search) per element and stores 2 bytes
-        # per thread, and with 32 blocks per image a launch lasts as long as its largest image (512 x 8192 elements).
+        # ... so rebuild the ones that exist in ONE launch instead of one launch per image at their next use (DL_PACK_BATCH=0
+        # restores the lazy per-image path).  Measured in round 1 (rocprof, 3 steps x 2 optimizers): 6 batched launches x 302 us
+        # = 1.81 ms replace 645 single-image launches x 6.2 us = 4.0 ms, i.e. -0.73 ms/step
+        # (profiles/r01/bench_train_kernel_stats_v17_packbatch.csv).  The first version of the batched kernel -- per-element decode,
+        # 2-byte stores, 32 blocks per image regardless of size -- took 766 us per launch and LOST 0.6 ms per 3 steps
+        # (profiles/r01/bench_train_kernel_stats_v16_packbatch.csv): chunked 16-byte stores and a size-proportional block table fixed it.
         if not _PACK_BATCH:
             return
         if self._pack_batch is None:

@@ -134,14 +134,16 @@ typedef struct dl_pack_desc {
 } dl_pack_desc;
 
 int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *stream);
-/* Batched form for "repack everything after an optimizer step" (hundreds of small images: one launch instead of one each).
+/* Batched form for "repack everything after an optimizer step" (hundreds of images: one launch, work split by image size).
  * A job record is an opaque blob of dl_pack_job_bytes() bytes that dl_pack_job_fill() writes into HOST memory from the same
- * arguments dl_pack_weights takes (device pointers are only recorded, nothing is launched).  The caller copies `count` records,
- * back to back, into device memory once and calls dl_pack_weights_batch after every weight update; the records stay valid as
- * long as the descriptors and the three pointers of each job do. */
+ * arguments dl_pack_weights takes (device pointers are only recorded, nothing is launched).  dl_pack_batch_blocks() turns `count`
+ * back-to-back host records into the workgroup table {job, first 16-byte chunk} (int32 pairs; pass NULL to get the entry count).
+ * The caller copies both tables to device memory once and calls dl_pack_weights_batch after every weight update; they stay valid
+ * as long as the descriptors and the three pointers of each job do.  Results are bit-identical to dl_pack_weights. */
 size_t dl_pack_job_bytes(void);
 int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *job_host);
-int dl_pack_weights_batch(const void *jobs_dev, int count, void *stream);
+int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *block_tab_host);
+int dl_pack_weights_batch(const void *jobs_dev, const int32_t *block_tab_dev, int nblocks, void *stream);
 
 /* Narrow-Cout convolutions (the 7x7 ResnetGenerator head, networks.py:438-443: 64 -> 3 channels): an MFMA tile has at least 16
  * output rows, so Cout = 3 would waste 13/16 of the matrix pipe.  The kernel column is folded into the GEMM rows instead:

@@ -325,7 +325,7 @@ def test_pack_weights_batch_matches_single_packs():
                 jobs.append((batched, w))
                 refs.append(single)
     table = be.pack_batch_build(jobs)
-    assert table.numel() == len(jobs) * int(be.lib.dl_pack_job_bytes())
+    assert table[0].numel() == len(jobs) * int(be.lib.dl_pack_job_bytes()) and table[1].numel() == 2 * table[2] and table[2] >= len(jobs)
     be.pack_batch_run(table, len(jobs))
     sync()
     for (batched, _), single in zip(jobs, refs):

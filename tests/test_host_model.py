@@ -130,7 +130,7 @@ def test_fused_adam_repacks_existing_images_in_one_batch():
     fb = fake_backend.FakeBackend()
     old, old_flag = ops._impl, optim._PACK_BATCH
     ops._impl = fb
-    optim._PACK_BATCH = True            # the hook is opt-in (DL_PACK_BATCH=1) until the batched kernel beats the single launches
+    optim._PACK_BATCH = True            # (the default; DL_PACK_BATCH=0 in the environment would turn the hook off)
     try:
         torch.manual_seed(0)
         net = networks.define_D(6, 8, 'n_layers', n_layers_D=2, norm='instance', init_type='normal', init_gain=0.02, gpu_ids=[])
