@@ -9,8 +9,10 @@ One "step" = model.set_input(batch) + model.optimize_parameters() of the DeepLII
 batch of 8 synthetic 512x512x3 tiles per GPU that is already resident in HBM (BASELINE.json configs[2] per GPU; weak
 scaling).  `--workload infer` times the 9-generator inference DAG of configs[1] instead (4 Resnet-9 + 5 UNet-512, batch 8).
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : dominant kernel = conv_gemm_glds 256x256x64 (3x3, 256->256 ch, 8x128x128 pixels: the 18 ResnetBlock convs and
-                 their data-gradients), per-launch time from HIP events recorded on the launch stream inside the timed region
+  roofline     : dominant layer shape = the 3x3, 256->256 ch conv at 8x128x128 pixels (the 18 ResnetBlock convs of every Resnet-9
+                 and, when training, their data-gradients); the kernel NAME is whatever the library dispatches for that
+                 descriptor (dl_conv_kernel_name), per-launch time from events recorded on the launch stream around the host call
+                 inside the timed region; `traffic` only when the committed PMC summary was collected on that same kernel
   cpu_baseline : the CPU oracle (oracle/deepliif_oracle.py, a port of the reference's PyTorch step) timed on this box's host
                  cores for ONE step at batch 1 (rank 0, N=1 only).
 """
@@ -223,7 +225,7 @@ def main():
     if kt:
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv fwd + dgrad; timed by events around the host call',
+                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload == 'train' else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
         'metric': '512x512 tiles/s train-step (5G+5D)' if args.workload == 'train' else '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)',
@@ -241,6 +243,10 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args)
     else:
         out['cpu_baseline'] = None
+        out['cpu_baseline_note'] = ('disabled by --no-cpu-baseline' if args.no_cpu_baseline else
+                                    'only timed on rank 0 of a 1-GPU run' if world != 1 else
+                                    'the CPU oracle leg is implemented for the train workload only (oracle optimize_parameters); '
+                                    'run the default workload for the CPU baseline')
     if rank == 0:
         sys.stdout = sys.__stdout__
         print(json.dumps(out), flush=True)

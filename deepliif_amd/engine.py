@@ -8,6 +8,7 @@ Precision policies:
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 from dataclasses import dataclass
@@ -84,6 +85,10 @@ def new_act(n, h, w, c, prec: Precision, device, zero=False) -> Act:
     cp = cpad(c)
     t = (torch.zeros if zero else torch.empty)((n, h, w, cp), dtype=prec.dtype, device=device)
     return Act(t, c)
+
+
+# A/B switch (DL_CONV_PREACT=0 disables): apply a conv's input activation in a separate pass so the conv can take the direct-to-LDS path
+_PREACT = os.environ.get('DL_CONV_PREACT', '1') != '0'
 
 
 def empty_like_act(a: torch.Tensor) -> torch.Tensor:
@@ -224,8 +229,17 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
         del T
         nch = 0
     else:
-        nch = be.conv_forward(layer.packed_fwd, x.t, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, in_act,
+        xin, fwd_in_act = x.t, in_act
+        if in_act != L.ACT_NONE and _PREACT and ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16:
+            # The direct-to-LDS conv kernels cannot transform while staging (the DMA bypasses the registers), so a conv with an
+            # input activation falls back to the register-staged kernel.  Materialise in_act(x) once instead (one elementwise
+            # pass over the input) and run the fast kernel on it; backward still masks with the raw x (kept as it is).
+            xin = empty_like_act(x.t)
+            be.act_forward(in_act, x.t, xin)
+            fwd_in_act = L.ACT_NONE
+        nch = be.conv_forward(layer.packed_fwd, xin, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, fwd_in_act,
                               ctx.prec.prec, want_stats=stats and act == L.ACT_NONE)
+        del xin
     y = Act(out, spec.cout, x_needs or w_needs)
     if nch:
         y.stats = (nch, be.norm_ws_token())
