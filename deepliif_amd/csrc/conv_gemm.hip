@@ -279,6 +279,9 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
         if (m >= a.Mtot) continue;
         const int n = m / HWq, rem = m - n * HWq;
         const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        // sub-pixel phases of an odd-sized output (stride-2 data gradient of a 25-row input: phase grid 13 x .., 12 odd rows):
+        // the phase grid is ceil(Ho / out_step) and outputs that fall outside the tensor are dropped
+        if (hq * a.out_step + oh >= a.Ho || wq * a.out_step + ow >= a.Wo) continue;
         const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -344,6 +347,9 @@ __device__ __forceinline__ void glds_epilogue(const ConvArgs &a, f32x4_t (&acc)[
         if (m >= a.Mtot) continue;
         const int n = m / HWq, rem = m - n * HWq;
         const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        // sub-pixel phases of an odd-sized output (stride-2 data gradient of a 25-row input: phase grid 13 x .., 12 odd rows):
+        // the phase grid is ceil(Ho / out_step) and outputs that fall outside the tensor are dropped
+        if (hq * a.out_step + oh >= a.Ho || wq * a.out_step + ow >= a.Wo) continue;
         const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -1167,6 +1173,9 @@ __global__ void __launch_bounds__(512) conv_gemm_p32_kernel(const ConvArgs a) {
         if (m >= a.Mtot) continue;
         const int n = m / HWq, rem = m - n * HWq;
         const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+        // sub-pixel phases of an odd-sized output (stride-2 data gradient of a 25-row input: phase grid 13 x .., 12 odd rows):
+        // the phase grid is ceil(Ho / out_step) and outputs that fall outside the tensor are dropped
+        if (hq * a.out_step + oh >= a.Ho || wq * a.out_step + ow >= a.Wo) continue;
         const size_t opix = ((size_t)n * a.Ho + (hq * a.out_step + oh)) * a.Wo + (wq * a.out_step + ow);
 #pragma unroll
         for (int i = 0; i < 2; ++i)

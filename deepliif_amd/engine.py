@@ -273,8 +273,9 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
         if x_needs:
             dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
             if spec.kind == 'conv' and spec.stride == 2:
-                assert (hi, wi) == (2 * ho, 2 * wo), 'stride-2 data-gradient assumes even input sizes'
-                dq = (ho, wo)
+                # four sub-pixel phases over a ceil(hi/2) x ceil(wi/2) grid; for odd sizes the kernels drop the outputs of the
+                # odd phases that fall outside dx (torch accepts any tile size, so does this path)
+                dq = ((hi + 1) // 2, (wi + 1) // 2)
             else:
                 dq = (hi, wi)
             be.conv_forward(layer.packed_dgrad, g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec)

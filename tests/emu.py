@@ -37,12 +37,16 @@ def emu_gather_gemm(plan: GatherPlan, x: torch.Tensor, W: torch.Tensor, ho: int,
             k0 = plan.kbase[ph] + tl * plan.cc_pad
             Wt = W[:co_pad, k0:k0 + plan.cc_pad]                     # [co][ci]
             for a in range(hq):
+                if a * plan.out_step + oh >= ho:         # odd output size: this phase has one row less than the phase grid
+                    continue
                 hi = a * plan.in_step + dh
                 if plan.pad_mode == L.PAD_REFLECT:
                     hi = _reflect(hi, Hi)
                 elif not (0 <= hi < Hi):
                     continue
                 for b in range(wq):
+                    if b * plan.out_step + ow >= wo:
+                        continue
                     wi = b * plan.in_step + dw
                     if plan.pad_mode == L.PAD_REFLECT:
                         wi = _reflect(wi, Wi)

@@ -95,7 +95,8 @@ class FakeBackend:
                 k0 = plan.kbase[ph] + tl * plan.cc_pad
                 Wt = packed.fake_w[:cop, k0:k0 + plan.cc_pad]
                 g = _gather(xv, hq, wq, plan.in_step, dh, dw, plan.pad_mode == L.PAD_REFLECT)
-                acc[:, oh::plan.out_step, ow::plan.out_step, :][:, :hq, :wq] += g @ Wt.t()
+                dst = acc[:, oh::plan.out_step, ow::plan.out_step, :][:, :hq, :wq]          # odd sizes: an odd phase is one row / column shorter
+                dst += (g @ Wt.t())[:, :dst.shape[1], :dst.shape[2]]
         if bias is not None:
             acc[..., :bias.numel()] += bias.float()
         out.copy_(_act(act, acc).to(out.dtype))

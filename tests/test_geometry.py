@@ -59,17 +59,14 @@ def test_layer_formulas(kind, cin, cout, k, s, p, pm, op, H):
     if pm == L.PAD_ZERO:
         dp = spec.dgrad_plan()
         Wd = emu_pack(dp, w.detach())
-        if kind == 'conv' and s == 2:
-            assert H == 2 * Ho or True
         if kind == 'conv':
-            hq, wq = (H, W_) if s == 1 else (Ho, Wo)
+            # stride 2: four sub-pixel phases over a ceil(H/2) x ceil(W/2) grid; with an odd size the odd phases have one row /
+            # column less and the kernels drop the outputs that fall outside dx (W_ = H + 1 makes one of the two sizes odd)
+            hq, wq = (H, W_) if s == 1 else ((H + 1) // 2, (W_ + 1) // 2)
         else:
             hq, wq = H, W_
-        if kind == 'conv' and s == 2 and (H != 2 * Ho or W_ != 2 * Wo):
-            pass    # odd sizes never occur on the path (512 -> 256 -> ... -> 1); phases assume Hi == 2*Ho
-        else:
-            dx = emu_gather_gemm(dp, to_nhwc(r, cpad(cout)), Wd, H, W_, hq, wq, cpad(cin))
-            assert torch.allclose(from_nhwc(dx, cin), dx_ref, atol=1e-10)
+        dx = emu_gather_gemm(dp, to_nhwc(r, cpad(cout)), Wd, H, W_, hq, wq, cpad(cin))
+        assert torch.allclose(from_nhwc(dx, cin), dx_ref, atol=1e-10)
 
     # ---- weight gradient
     if kind == 'conv':
@@ -79,16 +76,19 @@ def test_layer_formulas(kind, cin, cout, k, s, p, pm, op, H):
     assert torch.allclose(g, dw_ref, atol=1e-10)
 
 
-def test_even_sizes_stride2_dgrad():
-    """the path only ever halves even sizes; check the 4-phase data-gradient on an even grid for both kernel sizes"""
+@pytest.mark.parametrize('hw', [(8, 6), (9, 6), (8, 7), (25, 19), (5, 5), (3, 2)])
+def test_stride2_dgrad_even_and_odd_sizes(hw):
+    """4-phase data-gradient of the stride-2 convs for both kernel sizes, on even grids (the 512-pixel path) and on odd ones
+    (arbitrary tile sizes: torch handles them, so must we)"""
     dt = torch.float64
+    H, W_ = hw
     for k in (3, 4):
         spec = ConvSpec('conv', 8, 16, k, 2, 1)
-        x = torch.randn(1, 8, 8, 6, dtype=dt, requires_grad=True)
+        x = torch.randn(1, 8, H, W_, dtype=dt, requires_grad=True)
         w = torch.randn(16, 8, k, k, dtype=dt)
         y = F.conv2d(x, w, stride=2, padding=1)
         r = torch.randn_like(y)
         dx_ref, = torch.autograd.grad((y * r).sum(), [x])
         dp = spec.dgrad_plan()
-        dx = emu_gather_gemm(dp, to_nhwc(r, 16), emu_pack(dp, w), 8, 6, y.shape[2], y.shape[3], 8)
+        dx = emu_gather_gemm(dp, to_nhwc(r, 16), emu_pack(dp, w), H, W_, (H + 1) // 2, (W_ + 1) // 2, 8)
         assert torch.allclose(from_nhwc(dx, 8), dx_ref, atol=1e-10)

@@ -107,6 +107,9 @@ CONV_CASES = [
     ('convT', 1024, 512, 4, 2, 1, L.PAD_ZERO, 0, 2, 4, 4),
     ('convT', 128, 3, 4, 2, 1, L.PAD_ZERO, 0, 1, 16, 16),
     ('conv', 512, 512, 4, 2, 1, L.PAD_ZERO, 0, 8, 2, 2),      # UNet innermost down: split-K path
+    ('conv', 64, 128, 3, 2, 1, L.PAD_ZERO, 0, 2, 25, 19),     # odd sizes: the stride-2 data gradient has ragged sub-pixel phases
+    ('conv', 6, 64, 4, 2, 1, L.PAD_ZERO, 0, 3, 25, 38),       # PatchGAN first conv on an odd-height tile
+    ('conv', 128, 256, 4, 2, 1, L.PAD_ZERO, 0, 1, 5, 5),      # tiny odd map, split-K
     ('convT', 512, 512, 4, 2, 1, L.PAD_ZERO, 0, 8, 1, 1),     # UNet innermost up
 ]
 
@@ -124,7 +127,7 @@ def _run_conv(be, plan_kind, spec, prec, x, w, bias, act, in_act, H, W_, splitk=
     else:
         ho, wo = H, W_                                  # dx has the layer-input size
         oh, ow = spec.out_hw(H, W_)
-        hq, wq = (oh, ow) if (spec.kind == 'conv' and spec.stride == 2) else (H, W_)
+        hq, wq = ((H + 1) // 2, (W_ + 1) // 2) if (spec.kind == 'conv' and spec.stride == 2) else (H, W_)     # ceil: odd sizes
         cop = cpad(spec.cin)
     out = torch.empty((n, ho, wo, cop), dtype=prec.dtype, device=dev)
     be.conv_forward(packed, x, out, hq, wq, bias, act, in_act, prec.prec, splitk)
@@ -154,8 +157,6 @@ def test_conv_forward_and_dgrad(case, precname):
     assert rel(got2, exp) < tol(prec), 'splitk'
     if pm == L.PAD_ZERO:
         ho, wo = spec.out_hw(H, W_)
-        if kind == 'conv' and s == 2 and (H != 2 * ho or W_ != 2 * wo):
-            return
         dy = torch.zeros(N, ho, wo, cpad(cout))
         dy[..., :cout] = rnd((N, ho, wo, cout), 4, prec)
         exp = _run_conv(fake, 'dgrad', spec, prec, dy.to(prec.dtype), w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
@@ -263,6 +264,8 @@ BIG_CASES = [
     ('conv', 192, 256, 3, 1, 1, 4, 128, 128),        # Cin padded to 256 (zero channels), 36 steps
     ('conv', 64, 256, 3, 1, 1, 16, 64, 128),         # kernel-column reuse with ONE channel chunk per tap (9 steps), 64-row images
     ('conv', 128, 256, 3, 1, 1, 4, 128, 256),        # 256-pixel rows: no kernel-column reuse
+    ('conv', 256, 256, 3, 1, 1, 5, 120, 136),        # ragged: 81 600 pixels = 318.75 tiles (masked last tile), 16 320-pixel images
+                                                     # are not a multiple of the 256-pixel tile, so tiles straddle two images
 ]
 
 
@@ -332,6 +335,30 @@ def test_pack_weights_batch_matches_single_packs():
         assert torch.equal(batched.hi.view(torch.int16), single.hi.view(torch.int16))
         if single.lo is not None:
             assert torch.equal(batched.lo.view(torch.int16), single.lo.view(torch.int16))
+
+
+def test_wgrad_fast_path_ragged_pixels():
+    """direct-to-LDS weight gradient (bf16, 256 -> 256, 3x3) over a pixel count that is neither a multiple of the 64-pixel K step
+    nor of the split-K chunk, with tiles straddling images: 5 x 120 x 136 = 81 600 pixels.  Also with every env-selectable
+    block order (default XCD grouping is what the training step uses)."""
+    prec = Precision.get('bf16')
+    N, H, W_, C = 5, 120, 136, 256
+    x = rnd((N, H, W_, C), 5, prec).to(prec.dtype)
+    dy = rnd((N, H, W_, C), 6, prec).to(prec.dtype)
+    fake, real = fake_backend.FakeBackend(), hip()
+    g_exp = torch.zeros(C, C, 3, 3)
+    fake.conv_wgrad(dy, x, g_exp, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False)
+    first = None
+    for sk in (None, 1, 7):
+        g = torch.empty(C, C, 3, 3, device=DEV)
+        real.conv_wgrad(dy.to(DEV), x.to(DEV), g, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, splitk=sk)
+        sync()
+        assert rel(g, g_exp) < 1e-3, ('splitk', sk)
+        if sk is None:
+            g2 = torch.empty_like(g)
+            real.conv_wgrad(dy.to(DEV), x.to(DEV), g2, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, splitk=sk)
+            sync()
+            assert torch.equal(g, g2), 'run-to-run difference (fixed-order reduction expected)'
 
 
 STATS_CASES = [

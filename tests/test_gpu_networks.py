@@ -83,6 +83,8 @@ CASES = [
     ('resnet_9blocks', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
     ('resnet_9blocks', 3, 16, 'instance', 'zero', (2, 3, 64, 48)),
     ('resnet_2blocks', 3, 8, 'batch', 'reflect', (1, 3, 32, 32)),
+    ('resnet_9blocks', 3, 8, 'instance', 'zero', (1, 3, 72, 104)),      # batch 1, H != W, not a multiple of any tile size
+    ('n_layers', 6, 8, 'instance', 'zero', (3, 6, 100, 76)),           # odd batch, sizes that leave odd feature maps in the PatchGAN
     ('unet_32', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
     ('unet_64', 9, 8, 'instance', 'zero', (1, 9, 64, 64)),
     ('unet_512', 3, 8, 'batch', 'zero', (1, 3, 512, 512)),

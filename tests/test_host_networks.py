@@ -34,6 +34,8 @@ CASES = [
     ('unet_64', 3, 8, 'batch', 'zero', (1, 3, 64, 64)),
     ('n_layers', 6, 8, 'batch', 'zero', (2, 6, 64, 64)),
     ('n_layers', 12, 8, 'instance', 'zero', (1, 12, 64, 64)),
+    ('n_layers', 6, 8, 'instance', 'zero', (3, 6, 100, 76)),       # 100 -> 50 -> 25 -> 12: an odd map in front of a stride-2 conv
+    ('resnet_9blocks', 3, 8, 'instance', 'zero', (1, 3, 36, 52)),   # batch 1, H != W
 ]
 
 
