@@ -1454,7 +1454,11 @@ extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
 extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
                                void *out, float *slab, float *stats_part, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!d || !in || !w_hi || (!out && !d->raw_out)) DL_FAIL("dl_conv_forward: null argument");
+    if (!d) DL_FAIL("dl_conv_forward: null descriptor");
+    if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hq <= 0 || d->Wq <= 0)
+        DL_FAIL("dl_conv_forward: empty problem (N=%d, in %dx%d, out %dx%d, phase grid %dx%d): nothing to launch", d->N, d->Hi, d->Wi, d->Ho,
+                d->Wo, d->Hq, d->Wq);
+    if (!in || !w_hi || (!out && !d->raw_out)) DL_FAIL("dl_conv_forward: null argument");
     const int l2 = ilog2_exact(d->Ci);
     if (l2 < 3) DL_FAIL("dl_conv_forward: Ci=%d must be a power of two >= 8", d->Ci);
     if (d->Co % 8 || d->Co <= 0) DL_FAIL("dl_conv_forward: Co=%d must be a positive multiple of 8", d->Co);

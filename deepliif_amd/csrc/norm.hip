@@ -353,6 +353,7 @@ static dim3 apply_grid(const NormGeom &g) {
 
 static int check_desc(const dl_norm_desc *d, const char *who) {
     if (!d) DL_FAIL("%s: null desc", who);
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) DL_FAIL("%s: empty problem (N=%d, %dx%d): nothing to launch", who, d->N, d->H, d->W);
     if (d->Cp % 8 || d->Cp <= 0 || d->C > d->Cp) DL_FAIL("%s: Cp=%d C=%d", who, d->Cp, d->C);
     if (d->y_pstride % 8 || d->z_pstride % 8 || (d->r_pstride % 8)) DL_FAIL("%s: pixel strides must be multiples of 8", who);
     if (d->dtype != DL_F32 && d->dtype != DL_BF16) DL_FAIL("%s: dtype %d", who, d->dtype);

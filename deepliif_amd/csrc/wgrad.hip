@@ -495,7 +495,10 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 
 extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!d || !P || !Q || !grad || !slab) DL_FAIL("dl_conv_wgrad: null argument");
+    if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
+    if (d->N <= 0 || d->Hp <= 0 || d->Wp <= 0 || d->Hq <= 0 || d->Wq <= 0)
+        DL_FAIL("dl_conv_wgrad: empty problem (N=%d, P %dx%d, Q %dx%d): nothing to launch", d->N, d->Hp, d->Wp, d->Hq, d->Wq);
+    if (!P || !Q || !grad || !slab) DL_FAIL("dl_conv_wgrad: null argument");
     const int l2 = ilog2_exact(d->CBp);
     if (l2 < 3) DL_FAIL("dl_conv_wgrad: CBp=%d must be a power of two >= 8", d->CBp);
     if (d->CAp % 8) DL_FAIL("dl_conv_wgrad: CAp=%d must be a multiple of 8", d->CAp);

@@ -6,6 +6,8 @@
  * call site (paths relative to /root/reference).  Everything is `extern "C"`, plain pointers and sizes, caller-owned
  * device memory, an explicit hipStream_t (passed as void*), no hidden global stream, no allocation, thread-safe.
  * Return value: 0 = ok, negative = error (message via dl_last_error(), thread-local).
+ * Arguments are validated on the host before anything is launched; an empty problem (N = 0 or a zero-sized image) is an error
+ * ("empty problem ..."), not a no-op: the reference never produces one and a silent success would hide a caller bug.
  *
  * Data layout (engine-internal; the host side converts at the seam):
  *   activations  NHWC, channel count padded to a power of two >= 8 ("Cp"), element type bf16 (DL_BF16) or fp32 (DL_F32);

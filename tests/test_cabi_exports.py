@@ -2,6 +2,8 @@
 GPU), and the ctypes structure mirrors must have the C structs' sizes."""
 import ctypes
 import os
+
+import pytest
 import re
 import subprocess
 
@@ -52,3 +54,27 @@ def test_product_has_no_cpu_fallback():
     for fn in os.listdir(pkg):
         if fn.endswith('.py'):
             assert 'oracle' not in open(os.path.join(pkg, fn)).read().replace('the oracle', ''), fn
+
+
+def test_empty_problems_are_rejected_before_any_launch():
+    """N = 0 (or a zero-sized image) is an error with a message that says so -- decided on the host before the device is touched,
+    so this runs without a GPU (the pointers below are never dereferenced)."""
+    import ctypes as C
+    from deepliif_amd import _lib as L
+    lib = L.load()
+    dummy = C.c_void_p(0x1000)
+    d = L.ConvDesc()
+    d.N, d.Hi, d.Wi, d.Ci, d.in_pstride = 0, 32, 32, 8, 8
+    d.Ho, d.Wo, d.Co, d.out_pstride, d.Hq, d.Wq = 32, 32, 8, 8, 32, 32
+    d.n_phase, d.splitk = 1, 1
+    assert lib.dl_conv_forward(C.byref(d), dummy, dummy, None, None, dummy, None, None, None) != 0
+    assert b'empty problem' in lib.dl_last_error()
+    with pytest.raises(L.HipLibraryError, match='empty problem'):
+        L.check(lib.dl_conv_forward(C.byref(d), None, dummy, None, None, None, None, None, None), 'dl_conv_forward')      # as torch hands over an empty tensor
+    w = L.WgradDesc()
+    w.N, w.Hp, w.Wp, w.CAp, w.Hq, w.Wq, w.CBp, w.splitk = 2, 0, 16, 8, 16, 16, 8, 1
+    assert lib.dl_conv_wgrad(C.byref(w), dummy, dummy, dummy, dummy, None) != 0 and b'empty problem' in lib.dl_last_error()
+    n = L.NormDesc()
+    n.N, n.H, n.W, n.Cp, n.C = 0, 8, 8, 8, 8
+    assert lib.dl_norm_forward(C.byref(n), dummy, None, None, None, None, dummy, dummy, dummy, dummy, None, dummy, dummy, None) != 0
+    assert b'empty problem' in lib.dl_last_error()
