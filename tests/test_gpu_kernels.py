@@ -225,7 +225,9 @@ def test_norm_forward_backward(shape, C, scope, precname):
     gamma = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(4))) if affine else None
     beta = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(5))) if affine else None
     fake, real = fake_backend.FakeBackend(), hip()
-    for act, use_res in ((L.ACT_RELU, False), (L.ACT_NONE, True), (L.ACT_LRELU, False)):
+    # every activation the C ABI accepts is its own kernel instantiation (tanh never follows a norm in the reference networks,
+    # but dl_norm_desc.act allows it)
+    for act, use_res in ((L.ACT_RELU, False), (L.ACT_NONE, True), (L.ACT_LRELU, False), (L.ACT_TANH, True)):
         rm_f, rv_f = (torch.zeros(C), torch.ones(C)) if affine else (None, None)
         rm_r, rv_r = (torch.zeros(C, device=DEV), torch.ones(C, device=DEV)) if affine else (None, None)
         z_f = torch.empty(shape, dtype=prec.dtype)
