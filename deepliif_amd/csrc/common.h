@@ -28,18 +28,30 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
 #endif
     return f;
 }
-__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u;
+// Device code converts with the native gfx950 instruction (v_cvt_pk_bf16_f32: round to nearest even, ONE VALU op per pair); the
+// integer emulation below (5-7 ops per pair, a dependent chain) is what every bf16 store used to pay -- the PMC passes of round 1
+// showed the norm apply kernels waiting on instruction issue for ~46 % of their wave cycles.  Identical results for finite values.
 #if defined(__HIP_DEVICE_COMPILE__)
-    u = __float_as_uint(f);
-#else
-    memcpy(&u, &f, 4);
+typedef __bf16 dl_bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float dl_f32x2_native __attribute__((ext_vector_type(2)));
 #endif
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const dl_f32x2_native f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, dl_bf16x2_native));
+#else
+    return 0;
+#endif
+}
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu);
+#else
+    uint32_t u;
+    memcpy(&u, &f, 4);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
 }
 
 // ---- 8-element vector load/store of an activation row chunk, as fp32 registers

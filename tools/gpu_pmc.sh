@@ -4,10 +4,10 @@ which=$1; tag=$2
 mkdir -p gpurun_out/pmc_$tag
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p1 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_UNALIGNED_STALL -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p2 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p3 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p4 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
+timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p1 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
+timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_UNALIGNED_STALL -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p2 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
+timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p3 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
+timeout 120 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag/p4 -o p -- python $GRAFT_REPO_ROOT/tools/conv_only.py $which > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, collections, glob
