@@ -411,6 +411,8 @@ class DeepLIIFExtModel(BaseModel):
     (netG[i], loss_G_GAN[i], ...), model names 'G_1', 'GS_1', ...  Quirks kept: the generator-side seg GAN loss uses
     criterionGAN_mod (:236), seg loss weights are 1/M (:27,30), no VGG term."""
 
+    _extra_g_loss_names = ()         # subclasses add per-modality generator loss names the reference reports (SDG: G_VGG)
+
     def __init__(self, opt):
         super().__init__(opt)
         M = self.mod_gen_no = opt.modalities_no
@@ -422,7 +424,7 @@ class DeepLIIFExtModel(BaseModel):
         seg = opt.seg_gen
         self.loss_names, self.visual_names = [], ['real_A']
         for i in range(1, M + 1):
-            self.loss_names += [f'G_GAN_{i}', f'G_L1_{i}', f'D_real_{i}', f'D_fake_{i}']
+            self.loss_names += [f'G_GAN_{i}', f'G_L1_{i}'] + [f'{x}_{i}' for x in self._extra_g_loss_names] + [f'D_real_{i}', f'D_fake_{i}']
             self.visual_names += [f'fake_B_{i}', f'real_B_{i}']
         if seg:
             for i in range(1, M + 1):
@@ -583,6 +585,10 @@ class SDGModel(DeepLIIFExtModel):
     """deepliif/models/SDG_model.py: DeepLIIFExt's translation branch only, with `input_no` input modalities concatenated on the
     channel axis (generators take input_nc*input_no channels, discriminators input_nc*input_no + output_nc).  The reference adds
     a VGG19 perceptual term (SDG_model.py:176-184); like for DeepLIIF it is outside the MI355X hot path (SURVEY 0 #4)."""
+
+    # SDG_model.py:33 lists a VGG19 term per modality; it is not computed on this path and is reported as 0.0 so that
+    # loss_names / get_current_losses() have the reference's keys in the reference's order
+    _extra_g_loss_names = ('G_VGG',)
 
     def __init__(self, opt):
         opt.seg_gen = False

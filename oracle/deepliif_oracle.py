@@ -587,3 +587,26 @@ class OracleDeepLIIFExt:
 
     def current_losses(self):
         return OrderedDict((k, float(v.detach())) for k, v in self.losses.items())
+
+
+class OracleSDG(OracleDeepLIIFExt):
+    """Functional SDGModel (deepliif/models/SDG_model.py): DeepLIIFExt's translation branch only.  `input['A']` is a LIST of
+    input_no modalities concatenated on the channel axis (set_input, SDG_model.py:108-112), so generators take
+    input_nc*input_no channels (:59-60) and discriminators input_nc*input_no + output_nc (:66-68); forward / backward_D /
+    backward_G (:126-183) are the Ext ones without the seg branch.  The reference also lists a VGG19 term per modality
+    (loss_names 'G_VGG_i', :33, :173-175): it is outside this path (zeroed when the fixtures are generated) and is
+    reported as 0 so that the loss_names of the seam are complete."""
+
+    def __init__(self, cfg: OracleConfig, nets: Dict[str, Dict[str, torch.Tensor]], train_bn_running: bool = True):
+        assert not cfg.seg_gen, 'SDG has no segmentation branch'
+        super().__init__(cfg, nets, train_bn_running)
+
+    def set_input(self, batch):
+        A = batch['A']
+        super().set_input({'A': torch.cat(list(A), 1) if isinstance(A, (list, tuple)) else A, 'B': batch['B']})
+
+    def current_losses(self):
+        out = super().current_losses()
+        for i in range(self.cfg.modalities_no):
+            out[f'G_VGG_{i + 1}'] = 0.0
+        return out

@@ -194,6 +194,45 @@ def make_step(tag, modalities_no, seg_gen, norm, padding, net_gs, size, nf=8, ba
     print(f'step_{tag}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def make_step_sdg(tag, modalities_no, input_no, norm, size, nf=8, batch=1, steps=2):
+    """SDGModel trajectory (SDG_model.py): input_no modalities concatenated on the channel axis, one translation generator +
+    discriminator per output modality, GAN + SmoothL1 (+ VGG, zeroed by _ref_import like everywhere else)."""
+    out = {}
+    p = base_params(modalities_no, False, norm, 'zero', 'unet_64', nf)
+    p.update(model='SDG', input_no=input_no, seg_weights=[1.0 / modalities_no] * modalities_no, lambda_feat=100.0,
+             loss_G_weights=[1.0 / modalities_no] * modalities_no, loss_D_weights=[1.0 / modalities_no] * modalities_no)
+    opt = Options(d_params=p)
+    from deepliif.models.SDG_model import SDGModel
+    model = SDGModel(opt)
+    model.setup(opt)
+    seeds = {}
+    for j, n in enumerate(model.model_names):
+        kind, idx = n.split('_')
+        net = getattr(model, 'net' + kind)[int(idx) - 1]
+        arch, cin, pad = {'G': ('resnet_9blocks', 3 * input_no, 'zero'), 'D': ('n_layers', 3 * input_no + 3, 'zero')}[kind]
+        load_seeded(net, arch, cin, nf, norm, pad, 1300 + j)
+        seeds[n] = 1300 + j
+    A = [seeded_uniform((batch, 3, size, size), 22 + 100 * k) for k in range(input_no)]
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(modalities_no)]
+    out['meta'] = np.array([str(modalities_no), str(input_no), norm, str(size), str(nf), str(batch), str(steps)])
+    out['model_names'] = np.array(model.model_names)
+    out['net_seeds'] = np.array([seeds[n] for n in model.model_names])
+    out['loss_names'] = np.array(model.loss_names)
+    for s in range(steps):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        losses = model.get_current_losses()
+        out[f'step{s}/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+        for i in range(modalities_no):
+            out[f'step{s}/fake_B_{i + 1}'] = model.fake_B[i].detach().numpy()[:, :, ::2, ::2]
+        for n in model.model_names:
+            kind, idx = n.split('_')
+            sd = getattr(model, 'net' + kind)[int(idx) - 1].state_dict()
+            out[f'step{s}/w_digest/{n}'] = digest(torch.cat([v.reshape(-1).float() for v in sd.values() if v.is_floating_point()]))
+    np.savez_compressed(os.path.join(HERE, f'step_sdg_{tag}.npz'), **out)
+    print(f'step_sdg_{tag}.npz', out['loss_names'])
+
+
 def make_step_ext(tag, modalities_no, norm, size, nf=8, batch=1, steps=2):
     """DeepLIIFExtModel trajectory (DeepLIIFExt_model.py): list-valued nets, GS input 9 ch, DS input 12 ch."""
     out = {}
@@ -269,6 +308,9 @@ def make_inference():
 
 if __name__ == '__main__':
     os.makedirs('/tmp/golden_ckpt/golden', exist_ok=True)
+    if sys.argv[1:] == ['sdg']:             # regenerate only the SDG trajectory (the other fixtures are left as committed)
+        make_step_sdg('m2_in2_instance', 2, 2, 'instance', 64)
+        sys.exit(0)
     make_nets_small()
     make_unet512()
     make_seeded_init()
@@ -278,3 +320,4 @@ if __name__ == '__main__':
     make_step('m2_seg_instance_reflect', 2, True, 'instance', 'reflect', 'unet_64', 64, batch=1)
     make_inference()
     make_step_ext('m2_batch', 2, 'batch', 64)
+    make_step_sdg('m2_in2_instance', 2, 2, 'instance', 64)

@@ -293,3 +293,38 @@ def test_deepliif_ext_step_golden_fixture_from_reference(precname):
                 e = rel(t[:, :, ::2, ::2], torch.from_numpy(z[f'step{s}/{fam}_{i + 1}']))
                 ERRLOG[f'step_ext/{precname}/s{s}/{fam}_{i + 1}'] = e
                 assert e < otol[min(s, 1)]
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_sdg_step_golden_fixture_from_reference(precname):
+    """SDGModel (input modalities concatenated: 6-channel generators, 9-channel discriminators) against the reference trajectory,
+    including the reference's loss_names (G_VGG_i reported as 0: the VGG term is outside this path and was zeroed in the fixture)."""
+    z = np.load(os.path.join(G, 'step_sdg_m2_in2_instance.npz'))
+    Mn, input_no, norm, size, nf, batch, steps = z['meta']
+    Mn, input_no, size, nf, batch = int(Mn), int(input_no), int(size), int(nf), int(batch)
+    opt = make_opt(Mn, False, norm, 'unet_64', nf, precname)
+    opt.model, opt.input_no = 'SDG', input_no
+    opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [1.0 / Mn] * Mn
+    model = M.create_model(opt)
+    model.setup(opt)
+    assert list(model.loss_names) == [str(n) for n in z['loss_names']]
+    spec = {'G': ('resnet_9blocks', 3 * input_no, 'zero'), 'D': ('n_layers', 3 * input_no + 3, 'zero')}
+    for name, seed in zip(z['model_names'], z['net_seeds']):
+        arch, cin, pad = spec[str(name).split('_')[0]]
+        model._net(str(name)).load_state_dict(O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(int(seed))))
+    A = [seeded_uniform((batch, 3, size, size), 22 + 100 * k) for k in range(input_no)]
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(Mn)]
+    ltol = {'fp32': (1e-3, 5e-3), 'bf16': (3e-2, 6e-2)}[precname]
+    otol = {'fp32': (1e-3, 8e-2), 'bf16': (6e-2, 3e-1)}[precname]
+    for s in range(int(steps)):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        for name, exp in zip(z['loss_names'], z[f'step{s}/losses']):
+            err = abs(got[str(name)] - exp) / max(1.0, abs(exp))
+            ERRLOG[f'step_sdg/{precname}/s{s}/{name}'] = err
+            assert err <= ltol[min(s, 1)], (s, name, got[str(name)], exp)
+        for i in range(Mn):
+            e = rel(model.fake_B[i][:, :, ::2, ::2], torch.from_numpy(z[f'step{s}/fake_B_{i + 1}']))
+            ERRLOG[f'step_sdg/{precname}/s{s}/fake_B_{i + 1}'] = e
+            assert e < otol[min(s, 1)]

@@ -1,9 +1,11 @@
 """Host logic of the DeepLIIFModel drop-in (deepliif_amd/models.py) on CPU with the emulated ops backend: the two-step
 optimize_parameters() trajectory must follow the oracle (which is pinned to the reference by tests/test_oracle_golden.py) --
 losses, generated images and updated weights -- for the translation-only and the full seg-generator graphs."""
+import os
 import types
 
 import pytest
+import numpy as np
 import torch
 
 import fake_backend
@@ -120,6 +122,45 @@ def test_deepliif_ext_two_steps_follow_oracle():
         for i in range(2):
             for a, b in ((model.fake_B[i], om.fake_B[i].detach()), (model.fake_BS[i], om.fake_BS[i].detach())):
                 assert float((a - b).abs().max() / b.abs().max()) < (5e-4 if step == 0 else 3e-2)
+
+
+class CpuSDGModel(M.SDGModel):
+    def _device_from_opt(self, opt):
+        return torch.device('cpu')
+
+    def _net_gpu_ids(self):
+        return []
+
+
+def test_sdg_two_steps_follow_oracle_and_reference_loss_names():
+    torch.manual_seed(0)
+    opt = make_opt(2, False, 'instance')
+    opt.model, opt.input_no = 'SDG', 2
+    opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
+    model = CpuSDGModel(opt)
+    model.setup(opt)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'step_sdg_m2_in2_instance.npz'))
+    assert list(model.loss_names) == [str(n) for n in z['loss_names']], 'loss_names of the reference SDGModel, in its order'
+    assert [n for n in model.model_names] == [str(n) for n in z['model_names']]
+    cfg = O.OracleConfig(modalities_no=2, seg_gen=False, norm='instance', padding='zero', ngf=8, ndf=8,
+                         loss_G_weights=[0.5, 0.5], loss_D_weights=[0.5, 0.5])
+    nets = {n: {k: v.detach().clone() for k, v in net.state_dict().items()} for n, net in model._nets()}
+    assert nets['G_1']['model.1.weight'].shape[1] == 6 and nets['D_1']['model.0.weight'].shape[1] == 9      # input_nc * input_no (+ output_nc)
+    om = O.OracleSDG(cfg, nets)
+    A = [seeded_uniform((1, 3, 64, 64), 22 + 100 * k) for k in range(2)]
+    B = [seeded_uniform((1, 3, 64, 64), 23 + i) for i in range(2)]
+    for step in range(2):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        om.set_input({'A': A, 'B': B})
+        om.optimize_parameters()
+        got, exp = model.get_current_losses(), om.current_losses()
+        tol = 5e-4 if step == 0 else 5e-3
+        for k, v in got.items():
+            assert abs(v - exp[k]) <= tol * max(1.0, abs(exp[k])), (step, k, v, exp[k])
+        for i in range(2):
+            a, b = model.fake_B[i], om.fake_B[i].detach()
+            assert float((a - b).abs().max() / b.abs().max()) < (5e-4 if step == 0 else 3e-2)
 
 
 def test_fused_adam_repacks_existing_images_in_one_batch():

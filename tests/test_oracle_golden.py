@@ -187,3 +187,35 @@ def test_deepliif_ext_two_step_trajectory():
             flat = torch.cat([v.detach().reshape(-1).float() for v in nets[str(n)].values() if v.is_floating_point()])
             ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
             assert ok, f'step {s} weights of {n}: {msg}'
+
+
+def test_sdg_two_step_trajectory():
+    """SDGModel (SDG_model.py): two input modalities concatenated on the channel axis -> 6-channel generators, 9-channel
+    discriminators; the reference's loss_names (with the zeroed G_VGG_i) and 2-step trajectory."""
+    z = np.load(os.path.join(G, 'step_sdg_m2_in2_instance.npz'))
+    M, input_no, norm, size, nf, batch, steps = z['meta']
+    M, input_no, size, nf, batch = int(M), int(input_no), int(size), int(nf), int(batch)
+    cfg = O.OracleConfig(modalities_no=M, seg_gen=False, norm=norm, padding='zero', ngf=nf, ndf=nf,
+                         loss_G_weights=[1.0 / M] * M, loss_D_weights=[1.0 / M] * M)
+    spec = {'G': ('resnet_9blocks', 3 * input_no, 'zero'), 'D': ('n_layers', 3 * input_no + 3, 'zero')}
+    nets = {}
+    for name, seed in zip(z['model_names'], z['net_seeds']):
+        arch, cin, pad = spec[str(name).split('_')[0]]
+        nets[str(name)] = O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(int(seed)))
+    om = O.OracleSDG(cfg, nets)
+    A = [seeded_uniform((batch, 3, size, size), 22 + 100 * k) for k in range(input_no)]
+    B = [seeded_uniform((batch, 3, size, size), 23 + i) for i in range(M)]
+    for s in range(int(steps)):
+        om.set_input({'A': A, 'B': B})
+        om.optimize_parameters()
+        got = om.current_losses()
+        assert set(got) == {str(n) for n in z['loss_names']}, 'loss names of the seam'
+        tol = 2e-4 if s == 0 else 3e-3
+        for name, exp in zip(z['loss_names'], z[f'step{s}/losses']):
+            assert abs(got[str(name)] - exp) <= tol * max(1.0, abs(exp)), (s, name, got[str(name)], exp)
+        for i in range(M):
+            assert rel_err(om.fake_B[i].detach()[:, :, ::2, ::2], z[f'step{s}/fake_B_{i + 1}']) < (tol if s == 0 else 2e-2)
+        for n in z['model_names']:
+            flat = torch.cat([v.detach().reshape(-1).float() for v in nets[str(n)].values() if v.is_floating_point()])
+            ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
+            assert ok, f'step {s} weights of {n}: {msg}'
