@@ -30,20 +30,23 @@ sys.path.insert(0, ROOT)
 
 GF_PER_TILE_TRAIN_5R5D = 6817.0      # BASELINE.md / SURVEY 8(d): conv MACs only, FLOP = 2*MAC
 GF_PER_TILE_INFER = 1828.0
+GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 + 5 UNet-512 generators, 9 NLayerD) step
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
-def make_opt(args, device_index):
-    M = 5
+def make_opt(args, device_index, M=5, seg_gen=False):
     w = [1.0 / (M + 1)] * (M + 1)      # cli.py:349-371 defaults for modalities_no != 4
+    lw = w
+    if M == 4:                         # the real DeepLIIF defaults (cli.py:349-371)
+        w, lw = [0.25, 0.15, 0.25, 0.1, 0.25], [0.2] * 5
     return types.SimpleNamespace(
         model='DeepLIIF', name='bench', checkpoints_dir='/tmp/dl_amd_bench', gpu_ids=[device_index], is_train=True, phase='train',
-        continue_train=False, modalities_no=M, seg_gen=False, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=64, ndf=64,
+        continue_train=False, modalities_no=M, seg_gen=seg_gen, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=64, ndf=64,
         net_g='resnet_9blocks', net_gs='unet_512', net_d='n_layers', n_layers_D=4, norm=args.norm, no_dropout=True, init_type='normal',
         init_gain=0.02, padding='zero', upsample='convtranspose', gan_mode='vanilla', gan_mode_s='lsgan', optimizer='adam', lr_g=2e-4,
-        lr_d=2e-4, beta1=0.5, lr_policy='linear', n_epochs=100, n_epochs_decay=100, epoch_count=0, seg_weights=w, loss_G_weights=w,
-        loss_D_weights=w, lambda_L1=100.0, verbose=False, epoch='latest', load_iter=0, precision=args.precision)
+        lr_d=2e-4, beta1=0.5, lr_policy='linear', n_epochs=100, n_epochs_decay=100, epoch_count=0, seg_weights=w, loss_G_weights=lw,
+        loss_D_weights=lw, lambda_L1=100.0, verbose=False, epoch='latest', load_iter=0, precision=args.precision)
 
 
 class KernelTimer:
@@ -141,7 +144,9 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp32_bf16mma'])
     ap.add_argument('--norm', default='instance', choices=['instance', 'batch'])
-    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--workload', default='train', choices=['train', 'train18', 'infer'],
+                    help="train = BASELINE's 5G+5D step (the contract line); train18 = the real DeepLIIF configuration (modalities_no=4, seg_gen: "
+                         '4 Resnet-9 + 5 UNet-512 generators + 9 discriminators, SURVEY 8d); infer = configs[1]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -176,6 +181,19 @@ def main():
         gf_per_tile = GF_PER_TILE_TRAIN_5R5D
         dom_shape = (n, s // 4, s // 4, 256)
         workload = 'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
+    elif args.workload == 'train18':
+        opt = make_opt(args, local_rank, M=4, seg_gen=True)
+        model = M.create_model(opt)
+        model.setup(opt)
+        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}      # 4 modalities + seg target
+
+        def step():
+            model.set_input(batch)
+            model.optimize_parameters()
+        gf_per_tile = GF_PER_TILE_TRAIN_18NETS
+        dom_shape = (n, s // 4, s // 4, 256)
+        workload = ('real DeepLIIF train step (modalities_no=4, seg_gen=True): 4x Resnet-9block + 5x UNet-512 generators, 4 + 5 NLayerD(n=4), '
+                    'GAN/LSGAN+SmoothL1+Adam (SURVEY 8d)')
     else:
         from deepliif_amd import inference as I
         iopt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3,
@@ -229,10 +247,11 @@ def main():
     if kt:
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload == 'train' else 'fwd only') + '; timed by events around the host call',
+                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload != 'infer' else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
-        'metric': '512x512 tiles/s train-step (5G+5D)' if args.workload == 'train' else '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)',
+        'metric': {'train': '512x512 tiles/s train-step (5G+5D)', 'train18': '512x512 tiles/s train-step (real DeepLIIF: 9 G + 9 D)',
+                   'infer': '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)'}[args.workload],
         'value': round(value, 3), 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else ('f32(split-bf16x3 MFMA)' if args.precision == 'fp32' else 'f32 storage/bf16 MFMA'),

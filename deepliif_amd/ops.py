@@ -13,6 +13,8 @@ exercise the host logic without a GPU (tests/fake_backend.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 from typing import Optional
 
 import torch
@@ -36,19 +38,41 @@ def pstride(t: torch.Tensor) -> int:
     return ps
 
 
+_SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
+_SHARED_STATE: dict = {}
+
+
 class Workspace:
-    """Grow-only fp32 scratch buffers, one per purpose.  All kernels run in stream order on one stream, so a buffer can be
-    reused by the next call of the same kind."""
+    """Grow-only fp32 scratch buffers, one per purpose AND PER THREAD.  Within a thread all kernels run in stream order, so a buffer
+    can be reused by the next call of the same kind.  Across threads nothing may be shared: one C call launches e.g. the split-K conv
+    and then its slab reduction, and another thread (the reference drives different nets from dask worker threads,
+    deepliif/models/__init__.py:283-334; ctypes releases the GIL) could launch its own conv into the same slab in between."""
 
     def __init__(self):
-        self.bufs = {}
+        self._tls = threading.local()
+
+    def _state(self):
+        # DL_SHARED_SCRATCH=1 restores the process-wide buffers: ONLY for demonstrating the hazard (tests/test_gpu_networks.py,
+        # test_inference_seam_is_thread_safe fails with it)
+        st = _SHARED_STATE if _SHARED_SCRATCH else self._tls.__dict__
+        if 'bufs' not in st:
+            st['bufs'], st['norm_ws_token'] = {}, 0
+        return st
 
     def get(self, name: str, nfloats: int, device) -> torch.Tensor:
-        b = self.bufs.get(name)
+        bufs = self._state()['bufs']
+        b = bufs.get(name)
         if b is None or b.numel() < nfloats or b.device != device:
             b = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
-            self.bufs[name] = b
+            bufs[name] = b
         return b
+
+    # the 'norm_ws' buffer carries conv-epilogue statistics to the following norm: a per-thread token says whether they are still there
+    def norm_token(self) -> int:
+        return self._state()['norm_ws_token']
+
+    def bump_norm_token(self):
+        self._state()['norm_ws_token'] += 1
 
 
 WS = Workspace()
@@ -82,11 +106,10 @@ class HipBackend:
 
     def __init__(self):
         self.lib = L.load()
-        self._norm_ws_token = 0          # bumped whenever the shared 'norm_ws' workspace is overwritten
         self.last_conv_kernel = ''
 
     def norm_ws_token(self) -> int:
-        return self._norm_ws_token
+        return WS.norm_token()           # bumped whenever this thread's 'norm_ws' workspace is overwritten
 
     # ---- weights
     def pack_weights(self, packed: PackedWeights, src: torch.Tensor):
@@ -156,7 +179,7 @@ class HipBackend:
                 nd = self._norm_desc(out, cop, L.NORM_BATCH, L.ACT_NONE, -1.0, 8, 8)     # only N/H/W/Cp matter for the size
                 nd.ext_nchunks = nch
                 part = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(nd)), x.device)
-                self._norm_ws_token += 1
+                WS.bump_norm_token()
         L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
                                          _ptr(part), _stream()), 'dl_conv_forward')
         return nch
@@ -204,7 +227,7 @@ class HipBackend:
         d = self._norm_desc(y, C_real, scope, act, momentum, pstride(z), pstride(residual) if residual is not None else 8)
         d.ext_nchunks = ext_nchunks
         if not ext_nchunks:
-            self._norm_ws_token += 1            # the stand-alone statistics pass overwrites the shared workspace
+            WS.bump_norm_token()            # the stand-alone statistics pass overwrites the shared workspace
         stats = torch.empty(4, y.shape[0], y.shape[3], dtype=torch.float32, device=y.device)   # mean, rstd, scale, shift
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
@@ -215,7 +238,7 @@ class HipBackend:
     def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
         _need_cuda(dz, y, dy, dy_chansum)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
-        self._norm_ws_token += 1
+        WS.bump_norm_token()
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
                                           _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _stream()), 'dl_norm_backward')

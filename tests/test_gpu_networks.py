@@ -328,3 +328,50 @@ def test_sdg_step_golden_fixture_from_reference(precname):
             e = rel(model.fake_B[i][:, :, ::2, ::2], torch.from_numpy(z[f'step{s}/fake_B_{i + 1}']))
             ERRLOG[f'step_sdg/{precname}/s{s}/fake_B_{i + 1}'] = e
             assert e < otol[min(s, 1)]
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_inference_seam_is_thread_safe(precname):
+    """The reference drives different generators concurrently from dask worker threads (deepliif/models/__init__.py:283-334,
+    SURVEY 8b) through net(tensor).  Small tiles put every conv on the split-K path, whose scratch slab is filled by one launch and
+    reduced by the next: with process-wide scratch a second thread could overwrite it in between.  Outputs of concurrent calls
+    must be bit-identical to the serial ones -- different nets in parallel, and the same net from two threads."""
+    import threading
+    torch.manual_seed(3)
+    nets = [N.define_G(3, 3, 16, 'resnet_9blocks', 'instance', False, 'normal', 0.02, [0], 'zero'),
+            N.define_G(3, 3, 16, 'unet_64', 'batch', False, 'normal', 0.02, [0], 'zero'),
+            N.define_G(9, 3, 8, 'unet_64', 'instance', False, 'normal', 0.02, [0], 'zero'),
+            N.define_G(3, 3, 8, 'resnet_9blocks', 'batch', False, 'normal', 0.02, [0], 'reflect')]
+    for net in nets:
+        net.precision = precname
+        net.eval()
+    xs = [seeded_uniform((2, 9 if i == 2 else 3, 64, 64), 70 + i).to(DEV) for i in range(len(nets))]
+    K = 12
+    with torch.no_grad():
+        serial = [[net(x).clone() for _ in range(K)] for net, x in zip(nets, xs)]
+    for i in range(len(nets)):
+        for k in range(1, K):
+            assert torch.equal(serial[i][k], serial[i][0]), 'serial runs must be deterministic to begin with'
+    results, errors = {}, []
+    start = threading.Barrier(len(nets) + 2)
+
+    def worker(tag, net, x):
+        try:
+            start.wait()
+            with torch.no_grad():
+                results[tag] = [net(x).clone() for _ in range(K)]
+        except Exception as e:          # surface the failure in the main thread
+            errors.append((tag, repr(e)))
+
+    jobs = [(f'net{i}', nets[i], xs[i]) for i in range(len(nets))] + [('net0/b', nets[0], xs[0]), ('net1/b', nets[1], xs[1])]
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for tag, outs in results.items():
+        ref = serial[int(tag[3])][0]
+        bad = [k for k, o in enumerate(outs) if not torch.equal(o, ref)]
+        assert not bad, f'{tag}: {len(bad)} of {K} concurrent results differ from the serial result (first at iteration {bad[0]})'
