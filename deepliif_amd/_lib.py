@@ -79,6 +79,7 @@ SIGNATURES = {
     'dl_nhwc_to_nchw': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'dl_shift_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'dl_shift_stack': (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'dl_reflect_fold': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),

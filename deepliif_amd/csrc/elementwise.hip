@@ -437,3 +437,51 @@ extern "C" int dl_probe_trread(const uint16_t *src, uint16_t *dst, void *stream_
     DL_CHECK_LAUNCH("dl_probe_trread");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------- reflection-pad backward (fold)
+// dst[n,h,w,:] = sum of src[n,hp,wp,:] over every position of the reflection-padded extent (H+2p) x (W+2p) that
+// nn.ReflectionPad2d(p) fills from (h,w): the interior copy (h+p, w+p) plus the mirrored border rows / columns
+// (padded index p-h for 1 <= h <= p, p+2H-2-h for H-1-p <= h <= H-2; same along w).  At most 3 x 3 sources, summed in a fixed
+// order in fp32.  src = the data gradient with respect to the explicitly padded input (dl_conv_forward with the pad-0 plan).
+template <typename T>
+__global__ void __launch_bounds__(256) reflect_fold_kernel(const T *src, int s_ps, T *dst, int d_ps, int N, int H, int W, int p, int Cp) {
+    const int cvec = Cp / 8;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const size_t total = (size_t)N * H * W * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cvec) * 8;
+        size_t pix = i / cvec;
+        const int w = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H), n = (int)(pix / H);
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + p;
+        if (h >= 1 && h <= p) hs[nh++] = p - h;
+        if (h <= H - 2 && h >= H - 1 - p) hs[nh++] = p + 2 * H - 2 - h;
+        ws[nw++] = w + p;
+        if (w >= 1 && w <= p) ws[nw++] = p - w;
+        if (w <= W - 2 && w >= W - 1 - p) ws[nw++] = p + 2 * W - 2 - w;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) {
+                float v[8];
+                Vec8<T>::load(src + (((size_t)n * Hp + hs[a]) * Wp + ws[b]) * s_ps + c0, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        Vec8<T>::store(dst + (((size_t)n * H + h) * W + w) * d_ps + c0, acc);
+    }
+}
+extern "C" int dl_reflect_fold(int dtype, const void *src, int src_pstride, void *dst, int dst_pstride, int N, int H, int W, int pad, int Cp,
+                               void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || H <= 0 || W <= 0) DL_FAIL("dl_reflect_fold: empty problem (N=%d, %dx%d): nothing to launch", N, H, W);
+    if (!src || !dst || Cp % 8 || src_pstride % 8 || dst_pstride % 8) DL_FAIL("dl_reflect_fold: bad argument");
+    if (pad < 1 || pad >= H || pad >= W) DL_FAIL("dl_reflect_fold: pad=%d must be in [1, min(H, W) - 1] (nn.ReflectionPad2d requires pad < size)", pad);
+    const size_t total = (size_t)N * H * W * (Cp / 8);
+    if (dtype == DL_F32) hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)src, src_pstride, (float *)dst, dst_pstride, N, H, W, pad, Cp);
+    else if (dtype == DL_BF16) hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)src, src_pstride, (bf16_t *)dst, dst_pstride, N, H, W, pad, Cp);
+    else DL_FAIL("dl_reflect_fold: dtype %d", dtype);
+    DL_CHECK_LAUNCH("dl_reflect_fold");
+    return 0;
+}

@@ -270,7 +270,18 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 be.conv_wgrad(x.t, g, layer.weight.grad, spec.k, spec.stride, spec.pad, L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True)
             if layer.bias is not None and layer.bias.requires_grad and not y.bias_done:
                 be.channel_sum(g, spec.cout, layer.bias.grad, True)
-        if x_needs:
+        if x_needs and spec.kind == 'conv' and spec.pad_mode == L.PAD_REFLECT:
+            # gradient w.r.t. the explicitly reflection-padded input, then fold the mirrored borders back (dl_reflect_fold)
+            hp, wp = hi + 2 * spec.pad, wi + 2 * spec.pad
+            dxp = torch.empty((n, hp, wp, x.t.shape[3]), dtype=g.dtype, device=g.device)
+            be.conv_forward(layer.packed_dgrad, g, dxp, hp, wp, None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec)
+            dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
+            be.reflect_fold(dxp, dx, spec.pad)
+            del dxp
+            if in_act != L.ACT_NONE:
+                be.act_backward(in_act, dx, x.t, dx)
+            x.add_grad(dx)
+        elif x_needs:
             dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
             if spec.kind == 'conv' and spec.stride == 2:
                 # four sub-pixel phases over a ceil(hi/2) x ceil(wi/2) grid; for odd sizes the kernels drop the outputs of the

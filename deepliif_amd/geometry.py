@@ -118,8 +118,12 @@ class ConvSpec:
         k, p, s = self.k, self.pad, self.stride
         if self.kind == 'conv':
             if self.pad_mode != L.PAD_ZERO:
-                raise NotImplementedError('backward through a reflection-padded conv (round 1: zero padding only; the '
-                                          'reference forces zero padding for deterministic training, cli.py:267-269)')
+                # nn.ReflectionPad2d(p) + Conv2d(padding=0): this plan is the gradient with respect to the EXPLICITLY PADDED input
+                # (extent (H+2p) x (W+2p), pad-0 conv: dxp[a,b] = sum dy[a-kh, b-kw] W); dl_reflect_fold then adds the mirrored
+                # borders back onto the interior (engine.conv).  Same packed image as the zero-padding plan, other tap offsets.
+                assert s == 1, 'reflection-padded convs of the reference networks are all stride 1 (networks.py:386-388, 438-440, 478-498)'
+                taps = [(-kh, -kw, kh, kw) for kh in range(k) for kw in range(k)]
+                return GatherPlan(1, [(0, 0)], [taps], 1, 1, L.PAD_ZERO, False, self.cin, self.cout).finish()
             if s == 1:
                 taps = [(p - kh, p - kw, kh, kw) for kh in range(k) for kw in range(k)]
                 return GatherPlan(1, [(0, 0)], [taps], 1, 1, L.PAD_ZERO, False, self.cin, self.cout).finish()

@@ -308,6 +308,13 @@ class HipBackend:
         L.check(self.lib.dl_shift_stack(dl_dtype(dy), _ptr(dy), pstride(dy), n, h, w, cout, kw, pad, L.PAD_ZERO, _ptr(D), D.shape[3], _stream()),
                 'dl_shift_stack')
 
+    def reflect_fold(self, src, dst, pad):
+        """dst [N,H,W,Cp] <- gradient of nn.ReflectionPad2d(pad) applied to src [N,H+2p,W+2p,Cp] (mirrored borders added back)"""
+        _need_cuda(src, dst)
+        n, h, w, cp = dst.shape
+        assert src.shape == (n, h + 2 * pad, w + 2 * pad, cp) and src.dtype == dst.dtype
+        L.check(self.lib.dl_reflect_fold(dl_dtype(src), _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, pad, cp, _stream()), 'dl_reflect_fold')
+
     # ---- losses
     def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
         _need_cuda(x, target, loss_out, grad)

@@ -157,6 +157,14 @@ int dl_shift_sum(const float *T, int N, int H, int W, int Tc, int Cout, int KW, 
 int dl_shift_stack(int dtype, const void *dy, int dy_pstride, int N, int H, int W, int Cout, int KW, int pad, int pad_mode,
                    void *D, int Dc, void *stream);
 
+/* Backward of nn.ReflectionPad2d(pad) in front of a padding=0 Conv2d (ResnetGenerator with padding_type='reflect':
+ * networks.py:386-388 stem, 478-481 / 495-498 ResnetBlock, 438-440 head).  The data gradient of such a layer is computed in two
+ * steps: dl_conv_forward with the pad-0 data-gradient plan gives the gradient with respect to the explicitly padded input
+ * (src: [N, H+2*pad, W+2*pad, Cp]); dl_reflect_fold adds every mirrored border row / column back onto the interior pixel it
+ * was copied from (dst: [N, H, W, Cp]).  pad < min(H, W) as for nn.ReflectionPad2d.  fp32 accumulation, fixed order. */
+int dl_reflect_fold(int dtype, const void *src, int src_pstride, void *dst, int dst_pstride, int N, int H, int W, int pad, int Cp,
+                    void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Normalisation (networks.py:25-44: BatchNorm2d on batch statistics / InstanceNorm2d; eps 1e-5, biased variance)
  * fused with the activation that follows it and the ResnetBlock residual add (networks.py:512).

@@ -250,6 +250,27 @@ class FakeBackend:
         out.zero_()
         out[..., :cout] = _act(act, acc).to(out.dtype)
 
+    def reflect_fold(self, src, dst, pad):
+        self._count('reflect_fold')
+        n, h, w, cp = dst.shape
+
+        def sources(i, size):           # padded indices that nn.ReflectionPad2d(pad) fills from interior index i
+            out = [i + pad]
+            if 1 <= i <= pad:
+                out.append(pad - i)
+            if size - 1 - pad <= i <= size - 2:
+                out.append(pad + 2 * size - 2 - i)
+            return out
+        acc = torch.zeros(dst.shape, dtype=torch.float32)
+        sv = src.float()
+        for i in range(h):
+            for hp in sources(i, h):
+                row = sv[:, hp]                                  # [N, W+2p, Cp]
+                for j in range(w):
+                    for wp in sources(j, w):
+                        acc[:, i, j] += row[:, wp]
+        dst.copy_(acc.to(dst.dtype))
+
     def shift_stack(self, dy, cout, kw, pad, D):
         self._count('shift_stack')
         n, h, w, _ = dy.shape

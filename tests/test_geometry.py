@@ -2,6 +2,8 @@
 literally on CPU (tests/emu.py), must reproduce torch's Conv2d / ConvTranspose2d forward, data-gradient and weight-gradient
 for every layer shape on the path (networks.py:386-444, 576-609, 638-660).  fp64, tolerance 1e-10."""
 import pytest
+
+import fake_backend
 import torch
 import torch.nn.functional as F
 
@@ -67,6 +69,16 @@ def test_layer_formulas(kind, cin, cout, k, s, p, pm, op, H):
             hq, wq = H, W_
         dx = emu_gather_gemm(dp, to_nhwc(r, cpad(cout)), Wd, H, W_, hq, wq, cpad(cin))
         assert torch.allclose(from_nhwc(dx, cin), dx_ref, atol=1e-10)
+
+    if pm == L.PAD_REFLECT:
+        # gradient w.r.t. the explicitly padded input (pad-0 plan over the (H+2p) x (W+2p) extent), then the reflection fold
+        dp = spec.dgrad_plan()
+        Wd = emu_pack(dp, w.detach())
+        Hp, Wpd = H + 2 * p, W_ + 2 * p
+        dxp = emu_gather_gemm(dp, to_nhwc(r, cpad(cout)), Wd, Hp, Wpd, Hp, Wpd, cpad(cin))
+        dx = torch.zeros(N, H, W_, cpad(cin), dtype=dt)
+        fake_backend.FakeBackend().reflect_fold(dxp, dx, p)
+        assert torch.allclose(from_nhwc(dx.to(dt), cin), dx_ref, atol=1e-5)       # the formula backend folds in fp32
 
     # ---- weight gradient
     if kind == 'conv':

@@ -363,6 +363,51 @@ def test_wgrad_fast_path_ragged_pixels():
             assert torch.equal(g, g2), 'run-to-run difference (fixed-order reduction expected)'
 
 
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape,pad', [((2, 9, 10, 16), 3), ((1, 5, 7, 8), 1), ((3, 32, 24, 64), 3), ((2, 4, 4, 8), 3), ((1, 128, 128, 256), 1)])
+def test_reflect_fold(shape, pad, precname):
+    """dl_reflect_fold (backward of nn.ReflectionPad2d) against the formula backend, including maps barely larger than the pad
+    (4 x 4 with pad 3: the mirrored ranges of both edges overlap)."""
+    prec = Precision.get(precname)
+    n, h, w, c = shape
+    src = rnd((n, h + 2 * pad, w + 2 * pad, c), 7, prec).to(prec.dtype)
+    exp = torch.empty(shape, dtype=prec.dtype)
+    fake_backend.FakeBackend().reflect_fold(src, exp, pad)
+    got = torch.empty(shape, dtype=prec.dtype, device=DEV)
+    hip().reflect_fold(src.to(DEV), got, pad)
+    sync()
+    assert rel(got, exp) < (1e-6 if precname == 'fp32' else 2.0 ** -7)     # bf16: same fp32 sums, different order -> one-ulp flips
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(3, 64, 7, 3, 1, 24, 20), (128, 128, 3, 1, 1, 12, 16), (32, 32, 3, 1, 2, 10, 6), (64, 3, 7, 3, 2, 40, 24),
+                                  (256, 256, 3, 1, 2, 64, 64)], ids=lambda c: f'c{c[0]}-{c[1]}k{c[2]}p{c[3]}n{c[4]}_{c[5]}x{c[6]}')
+def test_reflect_conv_data_gradient(case, precname):
+    """Data gradient of nn.ReflectionPad2d(p) + Conv2d(padding=0): dl_conv_forward with the pad-0 plan over the PADDED extent (the
+    output, (H+2p) x (W+2p), is larger than the input dy and every tap offset is <= 0 -- a geometry no other layer produces),
+    then dl_reflect_fold.  Against the formula backend, which test_geometry pins to torch.autograd."""
+    cin, cout, k, p, N, H, W_ = case
+    prec = Precision.get(precname)
+    spec = ConvSpec('conv', cin, cout, k, 1, p, L.PAD_REFLECT, 0)
+    w = rnd((cout, cin, k, k), 1, prec, 0.05)
+    dy = torch.zeros(N, H, W_, cpad(cout))
+    dy[..., :cout] = rnd((N, H, W_, cout), 4, prec)
+    plan = spec.dgrad_plan()
+    outs = []
+    for be, dev in ((fake_backend.FakeBackend(), 'cpu'), (hip(), DEV)):
+        packed = ops.PackedWeights(plan, dev, prec.prec == L.PREC_BF16X3)
+        be.pack_weights(packed, w.to(dev))
+        dxp = torch.empty((N, H + 2 * p, W_ + 2 * p, cpad(cin)), dtype=prec.dtype, device=dev)
+        be.conv_forward(packed, dy.to(prec.dtype).to(dev), dxp, H + 2 * p, W_ + 2 * p, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+        dx = torch.empty((N, H, W_, cpad(cin)), dtype=prec.dtype, device=dev)
+        be.reflect_fold(dxp, dx, p)
+        outs.append((dxp, dx))
+    sync()
+    (dxp_f, dx_f), (dxp_r, dx_r) = outs
+    assert rel(dxp_r, dxp_f) < tol(prec), 'gradient w.r.t. the padded input'
+    assert rel(dx_r, dx_f) < tol(prec), 'folded gradient'
+
+
 STATS_CASES = [
     # kind, cin, cout, k, s, p, N, H, W      (bf16 direct-to-LDS dispatch: 256x16 / 128x64 / 128x128 / 256x256 tiles, 4-phase convT)
     ('conv', 3, 64, 7, 1, 3, 2, 32, 32),

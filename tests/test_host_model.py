@@ -45,14 +45,18 @@ class CpuModel(M.DeepLIIFModel):
         return []
 
 
-@pytest.mark.parametrize('modalities_no,seg_gen,norm', [(1, False, 'batch'), (2, True, 'instance'), (4, True, 'batch')])
-def test_two_steps_follow_oracle(modalities_no, seg_gen, norm):
+@pytest.mark.parametrize('modalities_no,seg_gen,norm,padding', [(1, False, 'batch', 'zero'), (2, True, 'instance', 'zero'), (4, True, 'batch', 'zero'),
+                                                                 (2, True, 'instance', 'reflect'), (1, False, 'batch', 'reflect')])
+def test_two_steps_follow_oracle(modalities_no, seg_gen, norm, padding):
+    """padding='reflect' (cli --padding reflect): the ResnetGenerator convs sit behind nn.ReflectionPad2d; training needs their
+    data gradient (pad-0 plan over the padded extent + dl_reflect_fold) and the reflect-gather weight gradient"""
     torch.manual_seed(0)
     opt = make_opt(modalities_no, seg_gen, norm)
+    opt.padding = padding
     model = CpuModel(opt)
     model.setup(opt)
     # oracle with identical weights
-    cfg = O.OracleConfig(modalities_no=modalities_no, seg_gen=seg_gen, norm=norm, padding='zero', net_gs='unet_64', ngf=8, ndf=8)
+    cfg = O.OracleConfig(modalities_no=modalities_no, seg_gen=seg_gen, norm=norm, padding=padding, net_gs='unet_64', ngf=8, ndf=8)
     S = str(model.mod_id_seg)
     nets = {}
     for n in model.model_names:

@@ -36,6 +36,8 @@ CASES = [
     ('n_layers', 12, 8, 'instance', 'zero', (1, 12, 64, 64)),
     ('n_layers', 6, 8, 'instance', 'zero', (3, 6, 100, 76)),       # 100 -> 50 -> 25 -> 12: an odd map in front of a stride-2 conv
     ('resnet_9blocks', 3, 8, 'instance', 'zero', (1, 3, 36, 52)),   # batch 1, H != W
+    ('resnet_2blocks', 3, 8, 'instance', 'reflect', (2, 3, 20, 28)),  # ReflectionPad2d(3) stem / head on 20x28 -> 5x7 block maps
+    ('resnet_9blocks', 3, 8, 'batch', 'reflect', (1, 3, 32, 32)),
 ]
 
 
