@@ -144,9 +144,10 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp32_bf16mma'])
     ap.add_argument('--norm', default='instance', choices=['instance', 'batch'])
-    ap.add_argument('--workload', default='train', choices=['train', 'train18', 'infer'],
+    ap.add_argument('--workload', default='train', choices=['train', 'train18', 'ext', 'infer'],
                     help="train = BASELINE's 5G+5D step (the contract line); train18 = the real DeepLIIF configuration (modalities_no=4, seg_gen: "
-                         '4 Resnet-9 + 5 UNet-512 generators + 9 discriminators, SURVEY 8d); infer = configs[1]')
+                         '4 Resnet-9 + 5 UNet-512 generators + 9 discriminators, SURVEY 8d); ext = BASELINE configs[3], DeepLIIFExt with 2 modalities: '
+                         '2 Resnet-9 + 2 UNet-512 (9-channel input) generators, 2 + 2 discriminators (6 / 12 channels); infer = configs[1]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -181,6 +182,23 @@ def main():
         gf_per_tile = GF_PER_TILE_TRAIN_5R5D
         dom_shape = (n, s // 4, s // 4, 256)
         workload = 'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
+    elif args.workload == 'ext':
+        opt = make_opt(args, local_rank, M=2, seg_gen=True)
+        opt.model, opt.net_ds = 'DeepLIIFExt', 'n_layers'
+        opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
+        model = M.create_model(opt)
+        model.setup(opt)
+        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(2)], 'BS': [synth(1255 + i) for i in range(2)], 'A_paths': ['synthetic']}
+
+        def step():
+            model.set_input(batch)
+            model.optimize_parameters()
+        # per tile: generators forward + 2x backward; every discriminator: 2 forwards + 2x2 backward in backward_D, 1 forward + 1 dgrad
+        # in backward_G = 8 forward-equivalents (the accounting SURVEY 8d uses for the 5G+5D figure: 40 x 21.8 for 5 D)
+        gf_per_tile = 3 * (2 * 396.4 + 2 * 49.2) + 8 * (2 * 21.8 + 2 * 22.6)
+        dom_shape = (n, s // 4, s // 4, 256)
+        workload = ('DeepLIIFExt train step, modalities_no=2: 2x Resnet-9block + 2x UNet-512 (9-ch in) generators, 2x NLayerD (6 ch) + 2x NLayerD '
+                    '(12 ch), GAN/LSGAN+SmoothL1+Adam (BASELINE configs[3])')
     elif args.workload == 'train18':
         opt = make_opt(args, local_rank, M=4, seg_gen=True)
         model = M.create_model(opt)
@@ -250,7 +268,7 @@ def main():
                     'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload != 'infer' else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
-        'metric': {'train': '512x512 tiles/s train-step (5G+5D)', 'train18': '512x512 tiles/s train-step (real DeepLIIF: 9 G + 9 D)',
+        'metric': {'train': '512x512 tiles/s train-step (5G+5D)', 'train18': '512x512 tiles/s train-step (real DeepLIIF: 9 G + 9 D)', 'ext': '512x512 tiles/s train-step (DeepLIIFExt, 2 modalities: 4 G + 4 D)',
                    'infer': '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)'}[args.workload],
         'value': round(value, 3), 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
