@@ -34,3 +34,22 @@ def digest_close(actual, expected, rtol):
     err_other = np.abs(np.delete(a, [0, 2]) - np.delete(expected, [0, 2])).max() / scale
     worst = max(err_sum, err_other)
     return worst <= rtol, f'digest rel err {worst:.3e} (tol {rtol:.1e})'
+
+
+# ---- shared by make_golden_tiler.py and the tiler tests
+def synth_image(w, h, seed):
+    """low-entropy synthetic RGB image (gradients + blobs + a little noise) so that the npz stays small"""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 7) % 256], axis=-1).astype(np.int32)
+    for _ in range(6):
+        cx, cy, r = rng.randint(0, w), rng.randint(0, h), rng.randint(5, max(6, min(w, h) // 3))
+        m = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
+        img[m] = rng.randint(0, 256, 3)
+    img += rng.randint(-2, 3, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def tiler_result_tiles(tile_np):
+    """two deterministic 'network outputs' per tile (any per-pixel function of the tile works: it must survive crop + paste)"""
+    return {'A': 255 - tile_np, 'B': np.ascontiguousarray(tile_np[..., ::-1] // 2 + 7)}
