@@ -83,6 +83,9 @@ SIGNATURES = {
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    'dl_tile_gather_u8': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _i, _vp, _i, _i, _vp]),
+    'dl_tile_gray_stats_u8': (_i, [_vp, _i64, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _vp]),
+    'dl_tile_paste_u8': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i64, _vp]),
     'dl_probe_mfma16': (_i, [_vp, _vp, _vp, _vp]),
     'dl_probe_trread': (_i, [_vp, _vp, _vp]),
 }
@@ -108,8 +111,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 100:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 100 (stale build)')
+    if lib.dl_version() != 101:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 101 (stale build)')
     _lib = lib
     return lib
 

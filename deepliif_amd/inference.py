@@ -46,58 +46,110 @@ class _Opt:
         self.__dict__.update(d)
 
 
+def _seg_names_in_dir(model_dir):
+    """(mod_id_seg, input_id) sniffed from the generator file names like the reference does (deepliif/util/util.py:208-240):
+    'latest_net_GS0.pth' -> names 'S0', ...; the seg id is the first character of the longest name, input id '0' iff a '...0' file exists"""
+    files = os.listdir(model_dir)
+    names = [f[:-4].split('_')[2][1:] for f in files if f.endswith('.pth') and 'net_G' in f]
+    if not names:
+        names = [f[1:-3] for f in files if f.endswith('.pt') and f.startswith('G')]
+    if not names:
+        raise Exception('Cannot find any model file ending with .pt or .pth in directory', model_dir)
+    return max(names, key=len)[0], ('0' if '0' in [n[1:] for n in names] else '1')
+
+
 def get_opt(model_dir, mode='test'):
-    """deepliif/models/__init__.py:53-68 (test-mode defaults of deepliif/options/__init__.py:69-180 that the path reads)."""
-    p = read_model_params(os.path.join(model_dir, 'train_opt.txt'))
-    opt = _Opt(p)
-    opt.is_train = False
-    opt.phase = 'test'
-    opt.input_nc, opt.output_nc, opt.ngf = 3, 3, _get(opt, 'ngf', 64)
+    """deepliif/models/__init__.py:53-68 -> Options(path_file=..., mode='test') (deepliif/options/__init__.py:38-180): parse
+    '<phase>_opt.txt' and back-fill the test-mode defaults the inference path reads."""
+    path = os.path.join(model_dir, 'test_opt.txt')
+    if mode == 'train' or not os.path.exists(path):
+        path = os.path.join(model_dir, 'train_opt.txt')
+    opt = _Opt(read_model_params(path))
+    opt.optimizer = _get(opt, 'optimizer', 'adam')
+    opt.model = _get(opt, 'model', 'DeepLIIF')
+    if mode == 'train':
+        opt.is_train = True
+        return opt
+    opt.is_train, opt.phase, opt.continue_train = False, 'test', False
+    opt.input_nc, opt.output_nc, opt.ngf = 3, 3, 64                      # options/__init__.py:73-75 (forced in test mode)
     opt.norm = _get(opt, 'norm', 'batch')
     opt.no_dropout = True
-    opt.input_no = _get(opt, 'input_no', 1)
     if not hasattr(opt, 'modalities_no') and hasattr(opt, 'targets_no'):
         opt.modalities_no = opt.targets_no - 1
-    opt.seg_gen = _get(opt, 'seg_gen', True)
+    if opt.model in ('DeepLIIF', 'DeepLIIFKD'):
+        sniff = None
+        if not hasattr(opt, 'mod_id_seg') or opt.mod_id_seg is None:
+            sniff = _seg_names_in_dir(model_dir)
+            opt.mod_id_seg = sniff[0]
+        opt.input_id = int((sniff or _seg_names_in_dir(model_dir))[1])
+        if hasattr(opt, 'seg_gen') and opt.seg_gen is False:
+            opt.mod_id_seg = None
+        if opt.modalities_no == 4 and not hasattr(opt, 'modalities_names'):
+            opt.modalities_names = ['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker']
+            opt.seg_weights = [0.5, 0, 0, 0, 0.5]
+        if not _get(opt, 'modalities_names', None):
+            opt.modalities_names = [f'input{i + 1}' for i in range(_get(opt, 'input_no', 1))] + [f'mod{i + 1}' for i in range(opt.modalities_no)]
+    else:
+        opt.modalities_names = [f'mod{i}' for i in range(opt.modalities_no + 1)]
+    if not hasattr(opt, 'background_colors'):
+        opt.background_colors = ([(201, 211, 208), (10, 10, 10), (0, 0, 0), (10, 10, 10)] if opt.model in ('DeepLIIF', 'DeepLIIFKD')
+                                 else [(10, 10, 10)] * opt.modalities_no)
+    opt.checkpoints_dir, opt.name = os.path.dirname(os.path.abspath(model_dir)), os.path.basename(os.path.abspath(model_dir))
+    if isinstance(_get(opt, 'gpu_ids', ()), int):
+        opt.gpu_ids = (opt.gpu_ids,)
+    if not hasattr(opt, 'seg_no'):
+        if opt.model == 'DeepLIIF':
+            opt.seg_no, opt.seg_gen = 1, True
+        elif opt.model == 'DeepLIIFExt':
+            opt.seg_no = opt.modalities_no if opt.seg_gen else 0
+        elif opt.model == 'SDG':
+            opt.seg_no, opt.seg_gen = 0, False
+        else:
+            raise Exception(f'seg_gen cannot be automatically determined for {opt.model}')
+    if opt.model == 'SDG':
+        opt.seg_gen = False
+    opt.input_no = _get(opt, 'input_no', 1)
+    if not hasattr(opt, 'scale_size'):
+        opt.scale_size = {'DeepLIIF': 512, 'SDG': 512, 'DeepLIIFExt': 1024}[opt.model]
+    if not hasattr(opt, 'seg_weights'):
+        opt.seg_weights = [0.25, 0.15, 0.25, 0.1, 0.25] if opt.model == 'DeepLIIF' else [1 / opt.modalities_no] * opt.modalities_no
+    opt.upsample = _get(opt, 'upsample', 'convtranspose')
     opt.padding = _get(opt, 'padding', 'zero')
     if not hasattr(opt, 'net_g') and hasattr(opt, 'netG'):
         opt.net_g = opt.netG
     opt.net_g = _get(opt, 'net_g', 'resnet_9blocks')
     opt.net_gs = _get(opt, 'net_gs', 'unet_512')
-    files = os.listdir(model_dir)
-    seg_names = [f[:-4].split('_')[2][1:] for f in files if f.endswith('.pth') and 'net_G' in f]
-    if not hasattr(opt, 'mod_id_seg') or opt.mod_id_seg is None:
-        longest = max(seg_names, key=len) if seg_names else 'S0'
-        opt.mod_id_seg = longest[0] if opt.seg_gen else None
-    opt.input_id = 0 if any(n[1:] == '0' for n in seg_names if len(n) > 1) or not seg_names else 1
-    if opt.modalities_no == 4 and not hasattr(opt, 'modalities_names'):
-        opt.modalities_names = ['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker']
-        opt.seg_weights = [0.5, 0, 0, 0, 0.5]
-    if not _get(opt, 'modalities_names', None):
-        opt.modalities_names = [f'input{i + 1}' for i in range(opt.input_no)] + [f'mod{i + 1}' for i in range(opt.modalities_no)]
+    opt.use_dp = False
     opt.gpu_ids = list(range(torch.cuda.device_count()))
     return opt
 
 
 def generator_names(opt):
-    M, S, off = opt.modalities_no, _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
+    """(translation generators, seg generators) in the reference's naming (deepliif/models/__init__.py:172-198)"""
+    M = opt.modalities_no
+    if _get(opt, 'model', 'DeepLIIF') in ('DeepLIIFExt', 'SDG'):
+        return [f'G_{i + 1}' for i in range(M)], ([f'GS_{i + 1}' for i in range(M)] if opt.seg_gen else [])
+    S, off = _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
     g = [f'G{i + 1}' for i in range(M)]
     gs = [f'G{S}{off + i}' for i in range(M + 1)] if opt.seg_gen else []
     return g, gs
 
 
 def build_generators(opt, device, precision: Optional[str] = None) -> 'OrderedDict[str, torch.nn.Module]':
-    """All generators of a DeepLIIF model on ONE device, eval mode, BatchNorm on batch statistics."""
+    """All generators of a model on ONE device, eval mode, BatchNorm on batch statistics (288 GB of HBM hold every generator many
+    times over: the reference's per-group GPU placement, models/__init__.py:201-211, has no counterpart)."""
     g, gs = generator_names(opt)
     net_g = opt.net_g if isinstance(opt.net_g, (list, tuple)) else [opt.net_g] * len(g)
     net_gs = opt.net_gs if isinstance(opt.net_gs, (list, tuple)) else [opt.net_gs] * len(gs)
     ids = [device.index if device.index is not None else 0] if device.type == 'cuda' else []
     nets = OrderedDict()
-    cin = opt.input_nc * _get(opt, 'input_no', 1)
+    model = _get(opt, 'model', 'DeepLIIF')
+    cin = opt.input_nc * (_get(opt, 'input_no', 1) if model != 'DeepLIIFExt' else 1)
+    cin_s = opt.input_nc * 3 if model in ('DeepLIIFExt', 'SDG') else cin          # GS_i(cat(A, fake_1, fake_i)), DeepLIIFExt_model.py:85,173
     for n, arch in zip(g, net_g):
         nets[n] = networks.define_G(cin, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids, opt.padding)
     for n, arch in zip(gs, net_gs):
-        nets[n] = networks.define_G(cin, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids)
+        nets[n] = networks.define_G(cin_s, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids)
     for net in nets.values():
         net.eval()
         if precision:
@@ -109,7 +161,7 @@ _NETS_CACHE: Dict = {}
 
 
 def init_nets(model_dir, eager_mode=False, opt=None, phase='test'):
-    """deepliif/models/__init__.py:158-219.  Returns {name: net}; every net is callable on a [N,3,H,W] tensor.
+    """deepliif/models/__init__.py:158-219.  Returns {name: net}; every net is callable on a [N,C,H,W] tensor.
     TorchScript '<name>.pt' files are CUDA/ATen graphs and are not loaded here: the '<epoch>_net_<name>.pth' state_dicts
     (the reference's own checkpoint format, base_model.py:190-212) are the interchange."""
     key = (model_dir, phase)
@@ -152,22 +204,39 @@ def tensor_to_pil(t: torch.Tensor):
     return Image.fromarray(((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(np.uint8))
 
 
-def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, seg_weights=None) -> 'OrderedDict[str, torch.Tensor]':
-    """The DeepLIIF branch of run_dask (deepliif/models/__init__.py:293-361) on a batch of tiles [N,3,H,W]:
-    G_i(tile); GS_0(tile); GS_i(G_i(tile)); seg = sum_k w_k * seg_k.  Returns name -> [N,3,H,W] fp32 tensors."""
+def _seg_weight_map(opt, seg_weights):
     M, S, off = opt.modalities_no, _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
+    if seg_weights is None:
+        return {f'G{S}{off + i}': 1 / (M + 1) for i in range(M + 1)}
+    return {f'G{S}{off + i}': w for i, w in enumerate(seg_weights)}
+
+
+def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None) -> 'OrderedDict[str, E.Act]':
+    """The generator DAG of run_dask (deepliif/models/__init__.py:293-388) on a batch of tiles in ENGINE layout, outputs in engine
+    layout, keys and key ORDER as the reference's result dict.
+      DeepLIIF / DeepLIIFKD (:293-361): G_i(tile); GS_0(tile); GS_i(G_i(tile)); seg = sum_k w_k * seg_k
+      DeepLIIFExt / SDG     (:362-388): G_i(tile); GS_i(cat(tile, G_1(tile), G_i(tile)))"""
     first = next(iter(nets.values()))
-    device = next(first.parameters()).device
     prec = E.Precision.get(first.precision)
     ctx = E.Ctx(prec, None, training=False, per_sample_norm=True)
-    x = E.to_engine(ts.to(device), prec)
+    model = _get(opt, 'model', 'DeepLIIF')
+    M = opt.modalities_no
+    if model in ('DeepLIIFExt', 'SDG'):
+        names = [f'G_{i}' for i in range(1, M + 1)]
+        gens = OrderedDict((k, nets[k].run(ctx, x)) for k in names)
+        res = OrderedDict(gens)
+        if mod_only or not opt.seg_gen:
+            return res
+        for i, k in enumerate(names, start=1):
+            res[f'GS_{i}'] = nets[f'GS_{i}'].run(ctx, E.concat_channels(ctx, [x, gens[names[0]], gens[k]]))
+        return res
+    if model not in ('DeepLIIF', 'DeepLIIFKD'):
+        raise NotImplementedError(f'run_dask for model {model} is not on the MI355X hot path')
+    S, off = _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
     seg_map = OrderedDict((f'G{i + 1}', f'G{S}{off + i + 1}') for i in range(M))
     weights = None
     if opt.seg_gen:
-        if seg_weights is None:
-            weights = {f'G{S}{off + i}': 1 / (M + 1) for i in range(M + 1)}
-        else:
-            weights = {f'G{S}{off + i}': w for i, w in enumerate(seg_weights)}
+        weights = _seg_weight_map(opt, seg_weights)
         if seg_only:
             seg_map = OrderedDict((k, v) for k, v in seg_map.items() if weights[v] != 0)
     gens = OrderedDict((k, nets[k].run(ctx, x)) for k in seg_map)
@@ -176,9 +245,8 @@ def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, 
         km = f'G{names.index("Marker")}'
         if km not in gens and km in nets:
             gens[km] = nets[km].run(ctx, x)
-    res = OrderedDict((k, E.from_engine(v)) for k, v in gens.items())
     if not opt.seg_gen or mod_only:
-        return res
+        return OrderedDict(gens)
     segs = OrderedDict((v, nets[v].run(ctx, gens[k])) for k, v in seg_map.items())
     base = f'G{S}{off}'
     if weights[base] != 0:
@@ -187,26 +255,261 @@ def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, 
     seg = E.weighted_sum(ctx, [segs[k] for k in keys], [float(weights[k]) for k in keys])
     if seg_only and M > 0:
         last = f'G{M}'
-        res = OrderedDict([(last, res[last])] if last in res else [])
+        res = OrderedDict([(last, gens[last])] if last in gens else [])
     else:
-        res.update((k, E.from_engine(v)) for k, v in segs.items())
-    res[f'G{S}'] = E.from_engine(seg)
+        res = OrderedDict(gens)
+        res.update(segs)
+    res[f'G{S}'] = seg
     return res
+
+
+def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, seg_weights=None) -> 'OrderedDict[str, torch.Tensor]':
+    """run_generators_engine on a [N, C, H, W] fp32 tensor; returns name -> [N, 3, H, W] fp32 tensors (run_dask(output_tensor=True))."""
+    first = next(iter(nets.values()))
+    device = next(first.parameters()).device
+    x = E.to_engine(ts.to(device), E.Precision.get(first.precision))
+    return OrderedDict((k, E.from_engine(v)) for k, v in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items())
 
 
 def run_dask(img, model_path=None, nets=None, eager_mode=False, opt=None, seg_only=False, mod_only=False, seg_weights=None, use_dask=True,
              output_tensor=False):
-    """Same call shape as the reference's run_dask (`use_dask` is accepted and ignored: branch concurrency is the engine's
-    business).  `img` is a PIL image or a [N,3,H,W] tensor; PIL in -> dict of PIL images of the first tile."""
+    """Same call shape as the reference's run_dask (deepliif/models/__init__.py:258-388; `use_dask` is accepted and ignored: branch
+    concurrency is the engine's business).  `img` is a PIL image, a list of PIL images (multi-input models, :276-279) or a
+    [N, C, H, W] tensor; PIL in -> dict of PIL images of the first tile."""
     assert model_path is not None or nets is not None, 'Provide either the model path or the networks object.'
     if nets is None:
         nets = init_nets(os.getenv('DEEPLIIF_MODEL_DIR', model_path), eager_mode, opt)
     if opt is None:
         opt = get_opt(os.getenv('DEEPLIIF_MODEL_DIR', model_path))
-    if _get(opt, 'model', 'DeepLIIF') not in ('DeepLIIF', 'DeepLIIFKD'):
-        raise NotImplementedError(f'run_dask for model {opt.model} is not on the MI355X hot path yet')
-    ts = img if isinstance(img, torch.Tensor) else transform(img, _get(opt, 'scale_size', None))
+    if isinstance(img, torch.Tensor):
+        ts = img
+    elif _get(opt, 'input_no', 1) > 1 or _get(opt, 'model', 'DeepLIIF') == 'SDG':
+        ts = torch.cat([transform(i, _get(opt, 'scale_size', None)) for i in img], dim=1)
+    else:
+        ts = transform(img, _get(opt, 'scale_size', None))
     res = run_generators(ts, nets, opt, seg_only, mod_only, seg_weights)
     if output_tensor:
         return res
     return {k: tensor_to_pil(v) for k, v in res.items()}
+
+
+# -------------------------------------------------------------------------------------------------------------
+# tiled inference: inference() / infer_region()   (deepliif/models/__init__.py:399-579)
+# -------------------------------------------------------------------------------------------------------------
+def empty_tile_colors(opt, seg_only=False, mod_only=False) -> 'OrderedDict[str, tuple]':
+    """What run_wrapper returns for a tile that is_empty (deepliif/models/__init__.py:399-461): key -> constant colour."""
+    model, M = _get(opt, 'model', 'DeepLIIF'), opt.modalities_no
+    black = (0, 0, 0)
+    if model in ('DeepLIIFExt', 'SDG'):
+        res = OrderedDict((f'G_{i}', black) for i in range(1, M + 1))
+        res.update((f'GS_{i}', black) for i in range(1, M + 1))
+        return res
+    if model not in ('DeepLIIF', 'DeepLIIFKD'):
+        raise NotImplementedError(f'run_wrapper is not implemented for model {model}')
+    S, bg = _get(opt, 'mod_id_seg', 'S'), _get(opt, 'background_colors', None)
+    if bg is None:
+        bg = [(201, 211, 208), (10, 10, 10), (0, 0, 0), (10, 10, 10)]                      # options/__init__.py:118-122
+    if seg_only:
+        res = OrderedDict()
+        if M >= 1:
+            res[f'G{M}'] = tuple(bg[-1])
+        res[f'G{S}'] = black
+    elif mod_only or not opt.seg_gen:
+        res = OrderedDict((f'G{i + 1}', tuple(bg[i])) for i in range(M))
+    else:
+        res = OrderedDict((f'G{i + 1}', tuple(bg[i])) for i in range(M))
+        res[f'G{S}'] = black
+        first = 1 if int(_get(opt, 'input_id', 0)) == 1 else 0
+        res.update((f'G{S}{first + i}', black) for i in range(M + 1))
+    res.pop('G0', None)
+    return res
+
+
+def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod_only=False, seg_weights=None, batch_size=8, rank=0, world=1):
+    """Tile loop of inference() (deepliif/models/__init__.py:496-500) for uint8 RGB image(s) [H, W, 3] resident in HBM, entirely on
+    the GPU: crop + transform (dl_tile_gather_u8), is_empty (dl_tile_gray_stats_u8), the generator DAG on batches of `batch_size`
+    tiles with per-sample normalisation, tensor2im + stitch (dl_tile_paste_u8).
+    Tile-parallel over `world` ranks (BASELINE configs[4]): rank r owns a contiguous band of tile rows (tiling.split_rows) and
+    returns ({key: uint8 [band rows, W, 3]}, (y0, y1)); the bands of all ranks concatenate to the full result images."""
+    from .tiling import RegionTiler, TilePlan, split_rows
+    scale = _get(opt, 'scale_size', tile_size)
+    if tile_size != scale:
+        raise NotImplementedError(f'infer_region runs tiles at the network resolution (tile_size == scale_size == {scale}); '
+                                  f'inference() resamples other tile sizes with PIL on the host')
+    first = next(iter(nets.values()))
+    prec = E.Precision.get(first.precision)
+    h, w = int(images[0].shape[0]), int(images[0].shape[1])
+    n_rows = len(TilePlan(w, h, tile_size, overlap_size).ys)
+    tiler = RegionTiler(images, tile_size, overlap_size, rows=split_rows(n_rows, world)[rank])
+    if len(tiler) == 0:
+        return {}, tiler.band
+    empty = tiler.empty_mask()
+    ids = np.array(tiler.tile_ids)
+    colors = empty_tile_colors(opt, seg_only, mod_only)
+    if empty.any():
+        for k, c in colors.items():
+            tiler.paste(k, None, ids[empty].tolist(), const_rgb=c)
+    work = ids[~empty].tolist()
+    cp = E.cpad(3 * len(images))
+    for s in range(0, len(work), batch_size):
+        chunk = work[s:s + batch_size]
+        x = E.Act(tiler.gather(chunk, prec.dtype, cp), 3 * len(images))
+        for k, a in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items():
+            tiler.paste(k, a.t, chunk)
+    return tiler.results(), tiler.band
+
+
+def gather_bands(local: Dict[str, torch.Tensor], band, height: int, width: int, keys: List[str], rank: int, world: int):
+    """Concatenate the per-rank result bands on rank 0 (point-to-point sends of contiguous uint8 rows; every rank knows every band
+    from the plan, so no size exchange).  Returns {key: uint8 [height, width, 3]} on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    dev = next(iter(local.values())).device if local else torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    bands = [None] * world
+    dist.all_gather_object(bands, (int(band[0]), int(band[1])))
+    out = None
+    if rank == 0:
+        out = {k: torch.zeros((height, width, 3), dtype=torch.uint8, device=dev) for k in keys}
+    for k in keys:
+        for r in range(world):
+            y0, y1 = bands[r]
+            if y1 <= y0:
+                continue
+            if rank == 0:
+                if r == 0:
+                    out[k][y0:y1] = local[k] if k in local else 0
+                else:
+                    dist.recv(out[k][y0:y1], src=r)
+            elif r == rank:
+                dist.send(local[k].contiguous() if k in local else torch.zeros((y1 - y0, width, 3), dtype=torch.uint8, device=dev), dst=0)
+    return out
+
+
+def _to_u8_device(img, device) -> torch.Tensor:
+    a = np.asarray(img.convert('RGB') if img.mode != 'RGB' else img)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _result_names(opt, results, seg_only, mod_only, return_seg_intermediate):
+    """Result-key -> caller-facing name mapping of inference() (deepliif/models/__init__.py:502-579)."""
+    model, M = _get(opt, 'model', 'DeepLIIF'), opt.modalities_no
+    if model == 'DeepLIIFExt':
+        out = OrderedDict((f'mod{i}', f'G_{i}') for i in range(1, M + 1))
+        if opt.seg_gen:
+            out.update((f'Seg{i}', f'GS_{i}') for i in range(1, M + 1))
+        return out
+    if model == 'SDG':
+        return OrderedDict((f'mod{i}', f'G_{i}') for i in range(1, M + 1))
+    if model not in ('DeepLIIF', 'DeepLIIFKD'):
+        return OrderedDict((k, k) for k in results)
+    S, input_no = _get(opt, 'mod_id_seg', 'S'), _get(opt, 'input_no', 1)
+    names = list(_get(opt, 'modalities_names', []))
+    mods = [f'mod{i + 1}' for i in range(M)]
+    if mods != names[input_no:]:
+        mods = [f'mod{i + 1}-{n}' for i, n in enumerate(names[input_no:])]
+    ids = OrderedDict((n, f'G{i + 1}') for i, n in enumerate(mods))
+    seg_ids = OrderedDict()
+    if opt.seg_gen:
+        segm = [f'mod{i}' for i in range(M + 1)]
+        if segm != names:
+            segm = [f'mod{i}-{n}' for i, n in enumerate(names)]
+        first = 0 if f'G{S}0' in results else 1
+        seg_ids = OrderedDict((n, f'G{S}{first + i}') for i, n in enumerate(segm))
+    if not mod_only and opt.seg_gen:
+        ids['Seg'] = f'G{S}'
+    if seg_only:
+        out = OrderedDict([('Seg', ids['Seg'])])
+        marker = next((n for n in ids if n.endswith('Marker')), None)          # find_marker_key (models/__init__.py)
+        if marker is not None:
+            out[marker] = ids[marker]
+        return out
+    out = OrderedDict(ids)
+    if opt.seg_gen and return_seg_intermediate:
+        out.update((f'{n}_s', k) for n, k in seg_ids.items())
+    return out
+
+
+def inference(img, tile_size, overlap_size, model_path, use_torchserve=False, eager_mode=False, color_dapi=False, color_marker=False, opt=None,
+              return_seg_intermediate=False, seg_only=False, mod_only=False, seg_weights=None, opt_args={}, nets=None, batch_size=8):
+    """Drop-in for deepliif.models.inference (deepliif/models/__init__.py:464-579): PIL image in, dict name -> PIL image out.
+    The tile loop runs on the GPU in batches (infer_region); `nets` / `batch_size` are extensions (default: init_nets(model_path))."""
+    from PIL import Image
+    if use_torchserve:
+        raise NotImplementedError('the TorchServe client route is not part of the MI355X engine (use the in-process engine)')
+    if not opt:
+        opt = get_opt(model_path)
+    for k, v in opt_args.items():
+        setattr(opt, k, v)
+    if hasattr(opt, 'seg_gen') and opt.seg_gen is False and (seg_only or return_seg_intermediate):
+        seg_only = return_seg_intermediate = False
+        print('option seg_gen is False, disabled seg_only and return_seg_intermediate')
+    if nets is None:
+        nets = init_nets(os.getenv('DEEPLIIF_MODEL_DIR', model_path), eager_mode, opt)
+    device = next(next(iter(nets.values())).parameters()).device
+    input_no = _get(opt, 'input_no', 1)
+    if input_no > 1 or _get(opt, 'model', 'DeepLIIF') == 'SDG':
+        w, h = int(img.width / input_no), img.height
+        origs = [img.crop((w * i, 0, w * (i + 1), h)) for i in range(input_no)]
+    else:
+        origs = [img]
+    scale = _get(opt, 'scale_size', tile_size)
+    if tile_size == scale:
+        bands, _ = infer_region([_to_u8_device(o, device) for o in origs], tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights,
+                                batch_size)
+        results = {k: Image.fromarray(v.cpu().numpy()) for k, v in bands.items()}
+    else:
+        results = _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights, batch_size, scale)
+    names = _result_names(opt, results, seg_only, mod_only, return_seg_intermediate)
+    return {n: results[k] for n, k in names.items()}
+
+
+def _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights, batch_size, scale):
+    """tile_size != scale_size: the reference resamples every tile to the network resolution and every result tile back with PIL
+    (run_dask :276-280, InferenceTiler.stitch :291-292).  Resampling is image-format plumbing and stays PIL on the host; the tiles
+    still go through the generators in batches."""
+    from PIL import Image
+    from .tiling import TilePlan, gray_stats_empty
+    w, h = origs[0].size
+    plan = TilePlan(w, h, tile_size, overlap_size)
+    device = next(next(iter(nets.values())).parameters()).device
+    srcs = [np.asarray(o.convert('RGB')) for o in origs]
+    if (plan.image_width, plan.image_height) != (w, h):             # mirror extension (util/__init__.py:196-211)
+        def ext(a):
+            while a.shape[1] < plan.image_width:
+                a = np.concatenate([a, a[:, ::-1]], axis=1)
+            while a.shape[0] < plan.image_height:
+                a = np.concatenate([a, a[::-1]], axis=0)
+            return a[:plan.image_height, :plan.image_width]
+        srcs = [ext(a) for a in srcs]
+    rects, origins = plan.paste_rects(), plan.origins
+    colors = empty_tile_colors(opt, seg_only, mod_only)
+    out: Dict[str, np.ndarray] = {}
+
+    def put(key, tile_u8, t):
+        if key not in out:
+            out[key] = np.zeros((plan.image_height, plan.image_width, 3), dtype=np.uint8)
+        l, tp, rw, rh, px, py = rects[t]
+        out[key][py:py + rh, px:px + rw] = tile_u8[tp:tp + rh, l:l + rw]
+
+    def gray_empty(a):
+        g = ((a[..., 0].astype(np.uint32) * 19595 + a[..., 1].astype(np.uint32) * 38470 + a[..., 2].astype(np.uint32) * 7471 + 0x8000) >> 16).astype(np.int64)
+        v = g[(g != 0) & (g != 255)]
+        return bool(gray_stats_empty(np.array([[v.size, v.sum(), (v * v).sum()]], dtype=np.int64))[0])
+
+    pending = []
+    for t, (x, y) in enumerate(origins):
+        crops = [a[y:y + plan.patch_size, x:x + plan.patch_size] for a in srcs]
+        if all(gray_empty(c) for c in crops):
+            for k, c in colors.items():
+                put(k, np.broadcast_to(np.array(c, dtype=np.uint8), (tile_size, tile_size, 3)), t)
+            continue
+        pending.append((t, torch.cat([transform(Image.fromarray(c), scale) for c in crops], dim=1)))
+    for s in range(0, len(pending), batch_size):
+        chunk = pending[s:s + batch_size]
+        res = run_generators(torch.cat([ts for _, ts in chunk]).to(device), nets, opt, seg_only, mod_only, seg_weights)
+        for k, v in res.items():
+            for i, (t, _) in enumerate(chunk):
+                tile = tensor_to_pil(v[i:i + 1]).resize((tile_size, tile_size))
+                put(k, np.asarray(tile), t)
+    return {k: Image.fromarray(v[:h, :w]) for k, v in out.items()}

@@ -91,14 +91,34 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_LAUNCH = threading.local()
+
+
+def _stream(t: Optional[torch.Tensor] = None):
+    """torch's current HIP stream OF THE OPERANDS' DEVICE (not of whatever device happens to be current): nets live on
+    cuda:gpu_ids[0] (base_model.py:38), and a launch on another device's stream with these pointers would fault or silently rely on
+    peer access.  The launching thread's current device is switched to the operands' device if it differs (the reference's CLI does
+    torch.cuda.set_device(gpu_ids[0]) once, cli.py:250-256; the model classes here do the same in BaseModel.__init__)."""
+    dev = t.device if t is not None else getattr(_LAUNCH, 'dev', None)
+    if dev is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise L.HipLibraryError('deepliif_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise L.HipLibraryError(f'operands of one kernel launch live on different devices ({dev} and {t.device})')
+    _LAUNCH.dev = dev
 
 
 class HipBackend:
@@ -314,6 +334,32 @@ class HipBackend:
         n, h, w, cp = dst.shape
         assert src.shape == (n, h + 2 * pad, w + 2 * pad, cp) and src.dtype == dst.dtype
         L.check(self.lib.dl_reflect_fold(dl_dtype(src), _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, pad, cp, _stream()), 'dl_reflect_fold')
+
+    # ---- tiles: uint8 [H, W, 3] images <-> engine tile batches (crop + transform, is_empty statistic, tensor2im + stitch)
+    def tile_gather(self, images, H0, W0, origins, tile, pad, pad_rgb, lut, out):
+        _need_cuda(origins, lut, out, *images)
+        assert origins.dtype == torch.int32 and origins.is_contiguous() and lut.dtype == torch.float32 and lut.numel() == 256
+        n = len(images)
+        ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in images])
+        strides = (C.c_int64 * n)(*[im.stride(0) for im in images])
+        L.check(self.lib.dl_tile_gather_u8(ptrs, strides, n, H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(lut), dl_dtype(out),
+                                           _ptr(out), pstride(out), out.shape[3], _stream(out)), 'dl_tile_gather_u8')
+
+    def tile_gray_stats(self, image, H0, W0, origins, tile, pad, pad_rgb, stats):
+        _need_cuda(image, origins, stats)
+        assert stats.dtype == torch.int64 and stats.is_contiguous() and stats.shape == (origins.shape[0], 3)
+        L.check(self.lib.dl_tile_gray_stats_u8(_ptr(image), image.stride(0), H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(stats),
+                                               _stream(image)), 'dl_tile_gray_stats_u8')
+
+    def tile_paste(self, tiles, tile, rects, dst):
+        _need_cuda(tiles, rects, dst)
+        assert rects.dtype == torch.int32 and rects.is_contiguous() and rects.shape[1] == 8
+        assert dst.dtype == torch.uint8 and dst.stride(2) == 1 and dst.stride(1) == 3
+        if tiles is None:
+            dt, tp, ps = L.DL_F32, None, 8
+        else:
+            dt, tp, ps = dl_dtype(tiles), _ptr(tiles), pstride(tiles)
+        L.check(self.lib.dl_tile_paste_u8(dt, tp, ps, tile, _ptr(rects), rects.shape[0], _ptr(dst), dst.stride(0), _stream(dst)), 'dl_tile_paste_u8')
 
     # ---- losses
     def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 100
+#define DL_VERSION 101
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -245,6 +245,35 @@ int dl_loss(int kind, int dtype, const void *x, int x_pstride, const void *targe
  * ---------------------------------------------------------------------------------------------------------- */
 int dl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Tiles: the crop / is_empty / stitch steps either side of the generator DAG, on uint8 RGB images resident in HBM
+ * ([H][W][3] bytes, `row_stride` bytes between rows).  Integer and byte work, bit-exact with the reference:
+ *   dl_tile_gather_u8     InferenceTiler.__iter__ crop (deepliif/util/__init__.py:258-270, incl. the mirror extension of images smaller
+ *                         than a patch :196-211 and the solid border `pad` :268-269) fused with transform()
+ *                         (deepliif/data/__init__.py:133-138: ToTensor + Normalize(0.5, 0.5); `lut[v]` = float32((v/255 - 0.5)/0.5), 256
+ *                         entries supplied by the caller) -> an engine tile batch [n_tiles][tile][tile][Cp]; up to DL_TILE_MAX_SRC source
+ *                         images are concatenated on the channel axis (multi-input models, deepliif/models/__init__.py:276-279).
+ *                         origins: device int32 [n_tiles][2] = (x, y) of each tile in the (mirror-extended) image; H0, W0 = the image's
+ *                         real size.
+ *   dl_tile_gray_stats_u8 is_empty()'s statistic (deepliif/models/__init__.py:391-396 -> util/__init__.py:478-486 image_variance_gray
+ *                         -> PIL convert('L')): stats[t] = {count, sum, sum of squares} of the gray values in 1..254 of tile t (uint64);
+ *                         variance < 9  <=>  count == 0 or count*sumsq - sum^2 < 9*count^2, evaluated by the caller in integers.
+ *   dl_tile_paste_u8      tensor2im() (deepliif/util/util.py:117-135: (x + 1) / 2 * 255 in fp32, truncated to uint8) fused with
+ *                         InferenceTiler.stitch (util/__init__.py:272-320): rects = device int32 [n_rects][8] =
+ *                         {slot, l, t, w, h, px, py, rgb}: copy the w x h window at (l, t) of tile `slot` of the batch to (px, py) of the
+ *                         result image; slot < 0 pastes the constant colour rgb (r | g<<8 | b<<16) instead (empty tiles,
+ *                         deepliif/models/__init__.py:399-440).  The caller resolves overlapping pastes (last writer wins) into
+ *                         disjoint rectangles, so the launch is order-independent.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define DL_TILE_MAX_SRC 4
+int dl_tile_gather_u8(const void *const *imgs /*host array of device pointers*/, const int64_t *row_strides /*host*/, int n_src, int H0, int W0,
+                      const int32_t *origins, int n_tiles, int tile, int pad, uint32_t pad_rgb, const float *lut, int out_dtype, void *out,
+                      int out_pstride, int out_cp, void *stream);
+int dl_tile_gray_stats_u8(const void *img, int64_t row_stride, int H0, int W0, const int32_t *origins, int n_tiles, int tile, int pad,
+                          uint32_t pad_rgb, uint64_t *stats, void *stream);
+int dl_tile_paste_u8(int in_dtype, const void *tiles, int in_pstride, int tile, const int32_t *rects, int n_rects, void *dst,
+                     int64_t dst_row_stride, void *stream);
 
 /* hardware probes used by the GPU test-suite (MFMA fragment layouts, ds_read_b64_tr_b16 semantics) */
 int dl_probe_mfma16(const uint16_t *a /*16x32 bf16 row-major*/, const uint16_t *b /*32x16*/, float *d /*16x16*/, void *stream);

@@ -309,6 +309,49 @@ class FakeBackend:
         p.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
 
 
+    # ---- tiles (include/deepliif_hip.h dl_tile_*): written from the header's formulas, not from the oracle
+    @staticmethod
+    def _tile_pixels(img, H0, W0, ox, oy, tile, pad, pad_rgb):
+        import numpy as np
+        a = img.numpy()
+        patch = tile - 2 * pad
+        out = np.empty((tile, tile, 3), dtype=np.uint8)
+        out[...] = [pad_rgb & 255, (pad_rgb >> 8) & 255, (pad_rgb >> 16) & 255]
+
+        def mirror(c, n):
+            m = c % (2 * n)
+            return np.where(c < n, c, np.where(m < n, m, 2 * n - 1 - m))
+        sy = mirror(oy + np.arange(patch), H0)
+        sx = mirror(ox + np.arange(patch), W0)
+        out[pad:pad + patch, pad:pad + patch] = a[sy][:, sx]
+        return out
+
+    def tile_gather(self, images, H0, W0, origins, tile, pad, pad_rgb, lut, out):
+        self._count('tile_gather')
+        out.zero_()
+        for t, (ox, oy) in enumerate(origins.tolist()):
+            for s, im in enumerate(images):
+                px = self._tile_pixels(im, H0, W0, ox, oy, tile, pad, pad_rgb)
+                out[t, :, :, 3 * s:3 * s + 3] = lut[torch.from_numpy(px.astype('int64'))].to(out.dtype)
+
+    def tile_gray_stats(self, image, H0, W0, origins, tile, pad, pad_rgb, stats):
+        self._count('tile_gray_stats')
+        for t, (ox, oy) in enumerate(origins.tolist()):
+            px = torch.from_numpy(self._tile_pixels(image, H0, W0, ox, oy, tile, pad, pad_rgb).astype('int64'))
+            g = (19595 * px[..., 0] + 38470 * px[..., 1] + 7471 * px[..., 2] + 0x8000) >> 16
+            v = g[(g != 0) & (g != 255)]
+            stats[t, 0], stats[t, 1], stats[t, 2] = v.numel(), int(v.sum()), int((v * v).sum())
+
+    def tile_paste(self, tiles, tile, rects, dst):
+        self._count('tile_paste')
+        for slot, l, t, w, h, px, py, rgb in rects.tolist():
+            if slot < 0:
+                dst[py:py + h, px:px + w] = torch.tensor([rgb & 255, (rgb >> 8) & 255, (rgb >> 16) & 255], dtype=torch.uint8)
+                continue
+            v = tiles[slot, t:t + h, l:l + w, :3].float()
+            dst[py:py + h, px:px + w] = (((v + 1.0) * 0.5) * 255.0).to(torch.int32).to(torch.uint8)
+
+
 def install():
     """Route deepliif_amd.ops through the CPU emulation (tests only); returns the backend for call counting."""
     fb = FakeBackend()

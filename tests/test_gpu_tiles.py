@@ -1,0 +1,180 @@
+"""GPU parity of the tile kernels (dl_tile_gather_u8 / dl_tile_gray_stats_u8 / dl_tile_paste_u8, through the C ABI) and of the
+batched, tile-parallel inference loop built on them, against the tiling oracle (pinned to the reference's InferenceTiler by
+test_oracle_tiler.py) and the network oracle.  Integer / byte work: bit-exact; the float -> uint8 truncation of network outputs
+is compared exactly wherever the oracle's float value is not within the engine's fp32-policy error of an integer."""
+import hashlib
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import synth_image, tiler_result_tiles
+from oracle import deepliif_oracle as O
+from oracle import tiler_oracle as T
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tiler_cases.npz'))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _engine_from_u8(t_u8, dtype):
+    """engine-layout tensor whose tensor2im is exactly t_u8 (value (2 v + 1) / 255 - 1 sits mid-way between two truncation steps)"""
+    x = (torch.from_numpy(t_u8.astype(np.float32)) * 2 + 1) / 255 - 1
+    out = torch.zeros(t_u8.shape[:-1] + (8,), dtype=torch.float32)
+    out[..., :3] = x
+    return out.to(dtype).cuda()
+
+
+@pytest.mark.parametrize('tag', sorted({k.split('/')[0] for k in Z.files if k.endswith('/geom')}))
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gather_and_paste_match_reference_fixture(tag, dtype):
+    """the reference's own stitched images (tests/golden/tiler_cases.npz) reproduced on the GPU: crop (+ mirror / pad) -> the same
+    synthetic per-tile 'outputs' -> tensor2im + paste"""
+    from deepliif_amd import tiling as TL
+    w, h, tile, overlap, pad, seed = (int(v) for v in Z[f'{tag}/meta'])
+    img = synth_image(w, h, seed)
+    rt = TL.RegionTiler([torch.from_numpy(img).cuda()], tile, overlap, pad)
+    x = rt.gather(rt.tile_ids, dtype, 8)
+    lut = torch.from_numpy(TL.transform_lut())
+    g = T.TilerGeometry(w, h, tile, overlap, pad)
+    ext = T.mirror_to_patch(img, g.patch_size)
+    tiles = [T.extract_tile(ext, g, int(ox), int(oy)) for ox, oy in rt.plan.origins]
+    for i, t in enumerate(tiles):
+        exp = lut[torch.from_numpy(t.astype(np.int64))].to(dtype)
+        assert torch.equal(x[i, :, :, :3].cpu(), exp), f'tile {i}'
+        assert (x[i, :, :, 3:] == 0).all()
+    if dtype == torch.bfloat16:
+        return            # 8-bit mantissa cannot carry 256 distinct pixel values through tensor2im: the paste check runs in fp32
+    outs = [tiler_result_tiles(t) for t in tiles]
+    for k in ('A', 'B'):
+        batch = torch.stack([_engine_from_u8(o[k], dtype) for o in outs])
+        rt.paste(k, batch, rt.tile_ids)
+    res = rt.results()
+    for k in ('A', 'B'):
+        got = res[k].cpu().numpy()
+        assert list(got.shape) == Z[f'{tag}/res_shape/{k}'].tolist()
+        assert sha(got) == str(Z[f'{tag}/res_sha/{k}']), (tag, k)
+
+
+def test_tensor2im_kernel_matches_reference_vector():
+    from deepliif_amd import tiling as TL
+    t = torch.from_numpy(Z['t2i/in'])                        # [2, 3, 24, 24] incl. -1, 1, 0, +-0.999999
+    x = torch.zeros(1, 24, 24, 8)
+    x[0, :, :, :3] = t[0].permute(1, 2, 0)
+    rt = TL.RegionTiler([torch.zeros(24, 24, 3, dtype=torch.uint8).cuda()], 24, 0)
+    rt.paste('k', x.cuda(), [0])
+    assert np.array_equal(rt.results()['k'].cpu().numpy(), Z['t2i/out'])
+
+
+def test_is_empty_statistic_matches_reference_vector():
+    from deepliif_amd import tiling as TL
+    names = Z['empty/names'].tolist()
+    for i, n in enumerate(names):
+        t = torch.from_numpy(Z['empty/tiles'][i]).cuda()
+        rt = TL.RegionTiler([t], 64, 0)
+        assert rt.empty_mask().tolist() == [bool(Z['empty/is_empty'][i])], n
+    # a full 512 x 512 noise tile: sums close to the 32-bit range inside one workgroup
+    rng = np.random.RandomState(3)
+    big = rng.randint(0, 256, (512, 512, 3)).astype(np.uint8)
+    stats = torch.empty((1, 3), dtype=torch.int64, device='cuda')
+    from deepliif_amd import ops
+    rt = TL.RegionTiler([torch.from_numpy(big).cuda()], 512, 0)
+    ops.impl().tile_gray_stats(rt.images[0], 512, 512, rt.origins, 512, 0, rt.pad_rgb, stats)
+    assert tuple(stats[0].tolist()) == T.gray_sums(big)
+
+
+def _opt(M=2):
+    return types.SimpleNamespace(model='DeepLIIF', modalities_no=M, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                 norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_512', input_no=1, scale_size=512,
+                                 modalities_names=['input1', 'mod1', 'mod2'], background_colors=[(201, 211, 208), (10, 10, 10)], gpu_ids=[0])
+
+
+def _oracle_region(img, nets, opt, tile, overlap, seg_w):
+    """per-tile N=1 oracle forwards + the oracle tiler; returns (stitched uint8, stitched distance-to-integer of the float values)"""
+    g = T.TilerGeometry(img.shape[1], img.shape[0], tile, overlap)
+    pos = g.positions()
+    sds = {k: {kk: vv.detach().cpu().clone() for kk, vv in n.state_dict().items()} for k, n in nets.items()}
+    from deepliif_amd import inference as I
+    colors = I.empty_tile_colors(opt)
+    M = opt.modalities_no
+    u8, margin = [], []
+    cache = {}
+    for x, y in pos:
+        if (x, y) in cache:
+            a, b = cache[(x, y)]
+            u8.append(a); margin.append(b)
+            continue
+        t = T.extract_tile(img, g, x, y)
+        if T.is_empty(t):
+            a = {k: np.broadcast_to(np.array(c, dtype=np.uint8), (tile, tile, 3)) for k, c in colors.items()}
+            b = {k: np.full((tile, tile, 3), 127, dtype=np.uint8) for k in colors}
+        else:
+            ts = torch.from_numpy(T.transform(t))
+            f = {f'G{i}': O.run_generator(opt.net_g, sds[f'G{i}'], ts, 'batch', 'zero') for i in range(1, M + 1)}
+            segs = {f'GS{i}': O.run_generator(opt.net_gs, sds[f'GS{i}'], f[f'G{i}'], 'batch', 'zero') for i in range(1, M + 1)}
+            segs['GS0'] = O.run_generator(opt.net_gs, sds['GS0'], ts, 'batch', 'zero')
+            f.update(segs)
+            f['GS'] = sum(seg_w[i] * segs[f'GS{i}'] for i in range(1, M + 1)) + seg_w[0] * segs['GS0']
+            a = {k: T.tensor2im(v.numpy()) for k, v in f.items()}
+            b = {}
+            for k, v in f.items():
+                fv = (np.transpose(v[0].numpy(), (1, 2, 0)) + 1) / 2.0 * 255.0
+                d = np.minimum(fv - np.floor(fv), np.ceil(fv) - fv)            # distance to the nearest integer, in uint8 steps
+                b[k] = np.minimum(d * 1000, 255).astype(np.uint8)              # in 1e-3 steps, saturating
+        cache[(x, y)] = (a, b)
+        u8.append(a); margin.append(b)
+    return T.stitch(g, pos, u8), T.stitch(g, pos, margin)
+
+
+@pytest.mark.parametrize('world', [1, 3])
+def test_tiled_inference_matches_oracle(world):
+    """BASELINE configs[4] in miniature: a 1100 x 700 image, 512 tiles with 32 overlap (6 tiles, clamped last row / column), one blank
+    area, 2 Resnet-9 + 3 UNet-512 generators (ngf 8), batches of 4, row bands over `world` ranks run one after another on this GPU."""
+    from deepliif_amd import inference as I
+    torch.manual_seed(1)
+    opt = _opt()
+    nets = I.build_generators(opt, torch.device('cuda', 0), 'fp32')
+    img = synth_image(1100, 700, 21)
+    img[:, 580:] = 244                                   # blank right part: the tiles that only see it are empty
+    seg_w = [0.4, 0.35, 0.25]
+    got = {}
+    for r in range(world):
+        bands, band = I.infer_region([torch.from_numpy(img).cuda()], 512, 32, nets, opt, seg_weights=seg_w, batch_size=4, rank=r, world=world)
+        for k, v in bands.items():
+            got.setdefault(k, np.zeros((700, 1100, 3), dtype=np.uint8))[band[0]:band[1]] = v.cpu().numpy()
+    expect, margin = _oracle_region(img, nets, opt, 512, 32, seg_w)
+    assert set(got) == set(expect)
+    for k in expect:
+        diff = got[k].astype(int) - expect[k].astype(int)
+        assert np.abs(diff).max() <= 1, k
+        # fp32 policy: network outputs within ~1e-4 of the oracle -> 0.013 uint8 steps; pixels further than 0.05 steps from an
+        # integer boundary must be IDENTICAL
+        safe = margin[k] >= 50
+        assert safe.mean() > 0.8
+        assert (diff[safe] == 0).all(), (k, int((diff[safe] != 0).sum()))
+
+
+def test_inference_seam_returns_reference_names():
+    """inference(PIL, ...) -> dict of PIL images keyed like deepliif.models.inference (mod names, 'Seg', '<mod>_s')"""
+    from PIL import Image
+    from deepliif_amd import inference as I
+    torch.manual_seed(2)
+    opt = _opt()
+    opt.net_gs = 'unet_64'
+    opt.scale_size = 64
+    nets = I.build_generators(opt, torch.device('cuda', 0), 'fp32')
+    img = Image.fromarray(synth_image(150, 100, 5))
+    res = I.inference(img, 64, 4, None, opt=opt, nets=nets, return_seg_intermediate=True, seg_weights=[0.5, 0.25, 0.25])
+    assert list(res) == ['mod1', 'mod2', 'Seg', 'mod0-input1_s', 'mod1-mod1_s', 'mod2-mod2_s'] or list(res) == ['mod1', 'mod2', 'Seg', 'mod0_s', 'mod1_s', 'mod2_s']
+    assert all(v.size == (150, 100) for v in res.values())
+    only = I.inference(img, 64, 4, None, opt=opt, nets=nets, seg_only=True, seg_weights=[0.5, 0.25, 0.25])
+    assert list(only) == ['Seg']
+    assert np.array_equal(np.asarray(only['Seg']), np.asarray(res['Seg']))
+    # tile size != network resolution: PIL resampling on the host either side of the batched generators
+    res32 = I.inference(img, 32, 2, None, opt=opt, nets=nets, mod_only=True)
+    assert list(res32) == ['mod1', 'mod2'] and res32['mod1'].size == (150, 100)
