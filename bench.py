@@ -7,8 +7,13 @@
 One "step" = model.set_input(batch) + model.optimize_parameters() of the DeepLIIF model
 (modalities_no=5, seg_gen=False -> 5 x ResnetGenerator-9block + 5 x NLayerDiscriminator(n=4), GAN + SmoothL1, Adam) on a
 batch of 8 synthetic 512x512x3 tiles per GPU that is already resident in HBM (BASELINE.json configs[2] per GPU; weak
-scaling).  `--workload infer` times the 9-generator inference DAG of configs[1] instead (4 Resnet-9 + 5 UNet-512, batch 8).
+scaling).  `--workload infer` times the 9-generator inference DAG of configs[1] instead (4 Resnet-9 + 5 UNet-512, batch 8);
+`--workload wsi` the tile-parallel whole-slide loop of configs[4] (synthetic uint8 region in HBM -> crop / is_empty / 9 generators
+on batches of 8 tiles / uint8 stitch; one "step" = one batch of 8 tiles per GPU, every rank owns a band of tile rows).
+Without torchrun, `--gpus N` (N > 1) re-executes itself under `python -m torch.distributed.run --nproc-per-node N`.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
+  strict_parity: the SAME workload timed on the strict policy (fp32 storage, split-bf16 x3 MFMA: the one the GPU tests assert at 1e-3
+                 against the oracle) plus the measured distance of the headline (bf16) policy from it on this very batch
   roofline     : dominant layer shape = the 3x3, 256->256 ch conv at 8x128x128 pixels (the 18 ResnetBlock convs of every Resnet-9
                  and, when training, their data-gradients); the kernel NAME is whatever the library dispatches for that
                  descriptor (dl_conv_kernel_name), per-launch time from events recorded on the launch stream around the host call
@@ -33,6 +38,7 @@ GF_PER_TILE_INFER = 1828.0
 GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 + 5 UNet-512 generators, 9 NLayerD) step
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = os.path.join('r01', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
 def make_opt(args, device_index, M=5, seg_gen=False):
@@ -42,7 +48,7 @@ def make_opt(args, device_index, M=5, seg_gen=False):
         w, lw = [0.25, 0.15, 0.25, 0.1, 0.25], [0.2] * 5
     return types.SimpleNamespace(
         model='DeepLIIF', name='bench', checkpoints_dir='/tmp/dl_amd_bench', gpu_ids=[device_index], is_train=True, phase='train',
-        continue_train=False, modalities_no=M, seg_gen=seg_gen, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=64, ndf=64,
+        continue_train=False, modalities_no=M, seg_gen=seg_gen, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=args.ngf, ndf=args.ngf,
         net_g='resnet_9blocks', net_gs='unet_512', net_d='n_layers', n_layers_D=4, norm=args.norm, no_dropout=True, init_type='normal',
         init_gain=0.02, padding='zero', upsample='convtranspose', gan_mode='vanilla', gan_mode_s='lsgan', optimizer='adam', lr_g=2e-4,
         lr_d=2e-4, beta1=0.5, lr_policy='linear', n_epochs=100, n_epochs_decay=100, epoch_count=0, seg_weights=w, loss_G_weights=lw,
@@ -103,10 +109,11 @@ def cpu_baseline_child(norm, size):
     A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
     B = [torch.rand(1, 3, size, size, generator=g) * 2 - 1 for _ in range(5)]
     om.set_input({'A': A, 'B': B})
-    # bounded sample of ~10-30 s of CPU work: whole steps until at least 10 s have been spent (2 steps on a 16-core host),
-    # at most 4; the per-step mean is reported
+    # bounded sample of ~10-30 s of CPU work (1 warm-up + >= 3 timed steps): whole steps at batch 1, the warm-up step is
+    # not counted; stops early only if the host is so slow that 3 steps would exceed ~45 s
+    om.optimize_parameters()
     times = []
-    while len(times) < 4 and (sum(times) < 10.0 or not times):
+    while len(times) < 3 and (sum(times) < 45.0 or not times):
         t0 = time.time()
         om.optimize_parameters()
         times.append(time.time() - t0)
@@ -130,7 +137,7 @@ def cpu_baseline(args):
             continue
         scale = (size * size) / float(args.size * args.size)
         return {'value': round(scale / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
-                'sample': f"{d.get('steps', 1)} optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, "
+                'sample': f"1 warm-up + {d.get('steps', 1)} timed optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, "
                           f"{size}x{size} tile, {d.get('total_seconds', d['seconds']):.1f} s of CPU work, {d['seconds']:.1f} s per step" + ('' if size == args.size else f' (scaled to {args.size}x{args.size}-tile units by pixel count)')}
     return {'value': None, 'unit': 'tiles/s', 'cores': usable_cores(), 'kind': 'port', 'sample': f'CPU oracle step did not finish within the time limit ({last})'}
 
@@ -142,145 +149,239 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=8, help='tiles per GPU per step')
     ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--ngf', type=int, default=64, help='generator / discriminator width; the contract line uses 64 (smaller values only for launch-path tests)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp32_bf16mma'])
     ap.add_argument('--norm', default='instance', choices=['instance', 'batch'])
-    ap.add_argument('--workload', default='train', choices=['train', 'train18', 'ext', 'infer'],
+    ap.add_argument('--workload', default='train', choices=['train', 'train18', 'ext', 'infer', 'wsi'],
                     help="train = BASELINE's 5G+5D step (the contract line); train18 = the real DeepLIIF configuration (modalities_no=4, seg_gen: "
                          '4 Resnet-9 + 5 UNet-512 generators + 9 discriminators, SURVEY 8d); ext = BASELINE configs[3], DeepLIIFExt with 2 modalities: '
-                         '2 Resnet-9 + 2 UNet-512 (9-channel input) generators, 2 + 2 discriminators (6 / 12 channels); infer = configs[1]')
+                         '2 Resnet-9 + 2 UNet-512 (9-channel input) generators, 2 + 2 discriminators (6 / 12 channels); infer = configs[1]; '
+                         'wsi = configs[4], tile-parallel whole-slide inference (synthetic uint8 region, 512 tiles, overlap 32)')
+    ap.add_argument('--region', type=int, default=20000, help='wsi workload: side of the synthetic square region in pixels')
+    ap.add_argument('--no-strict', action='store_true', help='skip the strict-parity (fp32 policy) leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.norm, args.size)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under torchrun: become `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one process per
+        # GPU over RCCL); rank 0 of that job prints the one JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+                                  '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     from deepliif_amd import distributed as D
     from deepliif_amd import models as M
     from deepliif_amd import ops
-    rank, world, local_rank = D.init_process_group_from_env('nccl')
+    backend = os.environ.get('DL_BENCH_BACKEND', 'nccl')         # 'gloo' + DL_BENCH_DRYRUN=1: launch-path test without GPUs (tests/test_bench_launch.py)
+    rank, world, local_rank = D.init_process_group_from_env(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dry = os.environ.get('DL_BENCH_DRYRUN') == '1'
+    if dry:
+        # launch-path test on a GPU-less machine: CPU tensors through the test-suite's emulated backend (tests/fake_backend.py); the numbers
+        # mean nothing and the line says so
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import fake_backend
+        fake_backend.install()
+        dev = torch.device('cpu')
+        M.BaseModel._device_from_opt = lambda self, opt: torch.device('cpu')
+        M.BaseModel._net_gpu_ids = lambda self: []
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
     sys.stdout = open(os.devnull, 'w')      # the model classes print like the reference does; the contract is ONE JSON line
-
-    torch.manual_seed(0)
-    opt = make_opt(args, local_rank)
     n, s = args.batch, args.size
 
     def synth(seed):
         g = torch.Generator().manual_seed(seed + 1000 * rank)       # distinct tiles per rank (data-parallel shards)
         return (torch.rand(n, 3, s, s, generator=g) * 2 - 1).to(dev)
 
-    if args.workload == 'train':
-        model = M.create_model(opt)
-        model.setup(opt)
-        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}
-
-        def step():
-            model.set_input(batch)
-            model.optimize_parameters()
-        gf_per_tile = GF_PER_TILE_TRAIN_5R5D
-        dom_shape = (n, s // 4, s // 4, 256)
-        workload = 'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
-    elif args.workload == 'ext':
-        opt = make_opt(args, local_rank, M=2, seg_gen=True)
-        opt.model, opt.net_ds = 'DeepLIIFExt', 'n_layers'
-        opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
-        model = M.create_model(opt)
-        model.setup(opt)
-        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(2)], 'BS': [synth(1255 + i) for i in range(2)], 'A_paths': ['synthetic']}
-
-        def step():
-            model.set_input(batch)
-            model.optimize_parameters()
-        # per tile: generators forward + 2x backward; every discriminator: 2 forwards + 2x2 backward in backward_D, 1 forward + 1 dgrad
-        # in backward_G = 8 forward-equivalents (the accounting SURVEY 8d uses for the 5G+5D figure: 40 x 21.8 for 5 D)
-        gf_per_tile = 3 * (2 * 396.4 + 2 * 49.2) + 8 * (2 * 21.8 + 2 * 22.6)
-        dom_shape = (n, s // 4, s // 4, 256)
-        workload = ('DeepLIIFExt train step, modalities_no=2: 2x Resnet-9block + 2x UNet-512 (9-ch in) generators, 2x NLayerD (6 ch) + 2x NLayerD '
-                    '(12 ch), GAN/LSGAN+SmoothL1+Adam (BASELINE configs[3])')
-    elif args.workload == 'train18':
-        opt = make_opt(args, local_rank, M=4, seg_gen=True)
-        model = M.create_model(opt)
-        model.setup(opt)
-        batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}      # 4 modalities + seg target
-
-        def step():
-            model.set_input(batch)
-            model.optimize_parameters()
-        gf_per_tile = GF_PER_TILE_TRAIN_18NETS
-        dom_shape = (n, s // 4, s // 4, 256)
-        workload = ('real DeepLIIF train step (modalities_no=4, seg_gen=True): 4x Resnet-9block + 5x UNet-512 generators, 4 + 5 NLayerD(n=4), '
-                    'GAN/LSGAN+SmoothL1+Adam (SURVEY 8d)')
-    else:
-        from deepliif_amd import inference as I
-        iopt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3,
-                                     ngf=64, norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_512', input_no=1,
-                                     modalities_names=['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], gpu_ids=[local_rank])
-        nets = I.build_generators(iopt, dev, args.precision)
-        tiles = synth(1234)
-
-        def step():
-            I.run_generators(tiles, nets, iopt, seg_weights=[0.25, 0.15, 0.25, 0.1, 0.25])
-        gf_per_tile = GF_PER_TILE_INFER
-        dom_shape = (n, s // 4, s // 4, 256)
-        workload = 'DeepLIIF inference, 4x Resnet-9block + 5x UNet-512 generators + weighted seg sum (BASELINE configs[1])'
-
-    timer = KernelTimer(ops.impl(), dom_shape)
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def build(precision):
+        """-> (step function, model or None, GF per tile, dominant conv shape, workload description) for args.workload on `precision`"""
+        torch.manual_seed(0)
+        a = argparse.Namespace(**vars(args))
+        a.precision = precision
+        dom = (n, s // 4, s // 4, 4 * args.ngf)
+        if args.workload == 'train':
+            opt = make_opt(a, local_rank)
+            model = M.create_model(opt)
+            model.setup(opt)
+            batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}
+            return (lambda: (model.set_input(batch), model.optimize_parameters())), model, GF_PER_TILE_TRAIN_5R5D, dom, \
+                'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
+        if args.workload == 'ext':
+            opt = make_opt(a, local_rank, M=2, seg_gen=True)
+            opt.model, opt.net_ds = 'DeepLIIFExt', 'n_layers'
+            opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
+            model = M.create_model(opt)
+            model.setup(opt)
+            batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(2)], 'BS': [synth(1255 + i) for i in range(2)], 'A_paths': ['synthetic']}
+            # per tile: generators forward + 2x backward; every discriminator: 2 forwards + 2x2 backward in backward_D, 1 forward + 1 dgrad
+            # in backward_G = 8 forward-equivalents (the accounting SURVEY 8d uses for the 5G+5D figure: 40 x 21.8 for 5 D)
+            return (lambda: (model.set_input(batch), model.optimize_parameters())), model, 3 * (2 * 396.4 + 2 * 49.2) + 8 * (2 * 21.8 + 2 * 22.6), dom, \
+                ('DeepLIIFExt train step, modalities_no=2: 2x Resnet-9block + 2x UNet-512 (9-ch in) generators, 2x NLayerD (6 ch) + 2x NLayerD '
+                 '(12 ch), GAN/LSGAN+SmoothL1+Adam (BASELINE configs[3])')
+        if args.workload == 'train18':
+            opt = make_opt(a, local_rank, M=4, seg_gen=True)
+            model = M.create_model(opt)
+            model.setup(opt)
+            batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}      # 4 modalities + seg target
+            return (lambda: (model.set_input(batch), model.optimize_parameters())), model, GF_PER_TILE_TRAIN_18NETS, dom, \
+                ('real DeepLIIF train step (modalities_no=4, seg_gen=True): 4x Resnet-9block + 5x UNet-512 generators, 4 + 5 NLayerD(n=4), '
+                 'GAN/LSGAN+SmoothL1+Adam (SURVEY 8d)')
+        from deepliif_amd import inference as I
+        iopt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3,
+                                     ngf=args.ngf, norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_512', input_no=1, scale_size=s,
+                                     modalities_names=['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], gpu_ids=[local_rank])
+        nets = I.build_generators(iopt, dev, precision)
+        sw = [0.25, 0.15, 0.25, 0.1, 0.25]
+        if args.workload == 'infer':
+            tiles = synth(1234)
+            return (lambda: I.run_generators(tiles, nets, iopt, seg_weights=sw)), None, GF_PER_TILE_INFER, dom, \
+                'DeepLIIF inference, 4x Resnet-9block + 5x UNet-512 generators + weighted seg sum (BASELINE configs[1])'
+        # wsi: one synthetic region, identical on every rank (seeded noise, so no tile is_empty); rank r infers its band of tile rows
+        R = args.region
+        g = torch.Generator(device=dev).manual_seed(77)
+        region = torch.randint(0, 256, (R, R, 3), dtype=torch.uint8, device=dev, generator=g)
+        state = {'bands': None}
+
+        def run(limit):
+            state['bands'] = I.infer_region([region], s, s // 16, nets, iopt, seg_weights=sw, batch_size=n, rank=rank, world=world, limit_tiles=limit)
+        return run, None, GF_PER_TILE_INFER, dom, \
+            (f'tile-parallel whole-slide inference: synthetic {R}x{R} uint8 region in HBM, tile {s}, overlap {s // 16}, crop + is_empty + 4x Resnet-9block '
+             f'+ 5x UNet-512 + uint8 stitch on the GPU, batches of {n} tiles, one band of tile rows per rank (BASELINE configs[4])')
+
+    def timed(step, warmup, steps, timer=None):
+        for _ in range(warmup):
+            step()
+        barrier()
+        if timer is not None:
+            timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.enabled = False
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    step, model, gf_per_tile, dom_shape, workload = build(args.precision)
+
+    # ---- strict-parity leg, part 1 (before any optimizer step): distance of the headline policy from the strict policy on this batch
+    strict = None
+    want_strict = (not args.no_strict) and args.precision != 'fp32' and args.workload in ('train', 'train18', 'ext')
+    if want_strict:
+        sstep, smodel, _, _, _ = build('fp32')
+        for mdl in (model, smodel):
+            mdl.set_input(mdl_batch(mdl, args, synth))
+            mdl.calculate_losses()
+        sync()
+        la, lb = model.get_current_losses(), smodel.get_current_losses()
+        img_err = 0.0
+        for k in [k for k in model.visual_names if k.startswith('fake_B')]:
+            if hasattr(model, k) and hasattr(smodel, k):
+                a_, b_ = getattr(model, k).float(), getattr(smodel, k).float()
+                img_err = max(img_err, float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30)))
+        loss_err = max(abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-3) for k in la)
+        strict = {'dtype': 'f32 storage, split-bf16x3 MFMA (fp32-class products)', 'asserted_vs_oracle': 'network outputs / step-0 losses <= 1e-3 '
+                  '(tests/test_gpu_networks.py, profiles/parity_errors_r02.json)',
+                  'headline_vs_strict': {'what': f'{args.precision} policy vs strict policy, same weights, this batch, before any update',
+                                         'generated_images_max_abs_over_max': round(img_err, 6), 'losses_max_rel': round(float(loss_err), 6)}}
+
+    if args.workload == 'wsi':
+        from deepliif_amd.tiling import TilePlan, split_rows
+        plan = TilePlan(args.region, args.region, s, s // 16)
+        rows = split_rows(len(plan.ys), world)
+        per_rank = min((r1 - r0) * len(plan.xs) for r0, r1 in rows)           # every rank processes the same number of tiles in the timed region
+        n_batches = min(args.steps, per_rank // n)
+        assert n_batches >= 1, 'region too small for this many ranks'
+        step(n * max(args.warmup, 1))
+        barrier()
+        t0 = time.perf_counter()
+        step(n * n_batches)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        args.steps = n_batches
+        timer = types.SimpleNamespace(mean_seconds=lambda: None, pairs=[], kernel='?')
+    else:
+        timer = KernelTimer(ops.impl(), dom_shape) if not dry else types.SimpleNamespace(mean_seconds=lambda: None, pairs=[], kernel='?', enabled=False)
+        dt = timed(step, args.warmup, args.steps, timer)
 
     tiles_total = args.steps * n * world
     value = tiles_total / dt
+
+    # ---- strict-parity leg, part 2: the same workload timed on the strict policy
+    if want_strict:
+        ssteps = max(5, min(args.steps, 8))
+        sdt = timed(sstep, 1, ssteps)
+        strict.update({'value': round(ssteps * n * world / sdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(sdt / ssteps * 1e3, 3), 'steps': ssteps, 'warmup': 1})
+        del smodel, sstep
+
     kt = timer.mean_seconds()
-    flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * 256 * 256 * 9
+    flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * (4 * args.ngf) * (4 * args.ngf) * 9
     roofline = None
-    traffic = None
+    traffic, traffic_note = None, None
     try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc.sh)
-        with open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_dominant_conv256.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', PMC_FILE)) as f:
             pmc = json.load(f)
             # counters belong to ONE kernel at ONE shape: report them only when that is what this run dispatched
-            same = (n, s, args.precision) == (8, 512, 'bf16') and timer.kernel != '?' and timer.kernel.split('<')[0] in pmc.get('kernel', '')
+            same = (n, s, args.precision, args.ngf) == (8, 512, 'bf16', 64) and timer.kernel != '?' and timer.kernel.split('<')[0] in pmc.get('kernel', '')
             traffic = pmc['traffic_bytes'] if same else None
+            traffic_note = (f'NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same kernel and shape '
+                            f'(profiles/{PMC_FILE}, collected with tools/gpu_pmc.sh on forward launches only)') if same else None
     except Exception:
         traffic = None
     if kt:
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': traffic, 'kernel': f'{timer.kernel} (256x256x64 tile, 8 waves): 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload != 'infer' else 'fwd only') + '; timed by events around the host call',
+                    'traffic': traffic, 'traffic_note': traffic_note,
+                    'kernel': f'{timer.kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload not in ('infer', 'wsi') else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
     out = {
         'metric': {'train': '512x512 tiles/s train-step (5G+5D)', 'train18': '512x512 tiles/s train-step (real DeepLIIF: 9 G + 9 D)', 'ext': '512x512 tiles/s train-step (DeepLIIFExt, 2 modalities: 4 G + 4 D)',
-                   'infer': '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)'}[args.workload],
+                   'infer': '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)', 'wsi': '512x512 tiles/s whole-slide inference (tile-parallel, crop + 9 generators + stitch)'}[args.workload],
         'value': round(value, 3), 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else ('f32(split-bf16x3 MFMA)' if args.precision == 'fp32' else 'f32 storage/bf16 MFMA'),
-        'data': 'synthetic U(-1,1) tiles (seeds 1234..), N(0,0.02) random-init weights (torch.manual_seed(0)), dropout off, VGG loss off',
-        'config': {'workload': workload, 'tile': f'{s}x{s}x3', 'batch_per_gpu': n, 'global_batch': n * world, 'norm': args.norm,
-                   'precision_policy': args.precision, 'parallelism': f'dp{world}'},
+        'data': 'synthetic U(-1,1) tiles (seeds 1234..), N(0,0.02) random-init weights (torch.manual_seed(0)), dropout off, VGG loss off' if args.workload != 'wsi'
+                else 'synthetic uint8 noise region (seed 77), N(0,0.02) random-init weights (torch.manual_seed(0))',
+        'config': {'workload': workload, 'tile': f'{s}x{s}x3', 'batch_per_gpu': n, 'global_batch': n * world, 'norm': args.norm if args.workload not in ('infer', 'wsi') else 'batch (per-sample statistics)',
+                   'precision_policy': args.precision, 'parallelism': f'dp{world}', 'rccl_ranks': world, 'backend': backend},
         'model_tflops': round(value * gf_per_tile / 1e3, 1),
         'model_frac_of_bf16_peak': round(value * gf_per_tile / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         'roofline': roofline,
+        'strict_parity': strict,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train':
+    if args.precision == 'bf16' and strict is not None:
+        out['dtype_note'] = ('headline dtype bf16 is the throughput policy (BASELINE.json quotes the target on bf16 MFMA); it does NOT meet the 1e-3 parity bar -- '
+                             'its measured distance from the strict policy is in strict_parity.headline_vs_strict; the strict policy (asserted at 1e-3 against '
+                             'the oracle by the GPU tests) is timed on the same workload in strict_parity.value')
+    if dry:
+        out['data'] = 'DRY RUN on CPU through the test emulation backend (launch-path check only; numbers are meaningless)'
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train' and not dry:
         out['cpu_baseline'] = cpu_baseline(args)
     else:
         out['cpu_baseline'] = None
@@ -293,6 +394,13 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def mdl_batch(model, args, synth):
+    """the synthetic batch of the workload for `model` (same seeds as the timed steps)"""
+    if args.workload == 'ext':
+        return {'A': synth(1234), 'B': [synth(1235 + i) for i in range(2)], 'BS': [synth(1255 + i) for i in range(2)], 'A_paths': ['synthetic']}
+    return {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}
 
 
 if __name__ == '__main__':

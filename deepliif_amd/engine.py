@@ -367,12 +367,19 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
 _DROPOUT_COUNTER = [0]
 
 
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def dropout(ctx: Ctx, x: Act, p: float, in_place: bool = False) -> Act:
     """nn.Dropout(p) in training mode.  The mask is a function of a per-call seed (torch's CPU RNG seeds the stream, so
     torch.manual_seed() makes runs repeatable); backward re-applies the same mask to the gradient."""
     be = ops.impl()
     _DROPOUT_COUNTER[0] += 1
-    seed = (int(torch.initial_seed()) * 1000003 + _DROPOUT_COUNTER[0]) & (2 ** 63 - 1)
+    # the rank is mixed in: replicas seeded identically (parameters are broadcast anyway) must not drop the same units on different tiles
+    seed = (int(torch.initial_seed()) * 1000003 + 7919 * _rank() + _DROPOUT_COUNTER[0]) & (2 ** 63 - 1)
+    assert not (in_place and ctx.tape is not None and x.needs_grad), 'in-place dropout would let the gradient through unmasked: use in_place=False when training'
     out = x.t if in_place else empty_like_act(x.t)
     be.dropout(x.t, out, p, seed)
     needs = ctx.tape is not None and x.needs_grad

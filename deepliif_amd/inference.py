@@ -325,12 +325,14 @@ def empty_tile_colors(opt, seg_only=False, mod_only=False) -> 'OrderedDict[str, 
     return res
 
 
-def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod_only=False, seg_weights=None, batch_size=8, rank=0, world=1):
+def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod_only=False, seg_weights=None, batch_size=8, rank=0, world=1,
+                 limit_tiles=None):
     """Tile loop of inference() (deepliif/models/__init__.py:496-500) for uint8 RGB image(s) [H, W, 3] resident in HBM, entirely on
     the GPU: crop + transform (dl_tile_gather_u8), is_empty (dl_tile_gray_stats_u8), the generator DAG on batches of `batch_size`
     tiles with per-sample normalisation, tensor2im + stitch (dl_tile_paste_u8).
     Tile-parallel over `world` ranks (BASELINE configs[4]): rank r owns a contiguous band of tile rows (tiling.split_rows) and
-    returns ({key: uint8 [band rows, W, 3]}, (y0, y1)); the bands of all ranks concatenate to the full result images."""
+    returns ({key: uint8 [band rows, W, 3]}, (y0, y1)); the bands of all ranks concatenate to the full result images.
+    limit_tiles (measurement only): stop after that many non-empty tiles of the band."""
     from .tiling import RegionTiler, TilePlan, split_rows
     scale = _get(opt, 'scale_size', tile_size)
     if tile_size != scale:
@@ -350,6 +352,8 @@ def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod
         for k, c in colors.items():
             tiler.paste(k, None, ids[empty].tolist(), const_rgb=c)
     work = ids[~empty].tolist()
+    if limit_tiles is not None:
+        work = work[:limit_tiles]
     cp = E.cpad(3 * len(images))
     for s in range(0, len(work), batch_size):
         chunk = work[s:s + batch_size]

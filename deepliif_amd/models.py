@@ -60,7 +60,33 @@ class BaseModel:
     def _device_from_opt(self, opt) -> torch.device:
         if not opt.gpu_ids:
             raise L.HipLibraryError('deepliif_amd models run on MI355X only: opt.gpu_ids must name a GPU (no CPU fallback)')
-        return torch.device('cuda:{}'.format(opt.gpu_ids[0]))
+        if self.is_train and len(opt.gpu_ids) > 1:
+            # the reference wraps every net in nn.DataParallel(net, gpu_ids) here (networks.py:136): one process scattering each batch.
+            # This engine is one process per GPU (torchrun / `deepliif trainlaunch`, networks.py:131-134) -- refuse rather than silently
+            # train on gpu_ids[0] only
+            raise NotImplementedError(f'single-process multi-GPU training (gpu_ids={list(opt.gpu_ids)}, nn.DataParallel in the reference) is not '
+                                      'supported: launch one process per GPU with torchrun (deepliif_amd.distributed)')
+        dev = torch.device('cuda:{}'.format(opt.gpu_ids[0]))
+        torch.cuda.set_device(dev)          # cli.py:250-256 does this before building the model; kernels launch on the tensors' device anyway
+        return dev
+
+    def _mark_net(self, tape, net):
+        """Tape marker in front of a network's FIRST forward node of a pass: reverse mode reaches it after the network's last weight
+        gradient of that pass, which is when its slice of the flat gradient can go on the wire (distributed.GradExchanger.ready)."""
+        if tape is None or not self.is_train:
+            return
+        params = [p for p in net.parameters()]
+        tape.record(lambda: self.exchange.ready(params))
+
+    def _sync_replicas(self):
+        """once, before the first step: broadcast parameters / BatchNorm buffers from rank 0 (what DistributedDataParallel does at
+        construction, networks.py:134)"""
+        if getattr(self, '_replicas_synced', False):
+            return
+        nets = [net for _, net in self._nets()]
+        for o in self.optimizers:
+            self.exchange.sync_parameters(o, nets)
+        self._replicas_synced = True
 
     def _net_gpu_ids(self):
         return self.gpu_ids
@@ -279,6 +305,7 @@ class DeepLIIFModel(BaseModel):
         M, S = self.opt.modalities_no, self.mod_id_seg
         self._fake = []
         for i, n in enumerate(self.model_names_g):
+            self._mark_net(tape, getattr(self, 'net' + n))
             f = getattr(self, 'net' + n).run(ctx, self._A)
             self._fake.append(f)
             setattr(self, f'fake_B_{i + 1}', E.from_engine(f))
@@ -286,6 +313,7 @@ class DeepLIIFModel(BaseModel):
             parts = []
             for i, n in enumerate(self.model_names_gs):
                 src = self._A if i == 0 else self._fake[i - 1]
+                self._mark_net(tape, getattr(self, 'net' + n))
                 s = getattr(self, 'net' + n).run(ctx, src)
                 parts.append(s)
                 setattr(self, f'fake_B_{S}_{i}', E.from_engine(s))
@@ -321,6 +349,8 @@ class DeepLIIFModel(BaseModel):
         M, S = self.opt.modalities_no, self.mod_id_seg
         wD = self.loss_D_weights
         cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
+        for net in self._d_nets():               # every discriminator runs twice below (fake, real): mark before the first use
+            self._mark_net(tape, net)
         for i, n in enumerate(self.model_names_d):
             pair = E.concat_channels(ctx, [self._A, self._fake[i].detach()])
             pred = getattr(self, 'net' + n).run(ctx, pair)
@@ -381,16 +411,19 @@ class DeepLIIFModel(BaseModel):
 
     def optimize_parameters(self):
         """DeepLIIF_model.py:431-467."""
+        self._sync_replicas()
         self.forward()
         self.set_requires_grad(self._d_nets(), True)
         self.optimizer_D.zero_grad()
+        self.exchange.begin(self.optimizer_D)
         self.backward_D()
-        self.exchange.all_reduce(self.optimizer_D)
+        self.exchange.finish(self.optimizer_D)       # cannot hide: D must be updated before backward_G runs it (DeepLIIF_model.py:431-467)
         self.optimizer_D.step()
         self.set_requires_grad(self._d_nets(), False)
         self.optimizer_G.zero_grad()
-        self.backward_G()
-        self.exchange.all_reduce(self.optimizer_G)
+        self.exchange.begin(self.optimizer_G)
+        self.backward_G()                            # each generator's slice goes on the wire as soon as its backward is done
+        self.exchange.finish(self.optimizer_G)
         self.optimizer_G.step()
 
     def calculate_losses(self):
@@ -498,11 +531,15 @@ class DeepLIIFExtModel(BaseModel):
         record = self.is_train if record is None else record
         tape = E.Tape() if record else None
         ctx = E.Ctx(self.precision, tape, training=record)
-        self._fake = [net.run(ctx, self._A) for net in self.netG]
+        self._fake = []
+        for net in self.netG:
+            self._mark_net(tape, net)
+            self._fake.append(net.run(ctx, self._A))
         self.fake_B = [E.from_engine(f) for f in self._fake]
         self._fake_s = []
         for i, net in enumerate(self.netGS):
             if net is not None:
+                self._mark_net(tape, net)
                 self._fake_s.append(net.run(ctx, E.concat_channels(ctx, [self._A, self._fake[0], self._fake[i]])))
         self.fake_BS = [E.from_engine(f) for f in self._fake_s]
         for i, t in enumerate(self.fake_B):
@@ -520,6 +557,8 @@ class DeepLIIFExtModel(BaseModel):
         tape = E.Tape()
         ctx = E.Ctx(self.precision, tape, training=True)
         cg, cs, M = self.criterionGAN_mod, self.criterionGAN_seg, self.mod_gen_no
+        for net in self._d_nets():
+            self._mark_net(tape, net)
         rc = self._cat_real(ctx)
         for i in range(M):
             pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i].detach()]))
@@ -559,16 +598,19 @@ class DeepLIIFExtModel(BaseModel):
         return [n for n in self.netD + self.netDS if n is not None]
 
     def optimize_parameters(self):
+        self._sync_replicas()
         self.forward()
         self.set_requires_grad(self._d_nets(), True)
         self.optimizer_D.zero_grad()
+        self.exchange.begin(self.optimizer_D)
         self.backward_D()
-        self.exchange.all_reduce(self.optimizer_D)
+        self.exchange.finish(self.optimizer_D)       # cannot hide: D must be updated before backward_G runs it (DeepLIIF_model.py:431-467)
         self.optimizer_D.step()
         self.set_requires_grad(self._d_nets(), False)
         self.optimizer_G.zero_grad()
-        self.backward_G()
-        self.exchange.all_reduce(self.optimizer_G)
+        self.exchange.begin(self.optimizer_G)
+        self.backward_G()                            # each generator's slice goes on the wire as soon as its backward is done
+        self.exchange.finish(self.optimizer_G)
         self.optimizer_G.step()
 
     def calculate_losses(self):

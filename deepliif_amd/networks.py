@@ -490,13 +490,14 @@ class GANLoss(nn.Module):
 
 
 def get_optimizer(optimizer_name):
-    """networks.py:46-53.  'adam' maps to the fused flat Adam kernel; anything else falls back to torch.optim (plumbing)."""
+    """networks.py:46-53.  'adam' maps to the fused flat Adam kernel; any other torch.optim class keeps its own (ATen) update rule on
+    a flat parameter set (optim.flat_optimizer) -- functional, not the MI355X hot path."""
+    from .optim import FusedAdam, flat_optimizer
     if optimizer_name.lower() == 'adam':
-        from .optim import FusedAdam
         return FusedAdam
     names = {n.lower(): n for n in dir(torch.optim) if n[0].isupper()}
     try:
-        return getattr(torch.optim, names[optimizer_name.lower()])
+        return flat_optimizer(getattr(torch.optim, names[optimizer_name.lower()]))
     except KeyError:
         raise NotImplementedError('optimizer [%s] is not found' % optimizer_name)
 

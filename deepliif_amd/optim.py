@@ -76,7 +76,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.step_count = 0
-        self.grad_scale = 1.0          # set to 1/world_size by the data-parallel driver (sum all-reduce)
+        self.dp_scale = 1.0          # set to 1/world_size by the data-parallel driver (sum all-reduce)
         self._pack_batch = None        # engine.PackBatch over this set's conv weights, built at the first step
 
     def zero_grad(self, set_to_none: bool = False):
@@ -90,7 +90,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.step_count += 1
         ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                             self.step_count, self.grad_scale)
+                             self.step_count, self.dp_scale)
         self.flat.bump_epoch()         # packed bf16 weight images are stale now (engine.ConvLayer.ensure_packed)
         # ... so rebuild the ones that exist in ONE launch instead of one launch per image at their next use (DL_PACK_BATCH=0
         # restores the lazy per-image path).  Measured in round 1 (rocprof, 3 steps x 2 optimizers): 6 batched launches x 302 us
@@ -104,3 +104,32 @@ class FusedAdam(torch.optim.Optimizer):
             from . import engine            # (engine does not import optim: no cycle, but keep the import local to the hot path's owner)
             self._pack_batch = engine.PackBatch(self.flat.params)
         self._pack_batch.run()
+
+
+def flat_optimizer(cls):
+    """`--optimizer <name>` other than adam (networks.py:46-53 accepts any torch.optim class): the update rule stays torch.optim's
+    (ATen -- NOT an MI355X kernel, not the hot path), but the parameter set is flat like FusedAdam's so that the engine's gradient
+    writes (`p.grad` views of one buffer), zero_grad and the data-parallel exchange work unchanged."""
+
+    class Flat(cls):
+        def __init__(self, params, **kw):
+            params = list(params)
+            self.flat = FlatParams(params)
+            self.dp_scale = 1.0
+            super().__init__(params, **kw)
+
+        def zero_grad(self, set_to_none: bool = False):
+            self.flat.zero_grad()
+
+        @torch.no_grad()
+        def step(self, closure=None):
+            if not self.flat.attached():
+                raise RuntimeError('parameters were moved after the optimizer was built; rebuild the optimizer (FlatParams lost its views)')
+            if self.dp_scale != 1.0:
+                self.flat.grad.mul_(self.dp_scale)
+            out = super().step(closure)
+            self.flat.bump_epoch()
+            return out
+
+    Flat.__name__ = 'Flat' + cls.__name__
+    return Flat

@@ -1,7 +1,8 @@
 """The N>1 path on CPU: two processes, gloo backend, each running the DeepLIIFModel drop-in (emulated ops backend) on its own
-shard of the batch.  After optimize_parameters() with the flat-buffer sum-all-reduce + 1/world scaling in Adam, both ranks must
-hold identical weights, and those weights must equal a single-process run over the concatenated batch when the norm is
-per-sample (InstanceNorm) -- i.e. data parallelism is exact, not approximately right."""
+shard of the batch.  After optimize_parameters() with the per-network sum-all-reduces launched from the backward tape (overlapped
+with the rest of the backward pass) + 1/world scaling in Adam, both ranks must hold identical weights -- also when the replicas were
+seeded differently (one-time parameter broadcast) -- and those weights must equal a single-process run over the concatenated batch
+when the norm is per-sample (InstanceNorm): data parallelism is exact, not approximately right."""
 import os
 import socket
 import sys
@@ -50,11 +51,17 @@ def _worker(rank, world, port, out):
     torch.set_num_threads(2)
     from deepliif_amd import distributed as D
     D.init_process_group_from_env('gloo')
-    model = _build()
+    model = _build(seed=rank)       # replicas seeded DIFFERENTLY: the one-time broadcast from rank 0 must make them identical
     per = 4 // world
+    logs = []
     for _ in range(2):
         model.set_input(_batch(rank * per, (rank + 1) * per))
         model.optimize_parameters()
+        logs.append(list(model.exchange.launch_log))
+    # overlap: during backward_G every generator's slice went on the wire on its own, last-run generator first
+    flat = model.optimizer_G.flat
+    expect = [flat.slice_of(list(getattr(model, 'net' + n).parameters())) for n in reversed(model.model_names_g)]
+    assert logs[-1] == expect, (logs[-1], expect)
     torch.save(_flat(model), os.path.join(out, f'w{rank}.pt'))
     torch.distributed.destroy_process_group()
 
@@ -81,3 +88,59 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     # Adam's sign-like first steps amplify fp32 summation-order noise of near-zero gradients (tests/test_oracle_golden.py);
     # 2e-3 of |w| is 20% of the two-step update norm
     assert float((w0 - ws).norm() / ws.norm()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# tile-parallel inference (BASELINE configs[4]): every rank infers a band of tile rows, rank 0 concatenates the bands
+# ---------------------------------------------------------------------------------------------------------------------------
+def _wsi_setup():
+    import types
+    import fake_backend
+    from deepliif_amd import inference as I
+    from golden_util import synth_image
+    fake_backend.install()
+    torch.manual_seed(0)
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=1, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_32', input_no=1, scale_size=64,
+                                modalities_names=['input1', 'mod1'], background_colors=[(201, 211, 208)], gpu_ids=[])
+    nets = I.build_generators(opt, torch.device('cpu'), 'fp32')
+    img = synth_image(150, 230, 13)
+    img[:64] = 250                               # an empty first tile row
+    return I, opt, nets, torch.from_numpy(img)
+
+
+def _wsi_worker(rank, world, port, out):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from deepliif_amd import distributed as D
+    D.init_process_group_from_env('gloo')
+    I, opt, nets, img = _wsi_setup()
+    bands, band = I.infer_region([img], 64, 4, nets, opt, seg_weights=[0.5, 0.5], batch_size=3, rank=rank, world=world)
+    keys = sorted(I.empty_tile_colors(opt))
+    full = I.gather_bands(bands, band, img.shape[0], img.shape[1], keys, rank, world)
+    if rank == 0:
+        torch.save({k: v for k, v in full.items()}, os.path.join(out, 'wsi.pt'))
+    else:
+        assert full is None
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world', [2, 3])
+def test_tile_parallel_inference_bands_concatenate_to_the_single_process_result(tmp_path, world):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    mp.spawn(_wsi_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(tmp_path / 'wsi.pt')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    I, opt, nets, img = _wsi_setup()
+    single, band = I.infer_region([img], 64, 4, nets, opt, seg_weights=[0.5, 0.5], batch_size=3)
+    import fake_backend
+    fake_backend.uninstall()
+    assert band == (0, img.shape[0]) and set(single) == set(got)
+    for k, v in single.items():
+        assert torch.equal(v, got[k]), k        # per-sample normalisation: a tile's output does not depend on its batch mates

@@ -211,3 +211,29 @@ def test_fused_adam_repacks_existing_images_in_one_batch():
         assert fb.calls['pack'] > before
     finally:
         ops._impl, optim._PACK_BATCH = old, old_flag
+
+
+def test_non_adam_optimizer_runs_on_the_flat_parameter_set():
+    """--optimizer sgd (the reference's tests/test_cli_train.py exercises it): torch.optim's own update rule on a FlatParams set, so the
+    engine's gradient writes, zero_grad and the exchange keep working (p.grad used to be None after zero_grad)"""
+    torch.manual_seed(0)
+    opt = make_opt(1, False, 'batch')
+    opt.optimizer = 'sgd'
+    model = CpuModel(opt)
+    model.setup(opt)
+    assert type(model.optimizer_G).__name__ == 'FlatSGD' and model.optimizer_G.flat.attached()
+    before = torch.cat([p.detach().reshape(-1).clone() for p in model.netG1.parameters()])
+    A = seeded_uniform((2, 3, 64, 64), 1)
+    for _ in range(2):
+        model.set_input({'A': A, 'B': [seeded_uniform((2, 3, 64, 64), 2)], 'A_paths': ['x']})
+        model.optimize_parameters()
+    after = torch.cat([p.detach().reshape(-1) for p in model.netG1.parameters()])
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    assert all(p.grad is not None and p.grad.data_ptr() != 0 for p in model.netG1.parameters())
+
+
+def test_single_process_multi_gpu_training_is_refused():
+    opt = make_opt(1, False, 'batch')
+    opt.gpu_ids = [0, 1]
+    with pytest.raises(NotImplementedError, match='one process per GPU'):
+        M.DeepLIIFModel(opt)
