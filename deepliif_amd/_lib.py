@@ -13,7 +13,7 @@ PREC_BF16, PREC_BF16X3 = 1, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 NORM_INSTANCE, NORM_BATCH = 0, 1
-LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1, 2
+LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1 = 0, 1, 2, 3
 MAX_TAPS, MAX_PHASES = 64, 4
 
 i32 = C.c_int32
@@ -82,6 +82,9 @@ SIGNATURES = {
     'dl_reflect_fold': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
+    'dl_loss_acc': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _f, _i, _vp, _i, _f, _vp, _vp]),
+    'dl_maxpool2_forward': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    'dl_maxpool2_backward': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     'dl_tile_gather_u8': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _i, _vp, _i, _i, _vp]),
     'dl_tile_gray_stats_u8': (_i, [_vp, _i64, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _vp]),

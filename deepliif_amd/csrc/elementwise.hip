@@ -206,6 +206,10 @@ __global__ void __launch_bounds__(256) loss_kernel(int kind, const T *x, int x_p
             const float d = v - t;
             l = d * d;
             g = 2.f * d;
+        } else if (kind == DL_LOSS_L1) {
+            const float d = v - t;                       // nn.L1Loss: |d|, gradient sign(d) with sign(0) = 0
+            l = fabsf(d);
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         } else {
             const float d = v - t, ad = fabsf(d);
             l = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
@@ -228,24 +232,122 @@ __global__ void __launch_bounds__(256) loss_kernel(int kind, const T *x, int x_p
         }
     }
 }
-__global__ void loss_final_kernel(const float *part, int n, float inv_count, float *out) {
+__global__ void loss_final_kernel(const float *part, int n, float inv_count, float *out, float out_scale, int accumulate) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double s = 0.0;
         for (int i = 0; i < n; ++i) s += (double)part[i];
-        out[0] = (float)(s * (double)inv_count);
+        const float v = (float)(s * (double)inv_count) * out_scale;
+        out[0] = accumulate ? out[0] + v : v;
     }
 }
-extern "C" int dl_loss(int kind, int dtype, const void *x, int x_ps, const void *target, int t_ps, float tconst, int64_t npix, int C, int Cp,
-                       float *loss_out, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
+extern "C" int dl_loss_acc(int kind, int dtype, const void *x, int x_ps, const void *target, int t_ps, float tconst, int64_t npix, int C, int Cp,
+                           float *loss_out, float out_scale, int accumulate, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !loss_out || !ws || C <= 0 || C > Cp) DL_FAIL("dl_loss: bad argument");
-    if (kind < 0 || kind > 2) DL_FAIL("dl_loss: kind %d", kind);
+    if (kind < 0 || kind > 3) DL_FAIL("dl_loss: kind %d", kind);
     const float inv = 1.0f / (float)((double)npix * C);
     if (dtype == DL_F32) hipLaunchKernelGGL(loss_kernel<float>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const float *)x, x_ps, (const float *)target, t_ps, tconst, (size_t)npix, C, inv, (float *)grad, g_ps, gscale, Cp, ws);
     else hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const bf16_t *)x, x_ps, (const bf16_t *)target, t_ps, tconst, (size_t)npix, C, inv, (bf16_t *)grad, g_ps, gscale, Cp, ws);
     DL_CHECK_LAUNCH("dl_loss");
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, LOSS_BLOCKS, inv, loss_out);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, ws, LOSS_BLOCKS, inv, loss_out, out_scale, accumulate);
     DL_CHECK_LAUNCH("dl_loss(final)");
+    return 0;
+}
+extern "C" int dl_loss(int kind, int dtype, const void *x, int x_ps, const void *target, int t_ps, float tconst, int64_t npix, int C, int Cp,
+                       float *loss_out, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
+    return dl_loss_acc(kind, dtype, x, x_ps, target, t_ps, tconst, npix, C, Cp, loss_out, 1.0f, 0, grad, g_ps, gscale, ws, stream_);
+}
+
+// ------------------------------------------------------------------------------------------- 2x2 max pooling (VGG19 features)
+// nn.MaxPool2d(kernel_size=2, stride=2): y[n,ho,wo,c] = max over the 2x2 window; backward routes dy to the FIRST maximum of the window in
+// row-major window order (ATen's rule), everything else gets 0 (including a trailing odd row / column).  One thread = one window x 8 channels.
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T *__restrict__ x, int x_ps, T *__restrict__ y, int y_ps, int N, int H, int W, int Cp) {
+    const int Ho = H / 2, Wo = W / 2, cv = Cp / 8;
+    const long long total = (long long)N * Ho * Wo * cv;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv) * 8;
+        long long p = i / cv;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const T *b = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * x_ps + c8;
+        float a[8], q[8];
+        Vec8<T>::load(b, a);
+        Vec8<T>::load(b + x_ps, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], q[k]);
+        Vec8<T>::load(b + (long long)W * x_ps, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], q[k]);
+        Vec8<T>::load(b + (long long)W * x_ps + x_ps, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fmaxf(a[k], q[k]);
+        Vec8<T>::store(y + (((long long)n * Ho + ho) * Wo + wo) * y_ps + c8, a);
+    }
+}
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T *__restrict__ x, int x_ps, const T *__restrict__ dy, int dy_ps, T *__restrict__ dx, int dx_ps, int N, int H, int W, int Cp) {
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2, cv = Cp / 8;
+    const long long total = (long long)N * Hc * Wc * cv;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv) * 8;
+        long long p = i / cv;
+        const int wo = (int)(p % Wc); p /= Wc;
+        const int ho = (int)(p % Hc);
+        const int n = (int)(p / Hc);
+        const bool full = ho < Ho && wo < Wo;
+        float z[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = 0.f;
+        if (!full) {            // trailing odd row / column: no window covers it
+            for (int dh = 0; dh < 2; ++dh)
+                for (int dw = 0; dw < 2; ++dw) {
+                    const int h = 2 * ho + dh, w = 2 * wo + dw;
+                    if (h < H && w < W) Vec8<T>::store(dx + (((long long)n * H + h) * W + w) * dx_ps + c8, z);
+                }
+            continue;
+        }
+        const T *b = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * x_ps + c8;
+        float v[4][8], g[8], m[8];
+        Vec8<T>::load(b, v[0]);
+        Vec8<T>::load(b + x_ps, v[1]);
+        Vec8<T>::load(b + (long long)W * x_ps, v[2]);
+        Vec8<T>::load(b + (long long)W * x_ps + x_ps, v[3]);
+        Vec8<T>::load(dy + (((long long)n * Ho + ho) * Wo + wo) * dy_ps + c8, g);
+        int arg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m[k] = v[0][k]; arg[k] = 0;
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (v[j][k] > m[k]) { m[k] = v[j][k]; arg[k] = j; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = arg[k] == j ? g[k] : 0.f;
+            Vec8<T>::store(dx + (((long long)n * H + 2 * ho + (j >> 1)) * W + 2 * wo + (j & 1)) * dx_ps + c8, o);
+        }
+    }
+}
+extern "C" int dl_maxpool2_forward(int dtype, const void *x, int x_ps, void *y, int y_ps, int N, int H, int W, int Cp, void *stream) {
+    if (N <= 0 || H < 2 || W < 2 || Cp <= 0 || Cp % 8) DL_FAIL("dl_maxpool2_forward: empty problem or bad channel count (N=%d H=%d W=%d Cp=%d)", N, H, W, Cp);
+    const long long total = (long long)N * (H / 2) * (W / 2) * (Cp / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == DL_F32) hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)x, x_ps, (float *)y, y_ps, N, H, W, Cp);
+    else hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, x_ps, (bf16_t *)y, y_ps, N, H, W, Cp);
+    DL_CHECK_LAUNCH("dl_maxpool2_forward");
+    return 0;
+}
+extern "C" int dl_maxpool2_backward(int dtype, const void *x, int x_ps, const void *dy, int dy_ps, void *dx, int dx_ps, int N, int H, int W, int Cp, void *stream) {
+    if (N <= 0 || H < 2 || W < 2 || Cp <= 0 || Cp % 8) DL_FAIL("dl_maxpool2_backward: empty problem or bad channel count (N=%d H=%d W=%d Cp=%d)", N, H, W, Cp);
+    const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cp / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == DL_F32) hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)x, x_ps, (const float *)dy, dy_ps, (float *)dx, dx_ps, N, H, W, Cp);
+    else hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, x_ps, (const bf16_t *)dy, dy_ps, (bf16_t *)dx, dx_ps, N, H, W, Cp);
+    DL_CHECK_LAUNCH("dl_maxpool2_backward");
     return 0;
 }
 

@@ -450,12 +450,34 @@ def weighted_sum(ctx: Ctx, parts: List[Act], weights: List[float]) -> Act:
     return z
 
 
-def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: float, weight: float, loss_out: torch.Tensor) -> None:
-    """loss_out[0] = mean loss (unweighted, as the reference logs it); if x needs grad, d(weight*loss)/dx is queued."""
+def maxpool2(ctx: Ctx, x: Act) -> Act:
+    """nn.MaxPool2d(kernel_size=2, stride=2) (torchvision VGG19 features, networks.py:698-731)."""
+    be = ops.impl()
+    n, h, w, cp = x.t.shape
+    out = torch.empty((n, h // 2, w // 2, cp), dtype=x.t.dtype, device=x.t.device)
+    be.maxpool2_forward(x.t, out)
+    needs = ctx.tape is not None and x.needs_grad
+    y = Act(out, x.C, needs)
+    if needs:
+        def backward():
+            g = y.grad
+            y.grad = None
+            if g is None:
+                return
+            dx = empty_like_act(x.t)
+            be.maxpool2_backward(x.t, g, dx)
+            x.add_grad(dx)
+        ctx.tape.record(backward)
+    return y
+
+
+def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: float, weight: float, loss_out: torch.Tensor,
+            out_scale: float = 1.0, accumulate: bool = False) -> None:
+    """loss_out[0] (+)= out_scale * mean loss (unweighted by `weight`, as the reference logs it); if x needs grad, d(weight*loss)/dx is queued."""
     be = ops.impl()
     needs = ctx.tape is not None and x.needs_grad
     grad = empty_like_act(x.t) if needs else None
-    be.loss(kind, x.t, target.t if target is not None else None, target_const, x.C, loss_out, grad, weight)
+    be.loss(kind, x.t, target.t if target is not None else None, target_const, x.C, loss_out, grad, weight, out_scale, accumulate)
     if needs:
         def backward():
             x.add_grad(grad)

@@ -160,6 +160,15 @@ def build_generators(opt, device, precision: Optional[str] = None) -> 'OrderedDi
 _NETS_CACHE: Dict = {}
 
 
+def _device_for(opt) -> torch.device:
+    """every generator lives on ONE GPU: the first of opt.gpu_ids (the reference spreads net groups over them, models/__init__.py:201-211)"""
+    if not torch.cuda.is_available():
+        from . import _lib
+        raise _lib.HipLibraryError('deepliif_amd inference runs on MI355X only (no CPU fallback): no GPU is visible')
+    ids = _get(opt, 'gpu_ids', None)
+    return torch.device('cuda', ids[0] if ids else 0)
+
+
 def init_nets(model_dir, eager_mode=False, opt=None, phase='test'):
     """deepliif/models/__init__.py:158-219.  Returns {name: net}; every net is callable on a [N,C,H,W] tensor.
     TorchScript '<name>.pt' files are CUDA/ATen graphs and are not loaded here: the '<epoch>_net_<name>.pth' state_dicts
@@ -169,8 +178,7 @@ def init_nets(model_dir, eager_mode=False, opt=None, phase='test'):
         return _NETS_CACHE[key]
     if opt is None:
         opt = get_opt(model_dir, mode=phase)
-    device = torch.device('cuda', opt.gpu_ids[0] if _get(opt, 'gpu_ids', None) else 0)
-    nets = build_generators(opt, device, _get(opt, 'precision', None))
+    nets = build_generators(opt, _device_for(opt), _get(opt, 'precision', None))
     epoch = _get(opt, 'epoch', 'latest')
     for n, net in nets.items():
         path = os.path.join(model_dir, f'{epoch}_net_{n}.pth')
@@ -392,7 +400,7 @@ def gather_bands(local: Dict[str, torch.Tensor], band, height: int, width: int, 
 
 def _to_u8_device(img, device) -> torch.Tensor:
     a = np.asarray(img.convert('RGB') if img.mode != 'RGB' else img)
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return torch.from_numpy(np.array(a, dtype=np.uint8, order="C")).to(device)
 
 
 def _result_names(opt, results, seg_only, mod_only, return_seg_intermediate):

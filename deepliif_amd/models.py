@@ -70,6 +70,24 @@ class BaseModel:
         torch.cuda.set_device(dev)          # cli.py:250-256 does this before building the model; kernels launch on the tensors' device anyway
         return dev
 
+    def _make_vgg(self, opt):
+        """(lambda_feat, VGGLoss or None).  The reference builds VGGLoss() from DOWNLOADED torchvision weights (networks.py:701) and trains
+        with lambda_feat = 100 (options/__init__.py:67).  There is no network here: the weights come from a file (opt.vgg_weights or
+        $DEEPLIIF_VGG19_WEIGHTS, a torchvision vgg19 state_dict).  With lambda_feat > 0 and no file the objective would silently differ from
+        the reference's, so that is an error unless the caller opts out explicitly (opt.allow_no_vgg / DEEPLIIF_AMD_ALLOW_NO_VGG=1)."""
+        lam = float(_get(opt, 'lambda_feat', 0) or 0)
+        if lam <= 0:
+            return 0.0, None
+        path = networks.vgg_weights_path(opt)
+        if path:
+            return lam, networks.VGGLoss(path, self.device, self.precision.name)
+        if _get(opt, 'allow_no_vgg', False) or os.environ.get('DEEPLIIF_AMD_ALLOW_NO_VGG') == '1':
+            print('deepliif_amd: lambda_feat = %g but no VGG19 weight file was given: training WITHOUT the perceptual term (explicit opt-out)' % lam)
+            return 0.0, None
+        raise RuntimeError('lambda_feat = %g asks for the VGG19 perceptual loss (DeepLIIF_model.py:406-409), which needs torchvision\'s pretrained vgg19 weights; '
+                           'pass them as a file (opt.vgg_weights or DEEPLIIF_VGG19_WEIGHTS=/path/vgg19.pth), set lambda_feat = 0, or opt out with '
+                           'opt.allow_no_vgg / DEEPLIIF_AMD_ALLOW_NO_VGG=1' % lam)
+
     def _mark_net(self, tape, net):
         """Tape marker in front of a network's FIRST forward node of a pass: reverse mode reaches it after the network's last weight
         gradient of that pass, which is when its slice of the flat gradient can go on the wire (distributed.GradExchanger.ready)."""
@@ -258,8 +276,7 @@ class DeepLIIFModel(BaseModel):
             self.criterionGAN_mod = networks.GANLoss(opt.gan_mode).to(self.device)
             self.criterionGAN_seg = networks.GANLoss(opt.gan_mode_s).to(self.device)
             self.lambda_L1 = _get(opt, 'lambda_L1', 100.0)
-            if _get(opt, 'lambda_feat', 0):
-                print('deepliif_amd: the VGG19 perceptual loss (lambda_feat) is not part of the MI355X hot path; training uses GAN + SmoothL1')
+            self.lambda_feat, self.criterionVGG = self._make_vgg(opt)
             params_g = [p for n in self.model_names_g + self.model_names_gs for p in getattr(self, 'net' + n).parameters()]
             params_d = [p for n in self.model_names_d + self.model_names_ds for p in getattr(self, 'net' + n).parameters()]
             OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
@@ -271,6 +288,7 @@ class DeepLIIFModel(BaseModel):
                 self.optimizer_D = OptCls(params_d, lr=opt.lr_d)
             self.optimizers += [self.optimizer_G, self.optimizer_D]
             self.exchange = GradExchanger()
+            self._vgg_buf = torch.zeros(max(M, 1), dtype=torch.float32, device=self.device)
         self._tape_G: Optional[E.Tape] = None
 
     # ---------------------------------------------------------------------------------------------------------
@@ -388,10 +406,19 @@ class DeepLIIFModel(BaseModel):
             E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, wG[i] * self.lambda_L1, self._l1_raw(i))
         if self.seg_gen:
             E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_seg, self._Bseg, 0.0, wG[M - 1] * self.lambda_L1, self._l1_raw(M))
+        if self.criterionVGG is not None:
+            # DeepLIIF_model.py:406-421: loss_G_VGG_i * lambda_feat joins the modality terms; the seg image's VGG value is computed there
+            # too (:408-409) but never added to loss_G (:418-421), so it is not evaluated here
+            for i in range(M):
+                self.criterionVGG.run(ctx, self._fake[i], self._B[i], wG[i] * self.lambda_feat, self._vgg_buf[i:i + 1])
         tape.backward()
         self._tape_G = None
         # the reference logs loss_G_L1 already multiplied by lambda_L1 (:398-400)
         self._loss_buf[self._l1_slots] *= self.lambda_L1
+        if self.criterionVGG is not None:
+            self._vgg_buf *= self.lambda_feat
+            for i in range(M):
+                setattr(self, f'loss_G_VGG_{i + 1}', self._vgg_buf[i])
 
     def _l1_raw(self, i):
         M, S = self.opt.modalities_no, self.mod_id_seg
@@ -589,10 +616,22 @@ class DeepLIIFExtModel(BaseModel):
             E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, self.loss_G_weights[i] * self.lambda_L1, self._slot(f'G_L1_{i + 1}'))
         for i in range(len(self._fake_s)):
             E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_s[i], self._BS[i], 0.0, self.loss_GS_weights[i] * self.lambda_L1, self._slot(f'GS_L1_{i + 1}'))
+        vgg = getattr(self, 'criterionVGG', None)
+        if vgg is not None:                           # SDG_model.py:176-184 (DeepLIIFExt has the term commented out, DeepLIIFExt_model.py:257-265)
+            for i in range(M):
+                vgg.run(ctx, self._fake[i], self._B[i], self.loss_G_weights[i] * self.lambda_feat, self._slot(f'G_VGG_{i + 1}'))
         tape.backward()
         self._tape_G = None
         idx = [self._loss_index[n] for n in self.loss_names if '_L1_' in n]
         self._loss_buf[torch.tensor(idx, dtype=torch.long, device=self.device)] *= self.lambda_L1
+        vidx = [self._loss_index[n] for n in self.loss_names if '_VGG_' in n]
+        if vidx:
+            # reported like the reference does (value * lambda_feat); NaN, not a plausible-looking 0.0, when the term was not evaluated
+            sel = torch.tensor(vidx, dtype=torch.long, device=self.device)
+            if vgg is not None:
+                self._loss_buf[sel] *= self.lambda_feat
+            else:
+                self._loss_buf[sel] = float('nan')
 
     def _d_nets(self):
         return [n for n in self.netD + self.netDS if n is not None]
@@ -634,9 +673,9 @@ class SDGModel(DeepLIIFExtModel):
 
     def __init__(self, opt):
         opt.seg_gen = False
-        if _get(opt, 'lambda_feat', 0):
-            print('deepliif_amd: the VGG19 perceptual loss (lambda_feat) is not part of the MI355X hot path; training uses GAN + SmoothL1')
         super().__init__(opt)
+        if self.is_train:
+            self.lambda_feat, self.criterionVGG = self._make_vgg(opt)
 
     def _input_channels(self, opt):
         return opt.input_nc * _get(opt, 'input_no', 1)

@@ -456,6 +456,87 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
 
 
 # -------------------------------------------------------------------------------------------------------------
+# VGG19 perceptual loss (networks.py:698-743)
+# -------------------------------------------------------------------------------------------------------------
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']     # torchvision cfg 'E'
+VGG19_SLICE_ENDS = (2, 7, 12, 21, 30)       # Vgg19.slice1..5 = features[0:2], [2:7], [7:12], [12:21], [21:30] (networks.py:707-716)
+
+
+class Vgg19(EngineNet):
+    """torchvision.models.vgg19().features[0:30] as the reference slices it (networks.py:698-731), frozen.  `features` has torchvision's
+    module indices, so a torchvision `vgg19` state_dict ('features.N.weight' / '.bias'; classifier keys are ignored) loads directly:
+    the pretrained weights the reference downloads must be supplied as a FILE here (no network on the box): opt.vgg_weights or
+    $DEEPLIIF_VGG19_WEIGHTS.  Conv + ReLU run as one conv kernel with a ReLU epilogue; 2x2 max pooling is dl_maxpool2_*."""
+
+    def __init__(self):
+        super().__init__()
+        layers: List[nn.Module] = []
+        cin = 3
+        for v in VGG19_CFG:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers[:VGG19_SLICE_ENDS[-1]])
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def load_torchvision_state_dict(self, sd):
+        own = self.state_dict()
+        picked = {k: v for k, v in sd.items() if k in own}
+        missing = [k for k in own if k not in picked]
+        if missing:
+            raise KeyError(f'VGG19 weight file lacks {missing[:4]}... (expected torchvision vgg19 keys features.N.weight / .bias)')
+        self.load_state_dict(picked)
+
+    def _bind(self):
+        prog = []
+        for i, m in enumerate(self.features):
+            if isinstance(m, nn.Conv2d):
+                prog.append((i, E.ConvLayer(ConvSpec('conv', m.in_channels, m.out_channels, 3, 1, 1), m.weight, m.bias)))
+            elif isinstance(m, nn.MaxPool2d):
+                prog.append((i, None))
+        return prog
+
+    def run(self, ctx: E.Ctx, x: E.Act):
+        """-> [h_relu1 .. h_relu5] (networks.py:722-731)"""
+        outs, h = [], x
+        for i, layer in self._layers():
+            h = E.maxpool2(ctx, h) if layer is None else E.conv(ctx, h, layer, act=L.ACT_RELU)
+            if i + 2 in VGG19_SLICE_ENDS:            # the ReLU that closes a slice sits right after this conv
+                outs.append(h)
+        return outs
+
+
+class VGGLoss(nn.Module):
+    """networks.py:732-743: sum_i w_i * L1(vgg(x)_i, vgg(y)_i.detach()), w = [1/32, 1/16, 1/8, 1/4, 1]."""
+    weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def __init__(self, weights_path=None, device=None, precision=None):
+        super().__init__()
+        self.vgg = Vgg19()
+        if device is not None:
+            self.vgg.to(device)
+        if precision:
+            self.vgg.set_precision(precision)
+        if weights_path:
+            sd = torch.load(weights_path, map_location='cpu')
+            self.vgg.load_torchvision_state_dict(sd.get('state_dict', sd) if isinstance(sd, dict) else sd)
+
+    def run(self, ctx: E.Ctx, x: E.Act, y: E.Act, weight: float, loss_out: torch.Tensor):
+        """loss_out[0] = the VGG loss (unweighted); queues d(weight * loss)/dx on the tape.  The target features carry no gradient."""
+        fy = self.vgg.run(E.Ctx(ctx.prec, None, training=False), y.detach())
+        fx = self.vgg.run(ctx, x)
+        for i, (a, b) in enumerate(zip(fx, fy)):
+            E.loss_op(ctx, L.LOSS_L1, a, b, 0.0, weight * self.weights[i], loss_out, out_scale=self.weights[i], accumulate=i > 0)
+
+
+def vgg_weights_path(opt):
+    return getattr(opt, 'vgg_weights', None) or os.environ.get('DEEPLIIF_VGG19_WEIGHTS')
+
+
+# -------------------------------------------------------------------------------------------------------------
 # losses / optimiser / schedule
 # -------------------------------------------------------------------------------------------------------------
 class GANLoss(nn.Module):

@@ -362,13 +362,27 @@ class HipBackend:
         L.check(self.lib.dl_tile_paste_u8(dt, tp, ps, tile, _ptr(rects), rects.shape[0], _ptr(dst), dst.stride(0), _stream(dst)), 'dl_tile_paste_u8')
 
     # ---- losses
-    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
+    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
+        """loss_out[0] = (accumulate ? loss_out[0] : 0) + out_scale * mean loss; grad = grad_scale * d(mean loss)/dx"""
         _need_cuda(x, target, loss_out, grad)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         ws = WS.get('loss_ws', self.lib.dl_loss_ws_floats(), x.device)
-        L.check(self.lib.dl_loss(kind, dl_dtype(x), _ptr(x), pstride(x), _ptr(target), pstride(target) if target is not None else 8,
-                                 float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), _ptr(grad),
-                                 pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss')
+        L.check(self.lib.dl_loss_acc(kind, dl_dtype(x), _ptr(x), pstride(x), _ptr(target), pstride(target) if target is not None else 8,
+                                     float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale), 1 if accumulate else 0, _ptr(grad),
+                                     pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss_acc')
+
+    # ---- 2x2 max pooling (VGG19 features)
+    def maxpool2_forward(self, x, y):
+        _need_cuda(x, y)
+        n, h, w, cp = x.shape
+        assert tuple(y.shape) == (n, h // 2, w // 2, cp)
+        L.check(self.lib.dl_maxpool2_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), n, h, w, cp, _stream()), 'dl_maxpool2_forward')
+
+    def maxpool2_backward(self, x, dy, dx):
+        _need_cuda(x, dy, dx)
+        n, h, w, cp = x.shape
+        L.check(self.lib.dl_maxpool2_backward(dl_dtype(x), _ptr(x), pstride(x), _ptr(dy), pstride(dy), _ptr(dx), pstride(dx), n, h, w, cp, _stream()),
+                'dl_maxpool2_backward')
 
     # ---- optimiser
     def adam_step(self, p, g, m, v, lr, b1, b2, eps, step, gscale):

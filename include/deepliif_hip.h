@@ -35,7 +35,7 @@ enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
 enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3 };   /* LRELU slope 0.2 (networks.py:578,639) */
 enum { DL_PAD_ZERO = 0, DL_PAD_REFLECT = 1 };
 enum { DL_NORM_INSTANCE = 0, DL_NORM_BATCH = 1 };
-enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2 };
+enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L1 = 3 };
 
 #define DL_MAX_TAPS 64
 #define DL_MAX_PHASES 4
@@ -237,6 +237,17 @@ size_t dl_loss_ws_floats(void);
 int dl_loss(int kind, int dtype, const void *x, int x_pstride, const void *target, int t_pstride, float target_const,
             int64_t npix, int C, int Cp, float *loss_out, void *grad, int g_pstride, float grad_scale,
             float *ws, void *stream);
+/* same, with loss_out[0] = (accumulate ? loss_out[0] : 0) + out_scale * mean loss: the five weighted nn.L1Loss terms of VGGLoss
+ * (networks.py:732-743, DL_LOSS_L1) sum into one slot without a host round trip */
+int dl_loss_acc(int kind, int dtype, const void *x, int x_pstride, const void *target, int t_pstride, float target_const,
+                int64_t npix, int C, int Cp, float *loss_out, float out_scale, int accumulate, void *grad, int g_pstride, float grad_scale,
+                float *ws, void *stream);
+
+/* nn.MaxPool2d(kernel_size=2, stride=2) of torchvision's VGG19 `features` (networks.py:698-731 slices them): y [N, H/2, W/2, Cp];
+ * backward routes dy to the first maximum of each window in row-major window order (ATen's tie rule) and zeroes everything else. */
+int dl_maxpool2_forward(int dtype, const void *x, int x_pstride, void *y, int y_pstride, int N, int H, int W, int Cp, void *stream);
+int dl_maxpool2_backward(int dtype, const void *x, int x_pstride, const void *dy, int dy_pstride, void *dx, int dx_pstride,
+                         int N, int H, int W, int Cp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Adam over one flat fp32 parameter set (torch.optim.Adam semantics: networks.py:46-53, DeepLIIF_model.py:128-147;

@@ -238,6 +238,54 @@ def smooth_l1(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # seeded weights in the reference's RNG-consumption order (networks.py:84-139)
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# VGG19 perceptual loss  (networks.py:698-743; torchvision.models.vgg19().features[0:30])
+# ----------------------------------------------------------------------------------------------
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+VGG_SLICE_ENDS = (2, 7, 12, 21, 30)                 # Vgg19.slice1..5 (networks.py:707-716)
+VGG_WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)       # VGGLoss.weights (networks.py:736)
+
+
+def vgg19_features(sd: Dict[str, torch.Tensor], x: torch.Tensor):
+    """[h_relu1 .. h_relu5] of Vgg19.forward (networks.py:722-731) from a torchvision-keyed state_dict ('features.N.weight/bias')."""
+    outs, h, idx = [], x, 0
+    for v in VGG19_CFG:
+        if idx >= VGG_SLICE_ENDS[-1]:
+            break
+        if v == 'M':
+            h = F.max_pool2d(h, kernel_size=2, stride=2)
+            idx += 1
+        else:
+            h = F.relu(F.conv2d(h, sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias'], padding=1))
+            idx += 2
+        if idx in VGG_SLICE_ENDS:
+            outs.append(h)
+    return outs
+
+
+def vgg_loss(sd: Dict[str, torch.Tensor], x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """VGGLoss.forward (networks.py:738-743): sum_i w_i * mean|vgg(x)_i - vgg(y)_i.detach()|."""
+    fx, fy = vgg19_features(sd, x), vgg19_features(sd, y)
+    return sum(w * (a - b.detach()).abs().mean() for w, a, b in zip(VGG_WEIGHTS, fx, fy))
+
+
+def random_vgg19_state_dict(generator: Optional[torch.Generator] = None) -> 'OrderedDict[str, torch.Tensor]':
+    """Stand-in for the pretrained torchvision weights (a download): torchvision's own conv init, kaiming_normal_(fan_out, relu) with zero
+    biases, drawn from `generator` in module order -- keeps the 13-layer stack's activations O(1).  Keys = torchvision's."""
+    sd, cin, idx = OrderedDict(), 3, 0
+    for v in VGG19_CFG:
+        if idx >= VGG_SLICE_ENDS[-1]:
+            break
+        if v == 'M':
+            idx += 1
+            continue
+        std = math.sqrt(2.0 / (v * 9))
+        sd[f'features.{idx}.weight'] = torch.randn(v, cin, 3, 3, generator=generator) * std
+        sd[f'features.{idx}.bias'] = torch.zeros(v)
+        cin, idx = v, idx + 2
+    return sd
+
+
 def layer_table(arch: str, input_nc: int, output_nc: int = 3, nf: int = 64, norm: str = 'batch',
                 padding_type: str = 'zero', n_layers: int = 4):
     """Ordered (kind, key, ...) list of the parameterised layers of one network in nn.Module.apply() visiting order
@@ -337,7 +385,8 @@ class OracleConfig:
     def __init__(self, modalities_no=4, seg_gen=True, net_g='resnet_9blocks', net_gs='unet_512', norm='batch',
                  padding='zero', ngf=64, ndf=64, n_layers_D=4, gan_mode='vanilla', gan_mode_s='lsgan',
                  lambda_L1=100.0, lr_g=2e-4, lr_d=2e-4, beta1=0.5, seg_weights=None, loss_G_weights=None,
-                 loss_D_weights=None, input_nc=3, output_nc=3):
+                 loss_D_weights=None, input_nc=3, output_nc=3, lambda_feat=0.0):
+        self.lambda_feat = lambda_feat
         self.modalities_no = modalities_no
         self.seg_gen = seg_gen
         self.net_g = net_g
@@ -396,9 +445,10 @@ class OracleDeepLIIF:
     """Functional DeepLIIFModel: set_input / forward / backward_D / backward_G / optimize_parameters over
     reference-keyed state_dicts (one per network name).  torch autograd supplies the gradients."""
 
-    def __init__(self, cfg: OracleConfig, nets: Dict[str, Dict[str, torch.Tensor]], train_bn_running: bool = True):
+    def __init__(self, cfg: OracleConfig, nets: Dict[str, Dict[str, torch.Tensor]], train_bn_running: bool = True, vgg_sd=None):
         self.cfg = cfg
         self.nets = nets
+        self.vgg_sd = vgg_sd                    # torchvision-keyed VGG19 weights; required when cfg.lambda_feat > 0
         self.g_names, self.gs_names, self.d_names, self.ds_names = cfg.names()
         self.train_bn_running = train_bn_running
         self.losses: Dict[str, torch.Tensor] = {}
@@ -468,7 +518,7 @@ class OracleDeepLIIF:
         return total
 
     def loss_G(self):
-        """DeepLIIF_model.py:334-421 with the VGG term = 0.  The seg term is weighted by
+        """DeepLIIF_model.py:334-421 (VGG term only when cfg.lambda_feat > 0).  The seg term is weighted by
         loss_G_weights[modalities_no - 1]: the reference reuses the stale loop index `i` (:418-421)."""
         c, L = self.cfg, self.losses
         for i, n in enumerate(self.d_names):
@@ -479,9 +529,13 @@ class OracleDeepLIIF:
             L[f'G_L1_{i + 1}'] = smooth_l1(self.fake_B[i], self.real_B[i]) * c.lambda_L1
         if c.seg_gen:
             L['G_L1_S'] = smooth_l1(self.fake_seg, self.real_B[c.modalities_no]) * c.lambda_L1
+        vgg = [0.0] * c.modalities_no
+        if c.lambda_feat > 0:                   # :406-409; the seg image's VGG value (:408-409) never enters loss_G (:418-421)
+            vgg = [vgg_loss(self.vgg_sd, self.fake_B[i], self.real_B[i]) * c.lambda_feat for i in range(c.modalities_no)]
+            self.vgg_losses = [float(v.detach()) for v in vgg]
         total = 0.0
         for i in range(c.modalities_no):
-            total = total + (L[f'G_GAN_{i + 1}'] + L[f'G_L1_{i + 1}']) * c.loss_G_weights[i]
+            total = total + (L[f'G_GAN_{i + 1}'] + L[f'G_L1_{i + 1}'] + vgg[i]) * c.loss_G_weights[i]
         if c.seg_gen:
             total = total + (L['G_GAN_S'] + L['G_L1_S']) * c.loss_G_weights[c.modalities_no - 1]
         return total

@@ -281,7 +281,7 @@ class FakeBackend:
             m = ((ws >= 0) & (ws < w)).to(dy.dtype)
             D[..., k:cout * kw:kw] = dy[:, :, ws.clamp(0, w - 1)][..., :cout] * m[None, None, :, None]
 
-    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale):
+    def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
         self._count('loss')
         v = x[..., :C_real].float()
         t = target[..., :C_real].float() if target is not None else torch.full_like(v, target_const)
@@ -291,14 +291,33 @@ class FakeBackend:
         elif kind == L.LOSS_MSE:
             l = (v - t) ** 2
             g = 2 * (v - t)
+        elif kind == L.LOSS_L1:
+            l = (v - t).abs()
+            g = torch.sign(v - t)
         else:
             d = v - t
             l = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
             g = d.clamp(-1, 1)
-        loss_out[0] = l.mean()
+        loss_out[0] = (loss_out[0] if accumulate else 0.0) + out_scale * l.mean()
         if grad is not None:
             grad.zero_()
             grad[..., :C_real] = (g * grad_scale / v.numel()).to(grad.dtype)
+
+    def maxpool2_forward(self, x, y):
+        self._count('maxpool_fwd')
+        n, h, w, c = x.shape
+        v = x[:, :h // 2 * 2, :w // 2 * 2].float().reshape(n, h // 2, 2, w // 2, 2, c)
+        y.copy_(v.amax(dim=(2, 4)).to(y.dtype))
+
+    def maxpool2_backward(self, x, dy, dx):
+        self._count('maxpool_bwd')
+        n, h, w, c = x.shape
+        ho, wo = h // 2, w // 2
+        v = x[:, :ho * 2, :wo * 2].float().reshape(n, ho, 2, wo, 2, c).permute(0, 1, 3, 5, 2, 4).reshape(n, ho, wo, c, 4)
+        arg = v.argmax(dim=-1)                        # first maximum in row-major window order
+        g = torch.zeros_like(v).scatter_(-1, arg.unsqueeze(-1), dy.float().unsqueeze(-1))
+        dx.zero_()
+        dx[:, :ho * 2, :wo * 2] = g.reshape(n, ho, wo, c, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(n, ho * 2, wo * 2, c).to(dx.dtype)
 
     def adam_step(self, p, g, m, v, lr, b1, b2, eps, step, gscale):
         self._count('adam')

@@ -1,0 +1,42 @@
+"""Shared by the CPU (emulated backend) and GPU seam tests: rebuild the reference's checkpoint directories from the seeds stored in
+tests/golden/seam_cases.npz (weights are never stored; tests/golden/make_golden_seam.py), and compare uint8 result images."""
+import os
+import shutil
+
+import numpy as np
+import torch
+
+from golden_util import digest_close
+from oracle import deepliif_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+Z = np.load(os.path.join(G, 'seam_cases.npz'))
+
+
+def build_checkpoint_dir(tmp_path, tag, nf=8):
+    """<tmp>/<tag>/latest_net_<name>.pth + train_opt.txt exactly as the reference's save_networks / print_options left them"""
+    d = os.path.join(str(tmp_path), tag)
+    os.makedirs(d, exist_ok=True)
+    shutil.copy(os.path.join(G, f'seam_train_opt_{tag}.txt'), os.path.join(d, 'train_opt.txt'))
+    for name, seed, arch in zip(Z[f'{tag}/model_names'].tolist(), Z[f'{tag}/net_seeds'].tolist(), Z[f'{tag}/net_arch'].tolist()):
+        a, cin, pad = arch.split('|')
+        sd = O.random_state_dict(a, int(cin), 3, nf, 'batch', pad, 4, generator=torch.Generator().manual_seed(int(seed)))
+        assert list(sd.keys()) == Z[f'{tag}/sd_keys/{name}'].tolist()
+        assert ['x'.join(str(x) for x in v.shape) for v in sd.values()] == Z[f'{tag}/sd_shapes/{name}'].tolist()
+        ok, msg = digest_close(torch.cat([v.reshape(-1).float() for v in sd.values() if v.is_floating_point()]), Z[f'{tag}/sd_digest/{name}'], 1e-12)
+        assert ok, (name, msg)
+        torch.save(sd, os.path.join(d, f'latest_net_{name}.pth'))
+    assert sorted(os.listdir(d)) == Z[f'{tag}/files'].tolist()
+    return d
+
+
+def close_u8(got, exp, max_mismatch):
+    """uint8 images produced through float -> uint8 TRUNCATION: a 1e-5 difference in the float flips a pixel that sits on an integer
+    boundary, so equality is 'never more than one step apart, and only in a small fraction of the pixels'"""
+    got, exp = np.asarray(got), np.asarray(exp)
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    d = np.abs(got.astype(int) - exp.astype(int))
+    assert d.max() <= 1, int(d.max())
+    frac = float((d != 0).mean())
+    assert frac <= max_mismatch, frac
+    return frac

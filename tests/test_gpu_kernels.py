@@ -508,7 +508,7 @@ def test_losses(precname):
     a = torch.zeros(2, 16, 16, 8); a[..., :3] = rnd((2, 16, 16, 3), 2, prec)
     b = torch.zeros(2, 16, 16, 8); b[..., :3] = rnd((2, 16, 16, 3), 3, prec) * 2
     for kind, t, tgt, C, const in ((L.LOSS_BCE_LOGITS, x, None, 1, 1.0), (L.LOSS_BCE_LOGITS, x, None, 1, 0.0), (L.LOSS_MSE, x, None, 1, 1.0),
-                                   (L.LOSS_SMOOTH_L1, a, b, 3, 0.0)):
+                                   (L.LOSS_SMOOTH_L1, a, b, 3, 0.0), (L.LOSS_L1, a, b, 3, 0.0)):
         lf, lr = torch.zeros(1), torch.zeros(1, device=DEV)
         gf = torch.empty(t.shape, dtype=prec.dtype)
         gr = torch.full(t.shape, 7.0, dtype=prec.dtype, device=DEV)
@@ -517,6 +517,44 @@ def test_losses(precname):
         sync()
         assert abs(float(lr) - float(lf)) < 1e-5 * max(1.0, abs(float(lf))), kind
         assert rel(gr, gf) < (1e-5 if precname == 'fp32' else 8e-3), kind
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_loss_accumulates_weighted_terms(precname):
+    """dl_loss_acc: loss_out[0] (+)= out_scale * mean -- the five weighted L1 terms of VGGLoss land in one slot (networks.py:738-743)"""
+    prec = Precision.get(precname)
+    real = hip()
+    a = torch.zeros(2, 16, 16, 8); a[..., :5] = rnd((2, 16, 16, 5), 2, prec)
+    b = torch.zeros(2, 16, 16, 8); b[..., :5] = rnd((2, 16, 16, 5), 3, prec)
+    out = torch.full((1,), 3.0, device=DEV)
+    real.loss(L.LOSS_L1, a.to(prec.dtype).to(DEV), b.to(prec.dtype).to(DEV), 0.0, 5, out, None, 1.0, out_scale=0.25, accumulate=False)
+    real.loss(L.LOSS_L1, a.to(prec.dtype).to(DEV), b.to(prec.dtype).to(DEV), 0.0, 5, out, None, 1.0, out_scale=2.0, accumulate=True)
+    sync()
+    exp = 2.25 * float((a.to(prec.dtype).float()[..., :5] - b.to(prec.dtype).float()[..., :5]).abs().mean())
+    assert abs(float(out) - exp) < 1e-5 * exp
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 8), (1, 37, 51, 64), (3, 8, 10, 128)])
+def test_maxpool2_forward_backward_against_torch(precname, shape):
+    """nn.MaxPool2d(2, 2) of the VGG19 features: values, floor mode on odd sizes, and ATen's first-maximum tie rule in backward (ties are the
+    NORM after a ReLU: whole windows of zeros)"""
+    prec = Precision.get(precname)
+    real = hip()
+    n, h, w, c = shape
+    x = torch.relu(rnd(shape, 5, prec)).to(prec.dtype)                  # ~half the entries are exactly 0
+    x[:, ::4, ::4] = x[:, 1::4, 1::4][:, :x[:, ::4, ::4].shape[1], :x[:, ::4, ::4].shape[2]]     # positive ties inside windows
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yt = torch.nn.functional.max_pool2d(xt, 2, 2)
+    dy = rnd((n, h // 2, w // 2, c), 6, prec).to(prec.dtype)
+    yt.backward(dy.float().permute(0, 3, 1, 2))
+    y = torch.empty((n, h // 2, w // 2, c), dtype=prec.dtype, device=DEV)
+    dx = torch.full(shape, 9.0, dtype=prec.dtype, device=DEV)
+    real.maxpool2_forward(x.to(DEV), y)
+    real.maxpool2_backward(x.to(DEV), dy.to(DEV), dx)
+    sync()
+    assert torch.equal(y.cpu().float(), yt.detach().permute(0, 2, 3, 1))
+    assert torch.equal(dx.cpu().float(), xt.grad.permute(0, 2, 3, 1))
 
 
 def test_adam_matches_torch():

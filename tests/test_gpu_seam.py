@@ -1,0 +1,99 @@
+"""The checkpoint-directory / inference seam on the MI355X against the REFERENCE's own outputs for the same directories
+(tests/golden/make_golden_seam.py): init_nets(model_dir) -> run_dask(PIL) / inference(PIL) -> uint8 images, for DeepLIIF, DeepLIIFExt
+and SDG.  fp32 policy: float outputs agree to ~1e-5, so the truncated uint8 bytes differ by at most one step in a fraction of a
+percent of the pixels (an exact-equality test would only measure how many float values sit on an integer boundary)."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from golden_util import synth_image
+from seam_util import Z, build_checkpoint_dir, close_u8
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(mdir, precision):
+    from deepliif_amd import inference as I
+    I._NETS_CACHE.clear()
+    opt = I.get_opt(mdir)
+    opt.ngf, opt.precision, opt.gpu_ids = 8, precision, [0]
+    return opt
+
+
+def _images():
+    img = Image.fromarray(synth_image(150, 100, 31))
+    a = np.asarray(img).copy()
+    a[:, :50] = 252
+    return img, Image.fromarray(a)
+
+
+def test_deepliif_checkpoint_dir_to_pil_bytes(tmp_path):
+    from deepliif_amd import inference as I
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    opt = _opt(mdir, 'fp32')
+    img, img2 = _images()
+    tile = img.crop((0, 0, 64, 64))
+    nets = I.init_nets(mdir, eager_mode=True, opt=opt)
+    assert list(nets) == ['G1', 'G2', 'GS0', 'GS1', 'GS2'] and all(next(n.parameters()).is_cuda for n in nets.values())
+    res = I.run_dask(tile, model_path=mdir, eager_mode=True, opt=opt)
+    assert list(res) == Z['dl_m2/run_dask_keys'].tolist()
+    worst = max(close_u8(v, Z[f'dl_m2/run_dask/{k}'], 0.005) for k, v in res.items())
+    for name, kw in (('inf', {}), ('inf_seginter', dict(return_seg_intermediate=True)), ('inf_modonly', dict(mod_only=True)), ('inf_segonly', dict(seg_only=True))):
+        r = I.inference(img2, 64, 4, mdir, eager_mode=True, opt=opt, **kw)
+        assert list(r) == Z[f'dl_m2/{name}_keys'].tolist(), name
+        for k, v in r.items():
+            exp = Z[f'dl_m2/{name}/{k}']
+            worst = max(worst, close_u8(v, exp, 0.005))
+            assert np.array_equal(np.asarray(v)[:, :36], exp[:, :36]), (name, k)
+    print('fp32 policy: worst fraction of pixels one uint8 step away from the reference:', worst)
+
+
+@pytest.mark.parametrize('tag', ['ext_m2', 'sdg_m2_in2'])
+def test_ext_and_sdg_checkpoint_dir_to_pil_bytes(tmp_path, tag):
+    from deepliif_amd import inference as I
+    mdir = build_checkpoint_dir(tmp_path, tag)
+    opt = _opt(mdir, 'fp32')
+    img, img2 = _images()
+    if tag == 'ext_m2':
+        res = I.run_dask(img.crop((0, 0, 64, 64)), model_path=mdir, eager_mode=True, opt=opt)
+        assert list(res) == Z[f'{tag}/run_dask_keys'].tolist()
+        for k, v in res.items():
+            close_u8(v, Z[f'{tag}/run_dask/{k}'], 0.005)
+        src = img2
+    else:
+        src = Image.fromarray(np.concatenate([np.asarray(img2), synth_image(150, 100, 32)], axis=1))
+    r = I.inference(src, 64, 4, mdir, eager_mode=True, opt=opt)
+    assert list(r) == Z[f'{tag}/inf_keys'].tolist()
+    for k, v in r.items():
+        close_u8(v, Z[f'{tag}/inf/{k}'], 0.005)
+
+
+def test_bf16_policy_stays_within_its_documented_distance(tmp_path):
+    """the throughput policy on the same directory: bf16 activations put the images a few uint8 steps away (DESIGN.md precision table)"""
+    from deepliif_amd import inference as I
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    opt = _opt(mdir, 'bf16')
+    _, img2 = _images()
+    r = I.inference(img2, 64, 4, mdir, eager_mode=True, opt=opt)
+    for k, v in r.items():
+        d = np.abs(np.asarray(v).astype(int) - Z[f'dl_m2/inf/{k}'].astype(int))
+        assert d.max() <= 12 and d.mean() < 1.5, (k, int(d.max()), float(d.mean()))
+
+
+def test_model_on_second_argument_device_uses_that_devices_stream():
+    """kernels must launch on the stream of the tensors' device, whatever the current device is (one visible GPU here: the
+    check is that selecting the device explicitly, from a thread whose current stream is a side stream, still works)"""
+    from deepliif_amd import inference as I
+    import types
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=1, seg_gen=False, mod_id_seg=None, input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_64', input_no=1, modalities_names=['input1', 'mod1'], gpu_ids=[0])
+    torch.manual_seed(0)
+    nets = I.build_generators(opt, torch.device('cuda', 0), 'fp32')
+    x = torch.rand(2, 3, 64, 64) * 2 - 1
+    ref = nets['G1'](x.cuda())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out = nets['G1'](x.cuda())
+    side.synchronize()
+    assert torch.equal(out, ref)

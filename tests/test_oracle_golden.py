@@ -219,3 +219,53 @@ def test_sdg_two_step_trajectory():
             flat = torch.cat([v.detach().reshape(-1).float() for v in nets[str(n)].values() if v.is_floating_point()])
             ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
             assert ok, f'step {s} weights of {n}: {msg}'
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# VGG19 perceptual term (tests/golden/make_golden_vgg.py: the reference's VGGLoss on a seeded stand-in for the downloaded weights)
+# ---------------------------------------------------------------------------------------------------------------------------
+VGG = np.load(os.path.join(G, 'vgg_cases.npz'))
+
+
+def _vgg_sd():
+    return O.random_vgg19_state_dict(torch.Generator().manual_seed(int(VGG['vgg_seed'])))
+
+
+@pytest.mark.parametrize('tag', ['s64', 's48x80'])
+def test_vgg_loss_value_gradient_and_features(tag):
+    sd = _vgg_sd()
+    shape = tuple(int(v) for v in VGG[f'{tag}/shape'])
+    x = seeded_uniform(shape, 71).requires_grad_(True)
+    y = seeded_uniform(shape, 72)
+    loss = O.vgg_loss(sd, x, y)
+    loss.backward()
+    assert abs(float(loss) - float(VGG[f'{tag}/loss'])) <= RTOL * float(VGG[f'{tag}/loss'])
+    assert rel_err(x.grad, VGG[f'{tag}/dx']) < RTOL
+    for i, f in enumerate(O.vgg19_features(sd, x.detach())):
+        assert list(f.shape) == VGG[f'{tag}/feat{i}_shape'].tolist()
+        ok, msg = digest_close(f, VGG[f'{tag}/feat{i}_digest'], RTOL)
+        assert ok, (i, msg)
+
+
+def test_step_with_vgg_term_follows_reference():
+    """the reference's DEFAULT training objective (lambda_feat = 100): GAN + SmoothL1 + VGG for the modalities, GAN + SmoothL1 for seg"""
+    names = [str(n) for n in VGG['step/model_names']]
+    cfg = O.OracleConfig(modalities_no=2, seg_gen=True, norm='batch', padding='zero', net_gs='unet_64', ngf=8, ndf=8, seg_weights=[1 / 3] * 3,
+                         loss_G_weights=VGG['step/loss_G_weights'].tolist(), loss_D_weights=[1 / 3] * 3, lambda_feat=100.0)
+    nets = {}
+    for n, seed in zip(names, VGG['step/net_seeds']):
+        arch, cin, pad = ('n_layers', 6, 'zero') if n.startswith('D') else (('resnet_9blocks', 3, 'zero') if n in ('G1', 'G2') else ('unet_64', 3, 'reflect'))
+        nets[n] = O.random_state_dict(arch, cin, 3, 8, 'batch', pad, 4, generator=torch.Generator().manual_seed(int(seed)))
+    om = O.OracleDeepLIIF(cfg, nets, vgg_sd=_vgg_sd())
+    A = seeded_uniform((2, 3, 64, 64), 22)
+    B = [seeded_uniform((2, 3, 64, 64), 23 + i) for i in range(3)]
+    for s in range(2):
+        om.set_input({'A': A, 'B': B})
+        om.optimize_parameters()
+        got = om.current_losses()
+        tol = RTOL if s == 0 else 2e-3
+        for k, exp in zip(VGG['step/loss_names'], VGG[f'step{s}/losses']):
+            assert abs(got[str(k)] - exp) <= tol * max(1.0, abs(exp)), (s, k, got[str(k)], exp)
+        assert np.allclose(om.vgg_losses, VGG[f'step{s}/vgg'], rtol=tol)
+        for i in range(2):
+            assert rel_err(om.fake_B[i].detach()[:, :, ::2, ::2], VGG[f'step{s}/fake_B_{i + 1}']) < (RTOL if s == 0 else 2e-2)
