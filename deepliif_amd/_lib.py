@@ -77,6 +77,8 @@ SIGNATURES = {
     'dl_channel_sum': (_i, [_i, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp]),
     'dl_nchw_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     'dl_nhwc_to_nchw': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    'dl_conv_narrow_supported': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    'dl_conv_narrow_forward': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'dl_shift_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'dl_shift_stack': (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'dl_reflect_fold': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -221,7 +221,11 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     hq, wq = (ho, wo) if spec.kind == 'conv' else (hi, wi)
     if spec.kind == 'convT':
         assert (ho, wo) == (2 * hi, 2 * wi)
-    if layer.narrow:
+    if layer.narrow and in_act == L.ACT_NONE and ctx.prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
+        # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
+        be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
+        nch = 0
+    elif layer.narrow:
         # T[n,h,w,(co,kw)] by the gather GEMM (vertical taps), then y = act(bias + sum_kw T[.., w+kw-pad, (co,kw)])
         T = torch.empty((n, ho, wo, cpad(spec.cout * spec.k)), dtype=torch.float32, device=x.t.device)
         be.conv_forward(layer.packed_fwd, x.t, T, ho, wo, None, L.ACT_NONE, in_act, ctx.prec.prec, raw_out=True)

@@ -39,6 +39,7 @@ def pstride(t: torch.Tensor) -> int:
 
 
 _SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
+_NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
 
@@ -312,6 +313,16 @@ class HipBackend:
         assert dst.dtype == torch.float32 and dst.is_contiguous()
         n, c, h, w = dst.shape
         L.check(self.lib.dl_nhwc_to_nchw(dl_dtype(src), _ptr(src), pstride(src), c0, _ptr(dst), n, c, h, w, _stream()), 'dl_nhwc_to_nchw')
+
+    # ---- narrow-Cout forward in one kernel (rolling input rows, csrc/conv_small.hip)
+    def conv_narrow_supported(self, x, cin_p, cout, k, pad, pad_mode, act=L.ACT_NONE) -> bool:
+        return act in (L.ACT_NONE, L.ACT_TANH) and bool(self.lib.dl_conv_narrow_supported(dl_dtype(x), cin_p, pstride(x), cout, k, k, pad, pad_mode)) and not _NO_NARROW_ROLL
+
+    def conv_narrow_forward(self, packed, x, out, cout, k, pad, bias, act):
+        _need_cuda(x, out, bias, packed.hi)
+        n, h, w, cp = x.shape
+        L.check(self.lib.dl_conv_narrow_forward(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), packed.plan.kstride, cout, k, k, pad, _ptr(bias), act,
+                                                _ptr(out), pstride(out), out.shape[3], _stream()), 'dl_conv_narrow_forward')
 
     # ---- narrow-Cout helpers
     def shift_sum(self, T, cout, kw, pad, pad_mode, bias, act, out):

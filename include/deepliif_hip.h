@@ -157,6 +157,14 @@ int dl_shift_sum(const float *T, int N, int H, int W, int Tc, int Cout, int KW, 
 int dl_shift_stack(int dtype, const void *dy, int dy_pstride, int N, int H, int W, int Cout, int KW, int pad, int pad_mode,
                    void *D, int Dc, void *stream);
 
+/* The same layer (64 -> Cout <= 4 channels, 7 x KW taps, zero padding, bf16) in ONE kernel: every input row is staged once and multiplies the
+ * packed weights of all kernel rows into rolling accumulator blocks, the kernel-column sum runs from LDS (csrc/conv_small.hip).  w_hi is the
+ * SAME stack_kw image (rows co*KW + kw, columns kh*Ci + ci).  dl_conv_narrow_supported() says whether a layer qualifies; the two-call form
+ * above remains for everything else (fp32 policy, reflection padding, other shapes). */
+int dl_conv_narrow_supported(int dtype, int Ci, int x_pstride, int Cout, int KH, int KW, int pad, int pad_mode);
+int dl_conv_narrow_forward(const void *x, int N, int H, int W, int Ci, int x_pstride, const void *w_hi, int w_kstride, int Cout, int KH, int KW,
+                           int pad, const float *bias, int act, void *out, int out_pstride, int out_Cp, void *stream);
+
 /* Backward of nn.ReflectionPad2d(pad) in front of a padding=0 Conv2d (ResnetGenerator with padding_type='reflect':
  * networks.py:386-388 stem, 478-481 / 495-498 ResnetBlock, 438-440 head).  The data gradient of such a layer is computed in two
  * steps: dl_conv_forward with the pad-0 data-gradient plan gives the gradient with respect to the explicitly padded input

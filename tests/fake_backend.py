@@ -232,6 +232,21 @@ class FakeBackend:
         C = dst.shape[1]
         dst.copy_(src[..., c0:c0 + C].permute(0, 3, 1, 2).float())
 
+    def conv_narrow_supported(self, x, cin_p, cout, k, pad, pad_mode, act=L.ACT_NONE):
+        return act in (L.ACT_NONE, L.ACT_TANH) and cout in (1, 3) and x.dtype == torch.bfloat16 and cin_p == 64 and k == 7 and cout <= 4 and pad == 3 and pad_mode == L.PAD_ZERO
+
+    def conv_narrow_forward(self, packed, x, out, cout, k, pad, bias, act):
+        # same mathematics as the two-call form: raw (co, kw) planes from the vertical taps, then the shifted sum over kw
+        self._count('conv_narrow')
+        n, h, w, _ = x.shape
+        T = torch.empty((n, h, w, packed.plan.rows_pad if False else ((cout * k + 7) // 8 * 8 if cout * k > 8 else 8)), dtype=torch.float32)
+        tc = 8
+        while tc < cout * k:
+            tc *= 2
+        T = torch.empty((n, h, w, tc), dtype=torch.float32)
+        self.conv_forward(packed, x, T, h, w, None, L.ACT_NONE, L.ACT_NONE, L.PREC_BF16, raw_out=True)
+        self.shift_sum(T, cout, k, pad, L.PAD_ZERO, bias, act, out)
+
     def shift_sum(self, T, cout, kw, pad, pad_mode, bias, act, out):
         self._count('shift_sum')
         n, h, w, _ = T.shape

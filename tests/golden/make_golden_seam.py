@@ -172,7 +172,7 @@ def main():
     for k, v in pil_u8(res).items():
         out[f'{tag}/run_dask_segonly/{k}'] = v
     a = np.asarray(img).copy()
-    a[:, :50] = 252                                     # an empty strip: run_wrapper's constant tiles
+    a[:, :70] = 252                                     # an empty strip: run_wrapper's constant tiles
     img2 = Image.fromarray(a)
     for name, kw in (('inf', {}), ('inf_seginter', dict(return_seg_intermediate=True)), ('inf_modonly', dict(mod_only=True)),
                      ('inf_segonly', dict(seg_only=True))):

@@ -543,7 +543,8 @@ def test_maxpool2_forward_backward_against_torch(precname, shape):
     real = hip()
     n, h, w, c = shape
     x = torch.relu(rnd(shape, 5, prec)).to(prec.dtype)                  # ~half the entries are exactly 0
-    x[:, ::4, ::4] = x[:, 1::4, 1::4][:, :x[:, ::4, ::4].shape[1], :x[:, ::4, ::4].shape[2]]     # positive ties inside windows
+    he, we = h // 2 * 2, w // 2 * 2
+    x[:, 0:he:4, 0:we:4] = x[:, 1:he:4, 1:we:4]                       # positive ties inside windows (top-left == bottom-right)
     xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     yt = torch.nn.functional.max_pool2d(xt, 2, 2)
     dy = rnd((n, h // 2, w // 2, c), 6, prec).to(prec.dtype)
@@ -611,6 +612,35 @@ def test_narrow_cout_head_conv(precname, pm):
     if pm == L.PAD_ZERO:
         assert rel(res['real']['dw'], res['fake']['dw']) < (1e-4 if precname == 'fp32' else 2e-3)
         assert rel(res['real']['db'], res['fake']['db']) < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(2, 70, 130), (1, 16, 58), (1, 150, 64), (3, 33, 59), (1, 512, 512)])
+@pytest.mark.parametrize('cout,act', [(3, L.ACT_TANH), (1, L.ACT_NONE)])
+def test_narrow_roll_kernel_against_torch(shape, cout, act):
+    """dl_conv_narrow_forward (rolling input rows, every kernel row at once, kernel-column sum from LDS) vs torch's conv2d on the same
+    bf16-rounded operands: several strips with a ragged last one, row bands with recomputed halo rows, images narrower than a strip."""
+    from deepliif_amd import engine as E
+    n, h, w = shape
+    prec = Precision.get('bf16')
+    real = hip()
+    spec = ConvSpec('conv', 64, cout, 7, 1, 3, L.PAD_ZERO)
+    w0 = rnd((cout, 64, 7, 7), 11, prec, 0.05)
+    b0 = rnd((cout,), 12, Precision.get('fp32'), 0.1)
+    x0 = rnd((n, h, w, 64), 13, prec)
+    ref = torch.nn.functional.conv2d(x0.permute(0, 3, 1, 2), w0, b0, padding=3)
+    if act == L.ACT_TANH:
+        ref = torch.tanh(ref)
+    wp = torch.nn.Parameter(w0.clone().to(DEV))
+    layer = E.ConvLayer(spec, wp, torch.nn.Parameter(b0.clone().to(DEV)))
+    layer.ensure_packed(prec, need_dgrad=False)
+    xd = x0.to(torch.bfloat16).to(DEV)
+    assert real.conv_narrow_supported(xd, 64, cout, 7, 3, L.PAD_ZERO)
+    out = torch.full((n, h, w, 8), 5.0, dtype=torch.bfloat16, device=DEV)
+    real.conv_narrow_forward(layer.packed_fwd, xd, out, cout, 7, 3, layer.bias.detach(), act)
+    sync()
+    got = out.float().cpu()
+    assert (got[..., cout:] == 0).all(), 'padded channels must be written as zeros'
+    assert rel(got[..., :cout].permute(0, 3, 1, 2), ref) < 6e-3
 
 
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])

@@ -24,7 +24,7 @@ def _opt(mdir, precision):
 def _images():
     img = Image.fromarray(synth_image(150, 100, 31))
     a = np.asarray(img).copy()
-    a[:, :50] = 252
+    a[:, :70] = 252
     return img, Image.fromarray(a)
 
 
@@ -45,7 +45,7 @@ def test_deepliif_checkpoint_dir_to_pil_bytes(tmp_path):
         for k, v in r.items():
             exp = Z[f'dl_m2/{name}/{k}']
             worst = max(worst, close_u8(v, exp, 0.005))
-            assert np.array_equal(np.asarray(v)[:, :36], exp[:, :36]), (name, k)
+            assert np.array_equal(np.asarray(v)[:, :60], exp[:, :60]), (name, k)
     print('fp32 policy: worst fraction of pixels one uint8 step away from the reference:', worst)
 
 

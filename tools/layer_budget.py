@@ -57,7 +57,13 @@ def conv_case(name, kind, cin, cout, k, s, p, N, H, W, prec, n_fwd, n_dgrad, n_w
             T = torch.empty((N, ho, wo, cpad(cout * k)), dtype=torch.float32, device=DEV)
             out = torch.empty(N, ho, wo, cpad(cout), device=DEV, dtype=prec.dtype)
 
+            roll = prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x, cpad(cin), cout, k, p, L.PAD_ZERO)
+            res['fwd_path'] = 'dl_conv_narrow_forward (rolling rows)' if roll else 'dl_conv_forward(raw) + dl_shift_sum'
+
             def f():
+                if roll:
+                    be.conv_narrow_forward(pf, x, out, cout, k, p, b, act)
+                    return
                 be.conv_forward(pf, x, T, ho, wo, None, L.ACT_NONE, L.ACT_NONE, prec.prec, raw_out=True)
                 be.shift_sum(T, cout, k, p, L.PAD_ZERO, b, act, out)
         else:
