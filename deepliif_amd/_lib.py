@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
                 ('tap_dh', C.c_int8 * MAX_TAPS), ('tap_dw', C.c_int8 * MAX_TAPS),
                 ('pad_mode', i32), ('w_kstride', i32), ('w_rows', i32), ('act', i32),
-                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32)]
+                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32), ('ci_real', i32)]
 
 
 class WgradDesc(C.Structure):

@@ -1383,6 +1383,8 @@ __global__ void __launch_bounds__(256) conv_slab_reduce_kernel(const float *slab
     }
 }
 
+#include "conv_c4.h"
+
 // ------------------------------------------------------------------------------------------------ host dispatch
 template <typename TIn, typename TOut, int PREC, int BM, int BN, int BK, int WM, int WN>
 static int launch_conv(const ConvArgs &a0, hipStream_t stream) {
@@ -1428,6 +1430,7 @@ static int glds_tile_bm(const dl_conv_desc *d) {
 // benchmark label its roofline line from the dispatch itself instead of a string that goes stale when a default changes.
 extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (!d) return "(null)";
+    if (c4_eligible(d)) return "conv_c4_patch_kernel";
     const int bm = glds_tile_bm(d);
     if (bm == 0) return (d->in_dtype == DL_BF16) ? "conv_gemm_kernel<bf16>" : "conv_gemm_kernel<f32>";
     if (d->Co <= 16) return "conv_gemm_glds_kernel<256,16,32>";
@@ -1445,6 +1448,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
+    if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
     const int bm = glds_tile_bm(d);
     const int hw = d->Hq * d->Wq;
     if (bm == 0 || hw % bm) return 0;
@@ -1502,7 +1506,8 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
 
     int rc;
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
-    if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
+    if (c4_eligible(d)) rc = launch_conv_c4(a, d, stream);
+    else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_tile<float, float, 3>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_tile<float, float, 1>(a, stream);

@@ -198,6 +198,7 @@ def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, 
     d.pad_mode, d.w_kstride, d.w_rows = plan.pad_mode, plan.kstride, plan.rows_pad
     d.act, d.in_dtype, d.out_dtype, d.prec, d.splitk, d.in_act, d.bias_n = act, dtype, dtype, prec, splitk, in_act, bias_n
     d.raw_out = raw_out
+    d.ci_real = plan.cc_real
     return d
 
 

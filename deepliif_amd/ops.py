@@ -186,11 +186,19 @@ class HipBackend:
         n, hi, wi, cp = x.shape
         assert cp == plan.cc_pad, (cp, plan.cc_pad)
         _, ho, wo, cop = out.shape
-        if splitk is None:
+        auto_split = splitk is None
+        if auto_split:
             splitk = choose_splitk(plan, n, hq, wq, cop)
         d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, pstride(out), hq, wq, dl_dtype(x), prec, act, in_act,
                            0 if bias is None else bias.numel(), splitk)
         assert dl_dtype(out) == d.in_dtype
+        if auto_split and splitk > 1 and plan.cc_real <= 4:
+            # the 4-channel patch kernel (csrc/conv_c4.h) has no split-K form and needs none (its K is 7 steps): prefer it when it applies
+            d.splitk = 1
+            if self.lib.dl_conv_kernel_name(C.byref(d)).decode() == 'conv_c4_patch_kernel':
+                splitk = 1
+            else:
+                d.splitk = splitk
         self.last_conv_kernel = self.lib.dl_conv_kernel_name(C.byref(d)).decode()      # diagnostic (bench.py roofline label)
         slab = WS.get('conv_slab', splitk * n * ho * wo * cop, x.device) if splitk > 1 else None
         nch, part = 0, None

@@ -78,6 +78,8 @@ typedef struct dl_conv_desc {
     int32_t bias_n;                 /* valid entries of `bias` (the real channel count; bias may be unaligned)    */
     int32_t raw_out;                /* 1: write the raw fp32 accumulators to `slab` ([N*Ho*Wo][Co]) and nothing to `out`
                                        (first half of the narrow-Cout path, see dl_shift_sum)                            */
+    int32_t ci_real;                /* real (unpadded) contracted channels; 0 = unknown.  <= 4 with Ci == 8 lets a stride-1 7x7 layer take the
+                                       4-channel patch kernel (csrc/conv_c4.h: ResnetGenerator stem forward, head data gradient)               */
 } dl_conv_desc;
 
 int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,

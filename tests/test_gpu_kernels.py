@@ -643,6 +643,53 @@ def test_narrow_roll_kernel_against_torch(shape, cout, act):
     assert rel(got[..., :cout].permute(0, 3, 1, 2), ref) < 6e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 128), (1, 8, 64), (3, 36, 192), (1, 512, 512)])
+@pytest.mark.parametrize('pm', [L.PAD_ZERO, L.PAD_REFLECT])
+def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm):
+    """conv_c4_patch_kernel (<= 4 real input channels, 7x7, input patch staged once in two 8-byte-shifted copies): the ResnetGenerator
+    stem forward incl. the fused norm statistics, and the head's data gradient (a 3 -> 64 conv with the flipped kernel), vs torch."""
+    from deepliif_amd import engine as E
+    n, h, w = shape
+    prec = Precision.get('bf16')
+    real = hip()
+    # ---- stem: 3 -> 64, bias, statistics for the following norm
+    spec = ConvSpec('conv', 3, 64, 7, 1, 3, pm)
+    w0 = rnd((64, 3, 7, 7), 21, prec, 0.05)
+    b0 = rnd((64,), 22, Precision.get('fp32'), 0.1)
+    x0 = torch.zeros(n, h, w, 8)
+    x0[..., :3] = rnd((n, h, w, 3), 23, prec)
+    layer = E.ConvLayer(spec, torch.nn.Parameter(w0.clone().to(DEV)), torch.nn.Parameter(b0.clone().to(DEV)))
+    layer.ensure_packed(prec, need_dgrad=False)
+    out = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=DEV)
+    nch = real.conv_forward(layer.packed_fwd, x0.to(torch.bfloat16).to(DEV), out, h, w, layer.bias.detach(), L.ACT_NONE, L.ACT_NONE, prec.prec, want_stats=True)
+    sync()
+    assert real.last_conv_kernel == 'conv_c4_patch_kernel' and nch == (h // 4) * (w // 64)
+    xp = x0[..., :3].permute(0, 3, 1, 2)
+    xp = torch.nn.functional.pad(xp, (3, 3, 3, 3), mode='reflect') if pm == L.PAD_REFLECT else torch.nn.functional.pad(xp, (3, 3, 3, 3))
+    ref = torch.nn.functional.conv2d(xp, w0, b0)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref) < 6e-3
+    part = ops.WS.get('norm_ws', 1, out.device)[:n * nch * 2 * 64].view(n, nch, 2, 64).cpu()
+    assert torch.allclose(part[:, :, 0].sum(1), got.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(part[:, :, 1].sum(1), (got * got).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    # ---- head data gradient: dx[64] from dy[3] (zero padding only: the reflect gradient runs over the padded extent, another plan)
+    if pm != L.PAD_ZERO:
+        return
+    hspec = ConvSpec('conv', 64, 3, 7, 1, 3, L.PAD_ZERO)
+    hw = rnd((3, 64, 7, 7), 24, prec, 0.05)
+    hl = E.ConvLayer(hspec, torch.nn.Parameter(hw.clone().to(DEV)), None)
+    hl.ensure_packed(prec, need_dgrad=True)
+    dy0 = torch.zeros(n, h, w, 8)
+    dy0[..., :3] = rnd((n, h, w, 3), 25, prec)
+    dx = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=DEV)
+    real.conv_forward(hl.packed_dgrad, dy0.to(torch.bfloat16).to(DEV), dx, h, w, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+    sync()
+    assert real.last_conv_kernel == 'conv_c4_patch_kernel'
+    xt = torch.zeros(n, 64, h, w, requires_grad=True)
+    torch.nn.functional.conv2d(xt, hw, padding=3).backward(dy0[..., :3].permute(0, 3, 1, 2).contiguous())
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), xt.grad) < 6e-3
+
+
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])
 def test_dropout_mask_properties(precname):
     """nn.Dropout(0.5) (networks.py:493-494, 604-605): the RNG stream cannot match torch's, so the test pins the properties the
