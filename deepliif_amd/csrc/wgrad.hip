@@ -493,6 +493,8 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
     return launch_wgrad<T, PREC, 128, 2, 2>(a, stream);
 }
 
+#include "wgrad_c4.h"
+
 extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
@@ -506,6 +508,8 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (d->splitk < 1) DL_FAIL("dl_conv_wgrad: splitk=%d", d->splitk);
     if (d->stack_kw && d->KW != 1) DL_FAIL("dl_conv_wgrad: stack_kw needs KW == 1");
     if (d->prec == DL_PREC_BF16X3 && d->dtype != DL_F32) DL_FAIL("dl_conv_wgrad: BF16X3 needs fp32 activations");
+
+    if (const int form = wgrad_c4_form(d)) return launch_wgrad_c4(d, form, P, Q, grad, slab, stream);
 
     WgradArgs a;
     memset(&a, 0, sizeof(a));

@@ -262,7 +262,11 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             be.act_backward(act, g, y.t, gp)
             g = gp
         if w_needs:
-            if layer.narrow and spec.pad_mode == L.PAD_ZERO:
+            if layer.narrow and spec.pad_mode == L.PAD_ZERO and getattr(be, 'wgrad_c4_applies', None) is not None and \
+                    be.wgrad_c4_applies(g, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec):
+                # 7x7, 64 -> 3: one persistent kernel over (dL/dy: 4-channel patch, x: 64-channel tile), csrc/wgrad_c4.h
+                be.conv_wgrad(g, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec, True)
+            elif layer.narrow and spec.pad_mode == L.PAD_ZERO:
                 # D[.., (co,kw)] = dy shifted by kw; the weight gradient becomes a KH x 1 problem with Cout*KW rows
                 D = torch.empty((n, ho, wo, cpad(spec.cout * spec.k)), dtype=g.dtype, device=g.device)
                 be.shift_stack(g, spec.cout, spec.k, spec.pad, D)

@@ -222,3 +222,16 @@ def choose_wgrad_splitk(cap: int, j: int, ptot: int, fast: bool = False, target_
     tiles = ((cap + ba - 1) // ba) * ((j + 127) // 128)
     sk = min(max_split, (target_blocks + tiles - 1) // tiles, max(1, ptot // 64))
     return max(1, sk)
+
+
+WGRAD_C4_PARTS = 512
+
+
+def wgrad_c4_ok(cap: int, ca: int, cbp: int, cb: int, k: int, step: int, pad: int, pad_mode: int, hp: int, wp: int, hq: int, wq: int, bf16: bool,
+                no_act: bool, stacked: bool) -> bool:
+    """mirror of wgrad_c4_form (csrc/wgrad_c4.h): the 7x7 weight gradient with one 64-channel and one <= 4-channel operand (Resnet stem / head)"""
+    if not (bf16 and no_act) or stacked or k != 7 or step != 1 or pad != 3 or pad_mode != L.PAD_ZERO:
+        return False
+    if (hp, wp) != (hq, wq) or hp % 4 or wp % 64:
+        return False
+    return (cap == 64 and cbp == 8 and cb <= 4) or (cap == 8 and ca <= 4 and cbp == 64)

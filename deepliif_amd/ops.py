@@ -20,7 +20,8 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from .geometry import GatherPlan, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc, wgrad_fast_path
+from .geometry import (GatherPlan, WGRAD_C4_PARTS, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc, wgrad_c4_ok,
+                       wgrad_fast_path)
 
 
 def dl_dtype(t: torch.Tensor) -> int:
@@ -39,6 +40,7 @@ def pstride(t: torch.Tensor) -> int:
 
 
 _SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
+_NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
@@ -235,10 +237,16 @@ class HipBackend:
         fast = wgrad_fast_path(d.CAp, j, d.dtype == L.DL_BF16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE,
                                pad_mode == L.PAD_ZERO)
         d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
+        if splitk is None and not _NO_WGRAD_C4 and self.wgrad_c4_applies(P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw):
+            d.splitk = WGRAD_C4_PARTS          # one partial result per persistent workgroup (csrc/wgrad_c4.h)
         d.accumulate = 1 if accumulate else 0
         d.p_act, d.q_act = p_act, q_act
         slab = WS.get('wgrad_slab', d.splitk * d.CAp * j, P.device)
         L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
+
+    def wgrad_c4_applies(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw=0) -> bool:
+        return wgrad_c4_ok(P.shape[3], grad.shape[0], Q.shape[3], grad.shape[1], k, step, pad, pad_mode, P.shape[1], P.shape[2], Q.shape[1], Q.shape[2],
+                           P.dtype == torch.bfloat16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE, bool(stack_kw))
 
     # ---- normalisation
     def _norm_desc(self, y, C_real, scope, act, momentum, z_ps, r_ps):

@@ -690,6 +690,30 @@ def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm):
     assert rel(dx.float().cpu().permute(0, 3, 1, 2), xt.grad) < 6e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 128), (1, 4, 64), (3, 36, 192), (2, 256, 256)])
+def test_c4_weight_gradient_of_the_7x7_layers(shape):
+    """wgrad_c4_kernel (csrc/wgrad_c4.h): dW of the Resnet stem (3 -> 64: wide = dL/dy, small = x) and of its head (64 -> 3: wide = x,
+    small = dL/dy, mirrored kernel indices), persistent workgroups + fixed-order combine, vs torch autograd; accumulate semantics."""
+    n, h, w = shape
+    prec = Precision.get('bf16')
+    real = hip()
+    for cin, cout in ((3, 64), (64, 3)):
+        x0 = torch.zeros(n, h, w, max(8, cin)); x0[..., :cin] = rnd((n, h, w, cin), 31, prec)
+        dy0 = torch.zeros(n, h, w, max(8, cout)); dy0[..., :cout] = rnd((n, h, w, cout), 32, prec)
+        wt = torch.zeros(cout, cin, 7, 7, requires_grad=True)
+        torch.nn.functional.conv2d(x0[..., :cin].permute(0, 3, 1, 2), wt, padding=3).backward(dy0[..., :cout].permute(0, 3, 1, 2).contiguous())
+        g0 = rnd((cout, cin, 7, 7), 33, Precision.get('fp32'))
+        grad = g0.clone().to(DEV)
+        P, Q = dy0.to(torch.bfloat16).to(DEV), x0.to(torch.bfloat16).to(DEV)
+        assert real.wgrad_c4_applies(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec)
+        real.conv_wgrad(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, True)
+        sync()
+        assert rel(grad.cpu() - g0, wt.grad) < 2e-3, (cin, cout)
+        real.conv_wgrad(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False)
+        sync()
+        assert rel(grad.cpu(), wt.grad) < 2e-3, (cin, cout, 'overwrite')
+
+
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])
 def test_dropout_mask_properties(precname):
     """nn.Dropout(0.5) (networks.py:493-494, 604-605): the RNG stream cannot match torch's, so the test pins the properties the

@@ -84,7 +84,13 @@ def conv_case(name, kind, cin, cout, k, s, p, N, H, W, prec, n_fwd, n_dgrad, n_w
         if narrow:
             D = torch.empty((N, ho, wo, cpad(cout * k)), dtype=dy.dtype, device=DEV)
 
+            c4 = getattr(be, 'wgrad_c4_applies', None) is not None and be.wgrad_c4_applies(dy, x, grad, k, 1, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec)
+            res['wgrad_path'] = 'wgrad_c4_kernel' if c4 else 'dl_shift_stack + stacked dl_conv_wgrad'
+
             def f():
+                if c4:
+                    be.conv_wgrad(dy, x, grad, k, 1, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, True)
+                    return
                 be.shift_stack(dy, cout, k, p, D)
                 be.conv_wgrad(D, x, grad, k, 1, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, True, stack_kw=k)
         elif kind == 'conv':
