@@ -27,6 +27,7 @@ struct ConvArgs {
     int phase_tap_begin[DL_MAX_PHASES + 1];
     int phase_kbase[DL_MAX_PHASES];
     int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
+    int epi_old;            // DL_OLD_EPILOGUE=1: per-fragment stores instead of the LDS-transposed whole-row stores (A/B switch)
     int tiles_m, tiles_n, Mtot;
     int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
     float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
@@ -326,9 +327,147 @@ __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 // Epilogue shared by the direct-to-LDS kernels: bias + activation + bf16 store (or raw fp32 slabs for split-K / raw_out) and the
 // optional fused per-(image, channel) statistics of the stored values.  `smem_raw` must be dead (all tile reads done, no DMA
 // in flight) when this is entered with statistics requested.
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror -- four VALU adds instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+// LDS bytes the store epilogue below needs: the bf16 output tile, one output-pixel index per tile row, the per-wave-row statistics
+template <int BM, int BN, int WM> constexpr size_t epilogue_lds_bytes() { return (size_t)BM * BN * 2 + BM * sizeof(int) + (size_t)WM * 2 * BN * sizeof(float); }
+
+// Store epilogue of the direct-to-LDS kernels (bf16 output, no split-K): the accumulators (rows = channels, 4 consecutive channels per
+// lane, 16 pixels across the lanes of a DPP row) would store as 32-byte pieces 16 pixels apart; instead the tile is transposed through
+// LDS (dead after the K loop; 8-byte units XOR-swizzled by the pixel so both the fragment writes and the 16-byte row reads are
+// conflict-free) and written out as whole NHWC pixel rows, 16 bytes per lane.  Fused bias / activation / per-channel statistics of the
+// stored (bf16-rounded) values as before; the 16-lane reductions of the statistics are DPP adds.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], int tm, int tn, int phase,
+                                                  int oh, int ow, int wm, int wn, int lane, int tid, char *smem_raw) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
+    constexpr int UNITS = BN / 4, SWZ = (UNITS - 1) & ~3;       // 8-byte units per tile row; unit bits the pixel index is XORed into
+    constexpr int CH = BN / 8;                                  // 16-byte chunks per tile row
+    char *tile = smem_raw;
+    int *rowtab = reinterpret_cast<int *>(smem_raw + (size_t)BM * BN * 2);
+    float *red = reinterpret_cast<float *>(rowtab + BM);        // [WM][2][BN]
+    const int fr = lane & 15, fg = lane >> 4;
+    const int HWq = a.Hq * a.Wq;
+    const bool want_stats = a.stats_part != nullptr;
+
+    // output pixel of every tile row (-1: outside the tensor -- ragged last tile, or a sub-pixel phase of an odd-sized output)
+    for (int r = tid; r < BM; r += NT) {
+        const int m = tm * BM + r;
+        int opix = -1;
+        if (m < a.Mtot) {
+            const int n = m / HWq, rem = m - n * HWq;
+            const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+            const int ho = hq * a.out_step + oh, wo = wq * a.out_step + ow;
+            if (ho < a.Ho && wo < a.Wo) opix = (n * a.Ho + ho) * a.Wo + wo;
+        }
+        rowtab[r] = opix;
+    }
+    bool live[FM];          // same test, for the statistics (per accumulator column of this lane)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = tm * BM + wm * PM + j * 16 + fr;
+        live[j] = m < a.Mtot;
+        if (a.out_step != 1 && live[j]) {
+            const int n = m / HWq, rem = m - n * HWq;
+            const int hq = rem / a.Wq, wq = rem - hq * a.Wq;
+            live[j] = hq * a.out_step + oh < a.Ho && wq * a.out_step + ow < a.Wo;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int cl = wn * PN + i * 16 + fg * 4;               // channel inside the tile
+        const int co = tn * BN + cl;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[r] = (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const int unit = (cl >> 2) ^ ((fr << 2) & SWZ);
+        char *dst = tile + (size_t)(wm * PM + fr) * (BN * 2) + unit * 8;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            f32x4_t v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bias[r];
+            if (a.act != DL_ACT_NONE) {       // one uniform branch per fragment (four instantiations of this epilogue behind a switch
+#pragma unroll                         // made the compiler keep a scratch copy of the kernel arguments)
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(a.act, v[r]);
+            }
+            u32x2_t p;
+            p[0] = pack2_bf16(v[0], v[1]);
+            p[1] = pack2_bf16(v[2], v[3]);
+            *reinterpret_cast<u32x2_t *>(dst + (size_t)j * 16 * (BN * 2)) = p;
+            if (want_stats && live[j]) {       // statistics of exactly what is stored (bf16-rounded), like the stand-alone kernel sees
+                const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
+                const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
+                s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+            if (fr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wm * 2 + 0) * BN + cl + r] = s1[r];
+                    red[(wm * 2 + 1) * BN + cl + r] = s2[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    bf16_t *out = reinterpret_cast<bf16_t *>(a.out);
+#pragma unroll 4
+    for (int idx = tid; idx < BM * CH; idx += NT) {
+        const int row = idx / CH, c = idx % CH;
+        const int opix = rowtab[row];
+        const int co = tn * BN + c * 8;
+        if (opix < 0 || co >= a.Co) continue;
+        const int unit = (c * 2) ^ ((row << 2) & SWZ);
+        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
+        *reinterpret_cast<u32x4_t *>(out + (size_t)opix * a.out_pstride + co) = v;
+    }
+    if (want_stats) {
+        // every pixel of this tile lies in ONE image (host guarantees HWq % BM == 0): chunk = (tile in image, phase)
+        const int m0 = tm * BM;
+        const int n = m0 / HWq;
+        const int chunk = ((m0 - n * HWq) / BM) * a.n_phase + phase;
+        for (int c = tid; c < BN; c += NT) {
+            const int co = tn * BN + c;
+            if (co < a.Co) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + c]; t2 += red[(w * 2 + 1) * BN + c]; }
+                float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + co;
+                o[0] = t1;
+                o[a.Co] = t2;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void glds_epilogue(const ConvArgs &a, f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], int tm, int tn, int phase, int ks,
                                               int wm, int wn, int lane, int tid, char *smem_raw) {
+    if constexpr (BN >= 64) {
+        static_assert(BM % 16 == 0, "tile rows");
+        if (a.splitk == 1 && !a.raw_out && !a.epi_old) {      // bf16 result: whole-row stores through LDS
+            const int oh0 = a.phase_oh[phase], ow0 = a.phase_ow[phase];
+            tile_epilogue_lds<BM, BN, WM, WN>(a, acc, tm, tn, phase, oh0, ow0, wm, wn, lane, tid, smem_raw);
+            return;
+        }
+    }
     constexpr int NW = WM * WN;
     constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
     const int fr = lane & 15, fg = lane >> 4;
@@ -691,7 +830,7 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_kernel(const ConvArgs a) {
     const int nk_total = ntaps * a.Ci / BK;
     const int nk_per = (nk_total + a.splitk - 1) / a.splitk;
     const int kt_begin = ks * nk_per;
-    const int T = max(min(nk_total, kt_begin + nk_per) - kt_begin, 0);
+    const int T = ABL == 4 ? 0 : max(min(nk_total, kt_begin + nk_per) - kt_begin, 0);       // ABL 4: prologue + epilogue only
 
     if (tid < DL_MAX_TAPS) {
         const int16_t tp = a.taps[tid];
@@ -903,7 +1042,8 @@ static int launch_conv_8ph(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
-    constexpr size_t smem = (size_t)8 * 128 * 64 * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int);
+    constexpr size_t smem_loop = (size_t)8 * 128 * 64 * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int);
+    constexpr size_t smem = smem_loop > epilogue_lds_bytes<256, 256, 2>() ? smem_loop : epilogue_lds_bytes<256, 256, 2>();
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_8ph_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1299,7 +1439,8 @@ static int launch_conv_glds_impl(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + BM - 1) / BM;
     a.tiles_n = (a.Co + BN - 1) / BN;
-    constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * (sizeof(int16_t) + sizeof(int));
+    constexpr size_t smem_loop = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t) + DL_MAX_TAPS * (sizeof(int16_t) + sizeof(int));
+    constexpr size_t smem = (BN >= 64 && epilogue_lds_bytes<BM, BN, WM>() > smem_loop) ? epilogue_lds_bytes<BM, BN, WM>() : smem_loop;
     auto kern = conv_gemm_glds_kernel<BM, BN, BK, WM, WN, UTAP, STAG, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1346,6 +1487,7 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
             if (abl8 && abl8[0] == '1') return launch_conv_8ph<1>(a, stream);
             if (abl8 && abl8[0] == '2') return launch_conv_8ph<2>(a, stream);
             if (abl8 && abl8[0] == '3') return launch_conv_8ph<3>(a, stream);
+            if (abl8 && abl8[0] == '4') return launch_conv_8ph<4>(a, stream);
             return launch_conv_8ph<0>(a, stream);
         }
         static const bool stag = getenv("DL_CONV_STAGGER") != nullptr;
@@ -1490,6 +1632,8 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
     for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
     for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
     a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
+    static const bool epi_old = getenv("DL_OLD_EPILOGUE") != nullptr;
+    a.epi_old = epi_old ? 1 : 0;
     a.Mtot = d->N * d->Hq * d->Wq;
     // A/B switch: "1" = channel-chunk-major K steps.  Measured on MI355X (r01): 4-7% faster in an isolated loop over one layer
     // (tools/ab_order.sh) but 3-12% SLOWER inside the training step (profiles/r01: 162.9 -> 168.7 us on the 256x256 tile),

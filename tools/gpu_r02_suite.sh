@@ -16,3 +16,14 @@ for f in ('bench_$TAG', 'bench_wsi_$TAG'):
     except Exception as e:
         print(f, 'failed', e); print(open(f'gpurun_out/{f}.err').read()[-1500:])
 PY
+# per-kernel statistics of the same bench command (kernel trace only; counters are collected in separate passes)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict > $GRAFT_REPO_ROOT/gpurun_out/bench_prof_$TAG.json 2> $GRAFT_REPO_ROOT/gpurun_out/bench_prof_$TAG.err); echo "rocprof rc=$?"
+cp gpurun_out/prof_$TAG/bench_kernel_stats.csv gpurun_out/bench_kernel_stats_$TAG.csv 2>/dev/null
+rm -rf gpurun_out/prof_$TAG
+python - <<PY
+import csv
+rows = list(csv.DictReader(open('gpurun_out/bench_kernel_stats_$TAG.csv')))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:24]:
+    print('%-70s %6s calls %9.1f us avg %6.2f %%' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+PY
