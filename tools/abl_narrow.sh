@@ -1,5 +1,7 @@
-for rep in 1 2; do
-for o in 0 1; do if [ $o = 1 ]; then export DL_OLD_EPILOGUE=1; else unset DL_OLD_EPILOGUE; fi
-echo "old=$o"; timeout 100 python tools/blk_probe.py 2>&1 | tail -1; done; done
-unset DL_OLD_EPILOGUE
-timeout 600 python tools/layer_budget.py r02d 2>&1 | tail -22
+timeout 900 python -m pytest tests/test_gpu_networks.py -q -m gpu -x -k "policy_variant or benched_configuration" 2>&1 | tail -8
+python - <<PY
+import json
+d = json.load(open('gpurun_out/parity_errors.json'))
+for k, v in d.items():
+    if k.startswith('policy') or k.startswith('fullsize'): print(k, v)
+PY
