@@ -30,6 +30,11 @@ class ConvDesc(C.Structure):
                 ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32), ('ci_real', i32)]
 
 
+
+class ConvBnStats(C.Structure):      # dl_conv_bnstats
+    _fields_ = [('y', C.c_void_p), ('y_pstride', C.c_int32), ('act', C.c_int32),
+                ('mean', C.c_void_p), ('rstd', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
 class WgradDesc(C.Structure):
     _fields_ = [('N', i32), ('Hp', i32), ('Wp', i32), ('CAp', i32), ('p_pstride', i32),
                 ('Hq', i32), ('Wq', i32), ('CBp', i32), ('q_pstride', i32),
@@ -59,6 +64,8 @@ SIGNATURES = {
     'dl_last_error': (C.c_char_p, []),
     'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
+    'dl_conv_bnstats_chunks': (_i, [C.POINTER(ConvDesc)]),
+    'dl_conv_forward_bnstats': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvBnStats), _vp]),
     'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
@@ -116,8 +123,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 101:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 101 (stale build)')
+    if lib.dl_version() != 102:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 102 (stale build)')
     _lib = lib
     return lib
 

@@ -32,6 +32,10 @@ struct ConvArgs {
     int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
     float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
     int stats_nchunks;
+    // fused norm-backward reductions (dl_conv_forward_bnstats): y tile read next to the dz tile in the store epilogue
+    const bf16_t *bn_y;
+    const float *bn_mean, *bn_rstd, *bn_scale, *bn_shift;
+    int bn_y_pstride, bn_act;
     int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
 };
 
@@ -357,7 +361,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
     float *red = reinterpret_cast<float *>(rowtab + BM);        // [WM][2][BN]
     const int fr = lane & 15, fg = lane >> 4;
     const int HWq = a.Hq * a.Wq;
-    const bool want_stats = a.stats_part != nullptr;
+    const bool want_stats = a.stats_part != nullptr && a.bn_y == nullptr;
 
     // output pixel of every tile row (-1: outside the tensor -- ragged last tile, or a sub-pixel phase of an odd-sized output)
     for (int r = tid; r < BM; r += NT) {
@@ -428,15 +432,84 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
     }
     __syncthreads();
     bf16_t *out = reinterpret_cast<bf16_t *>(a.out);
+    if (a.bn_y == nullptr) {
 #pragma unroll 4
-    for (int idx = tid; idx < BM * CH; idx += NT) {
-        const int row = idx / CH, c = idx % CH;
-        const int opix = rowtab[row];
+        for (int idx = tid; idx < BM * CH; idx += NT) {
+            const int row = idx / CH, c = idx % CH;
+            const int opix = rowtab[row];
+            const int co = tn * BN + c * 8;
+            if (opix < 0 || co >= a.Co) continue;
+            const int unit = (c * 2) ^ ((row << 2) & SWZ);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
+            *reinterpret_cast<u32x4_t *>(out + (size_t)opix * a.out_pstride + co) = v;
+        }
+    } else {
+        // ---- store + the reductions of the following normalisation backward: this thread owns the 8 channels c*8.. of every (NT/CH)-th
+        // tile row (NT is a multiple of CH, so c is fixed), reads the y values under the dz values it stores and accumulates
+        // S1 = sum dn, S2 = sum dn * xhat for them; the NT/CH row groups are then combined through LDS in a fixed order.
+        static_assert(NT % CH == 0, "one 16-byte column per thread");
+        constexpr int RG = NT / CH;                                  // row groups
+        const int c = tid % CH, rg = tid / CH;
         const int co = tn * BN + c * 8;
-        if (opix < 0 || co >= a.Co) continue;
-        const int unit = (c * 2) ^ ((row << 2) & SWZ);
-        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
-        *reinterpret_cast<u32x4_t *>(out + (size_t)opix * a.out_pstride + co) = v;
+        const int n_img = (tm * BM) / HWq;                           // the tile lies in one image (host guarantees HWq % BM == 0)
+        float mu[8], rs[8], sc[8], sh[8], s1[8], s2[8];
+        const bool cok = co < a.Co;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ci = n_img * a.Co + (cok ? co + i : 0);
+            mu[i] = a.bn_mean[ci]; rs[i] = a.bn_rstd[ci]; sc[i] = a.bn_scale[ci]; sh[i] = a.bn_shift[ci];
+            s1[i] = s2[i] = 0.f;
+        }
+        // all y loads of this thread are issued before the first one is used (16 x 16 B in flight per thread on the 256-pixel tile;
+        // a load-use-load chain here cost +40 us per launch: 16 dependent HBM round trips per tile)
+        constexpr int ITER = BM / RG;
+        static_assert(BM % RG == 0, "row groups tile the rows");
+        u32x4_t yv[ITER];
+        int opx[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            opx[it] = cok ? rowtab[rg + it * RG] : -1;
+            yv[it] = u32x4_t{0u, 0u, 0u, 0u};
+            if (opx[it] >= 0) yv[it] = *reinterpret_cast<const u32x4_t *>(a.bn_y + (size_t)opx[it] * a.bn_y_pstride + co);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (opx[it] < 0) continue;
+            const int row = rg + it * RG;
+            const int unit = (c * 2) ^ ((row << 2) & SWZ);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
+            *reinterpret_cast<u32x4_t *>(out + (size_t)opx[it] * a.out_pstride + co) = v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned dw = v[i >> 1], yw = yv[it][i >> 1];
+                float dn = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
+                const float yy = __uint_as_float((i & 1) ? (yw & 0xffff0000u) : (yw << 16));
+                const float nv = yy * sc[i] + sh[i];
+                if (a.bn_act == DL_ACT_RELU) dn = nv > 0.f ? dn : 0.f;
+                else if (a.bn_act == DL_ACT_LRELU) dn = nv > 0.f ? dn : 0.2f * dn;
+                s1[i] += dn;
+                s2[i] += dn * (yy - mu[i]) * rs[i];
+            }
+        }
+        __syncthreads();                                             // every thread is done reading the tile: reuse it
+        float *bred = reinterpret_cast<float *>(tile);               // [RG][2][BN]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bred[(rg * 2 + 0) * BN + c * 8 + i] = s1[i];
+            bred[(rg * 2 + 1) * BN + c * 8 + i] = s2[i];
+        }
+        __syncthreads();
+        const int m0 = tm * BM;
+        const int chunk = ((m0 - n_img * HWq) / BM) * a.n_phase + phase;
+        for (int cc = tid; cc < 2 * BN; cc += NT) {
+            const int which = cc / BN, ch = cc % BN;
+            if (tn * BN + ch >= a.Co) continue;
+            float t = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < RG; ++r) t += bred[(r * 2 + which) * BN + ch];
+            a.stats_part[((size_t)(n_img * a.stats_nchunks + chunk) * 2 + which) * a.Co + tn * BN + ch] = t;
+        }
+        return;
     }
     if (want_stats) {
         // every pixel of this tile lies in ONE image (host guarantees HWq % BM == 0): chunk = (tile in image, phase)
@@ -1461,13 +1534,19 @@ static int launch_conv_glds(const ConvArgs &a, hipStream_t stream) {
     return launch_conv_glds_impl<BM, BN, BK, WM, WN, false>(a, stream);
 }
 
+// 256 x 256 tiles are used when they (x sub-pixel phases x split-K partials) give every CU a workgroup; 224 rather than 256 so that a
+// 31 x 2-tile layer split 4 ways (PatchGAN 512->512 at 31 x 31) still qualifies.  geometry.py: conv_tile / choose_splitk mirror this.
+static bool big_tile_fills_gpu(int mtot, int Co, int n_phase, int splitk) {
+    return Co >= 256 && (Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (Co / 256) * n_phase * splitk >= 224;
+}
+
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
     static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
     // 256x256x64, 8 waves (each 128 pixels x 64 channels): twice the FLOP per staged byte of the 128x128 tile; needs
     // enough tiles to fill 256 CUs
-    if (!no_big && a.Co >= 256 && (a.Co % 256) == 0 && (size_t)((a.Mtot + 255) / 256) * (a.Co / 256) * a.n_phase * a.splitk >= 256)
+    if (!no_big && big_tile_fills_gpu(a.Mtot, a.Co, a.n_phase, a.splitk))
     {
         // "1": software-pipelined 32x32x16 kernel (+ kernel-column reuse).  Same-box A/B of the whole training step (r01,
         // tools/ab_bench.sh): 121.7-122.0 ms vs 121.4-122.1 ms for the 8-phase kernel, 123.4-123.6 ms for the one-barrier kernel;
@@ -1564,7 +1643,7 @@ static int glds_tile_bm(const dl_conv_desc *d) {
     if (d->Co <= 64) return 128;
     static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
     const int mtot = d->N * d->Hq * d->Wq;
-    if (!no_big && d->Co >= 256 && (d->Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (d->Co / 256) * d->n_phase * d->splitk >= 256) return 256;
+    if (!no_big && big_tile_fills_gpu(mtot, d->Co, d->n_phase, d->splitk)) return 256;
     return 128;
 }
 
@@ -1597,8 +1676,37 @@ extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     return (hw / bm) * d->n_phase;
 }
 
+extern "C" int dl_conv_bnstats_chunks(const dl_conv_desc *d) {
+    // the reductions live in the LDS-transposed store epilogue of the direct-to-LDS kernels (tile_epilogue_lds): bf16, >= 64 output
+    // channels per tile, no split-K, tiles that do not straddle images
+    static const bool off = getenv("DL_OLD_EPILOGUE") != nullptr;
+    static const char *p32 = getenv("DL_CONV_P32");
+    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d)) return 0;
+    static const int min_bm = getenv("DL_BNSTATS_MIN_BM") ? atoi(getenv("DL_BNSTATS_MIN_BM")) : 0;       // A/B: 256 = only the 256 x 256-tile kernels
+    if (glds_tile_bm(d) < min_bm) return 0;
+    return dl_conv_stats_chunks(d);
+}
+
+static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
+                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_);
+
 extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
                                void *out, float *slab, float *stats_part, void *stream_) {
+    return conv_forward_impl(d, in, w_hi, w_lo, bias, out, slab, stats_part, nullptr, stream_);
+}
+
+extern "C" int dl_conv_forward_bnstats(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, void *out,
+                                       float *stats_part, const dl_conv_bnstats *bn, void *stream_) {
+    if (!d || !bn || !stats_part) DL_FAIL("dl_conv_forward_bnstats: null argument");
+    if (!bn->y || !bn->mean || !bn->rstd || !bn->scale || !bn->shift) DL_FAIL("dl_conv_forward_bnstats: null statistics / y");
+    if (bn->act != DL_ACT_NONE && bn->act != DL_ACT_RELU && bn->act != DL_ACT_LRELU) DL_FAIL("dl_conv_forward_bnstats: act=%d", bn->act);
+    if (bn->y_pstride % 8) DL_FAIL("dl_conv_forward_bnstats: y_pstride must keep 16-byte alignment");
+    if (dl_conv_bnstats_chunks(d) == 0) DL_FAIL("dl_conv_forward_bnstats: not available for this descriptor (ask dl_conv_bnstats_chunks first)");
+    return conv_forward_impl(d, in, w_hi, w_lo, nullptr, out, nullptr, stats_part, bn, stream_);
+}
+
+static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
+                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d) DL_FAIL("dl_conv_forward: null descriptor");
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hq <= 0 || d->Wq <= 0)
@@ -1646,6 +1754,10 @@ extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void
         a.stats_nchunks = dl_conv_stats_chunks(d);
         if (a.stats_nchunks == 0) DL_FAIL("dl_conv_forward: fused statistics are not available for this descriptor (ask dl_conv_stats_chunks first)");
         a.stats_part = stats_part;
+    }
+    if (bn) {
+        a.bn_y = (const bf16_t *)bn->y; a.bn_y_pstride = bn->y_pstride; a.bn_act = bn->act;
+        a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;
     }
 
     int rc;

@@ -479,7 +479,9 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_backward")) return -1;
     if (!dz || !y || !dy || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
-    const NormGeom g = make_geom(d);
+    // ext_nchunks > 0: the producer of dz (dl_conv_forward_bnstats) already left the [N][ext_nchunks][2][Cp] partials at the start of ws
+    const bool ext = d->ext_nchunks > 0;
+    const NormGeom g = make_geom_fwd(d);
     float *part = ws;
     float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
     float *c1 = sums + (size_t)2 * g.N * g.Cp;
@@ -491,7 +493,8 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
                                                  d->y_pstride, (const float *)dz, dz_ps, g, mean, rstd, scale, shift, part)
 #define DL_LAUNCH_BRED_BF16(A) hipLaunchKernelGGL((norm_partial_kernel<bf16_t, 1, A>), dim3(pblocks), dim3(256), 0, stream, (const bf16_t *)y, \
                                                   d->y_pstride, (const bf16_t *)dz, dz_ps, g, mean, rstd, scale, shift, part)
-    if (d->dtype == DL_F32) { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BRED_F32) }
+    if (ext) { /* partials are in place */ }
+    else if (d->dtype == DL_F32) { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BRED_F32) }
     else { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BRED_BF16) }
     DL_CHECK_LAUNCH("dl_norm_backward(reduce)");
     if (d->scope == DL_NORM_INSTANCE && !dgamma) {

@@ -40,7 +40,7 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -50,6 +50,8 @@ class Act:
         self.bias_grad: Optional[torch.Tensor] = None     # conv output: where the producer's bias gradient accumulates
         self.bias_done = False                            # set when a consumer's backward already added sum(dy) to it
         self.stats = None                                 # conv output: (chunks, workspace token) of fused norm statistics
+        self.bn_ctx = None                                # norm_act output z = act(norm(y)): (y tensor, statistics, act) for a consumer conv's backward
+        self.grad_stats = None                            # (chunks, workspace token): the ONLY contribution to .grad also left the norm-backward reductions
 
     @property
     def shape(self):
@@ -64,6 +66,7 @@ class Act:
             self.grad = g
         else:
             ops.impl().axpby(1.0, self.grad, 1.0, g, self.grad)
+            self.grad_stats = None          # reductions fused into the first contribution's producer no longer describe the sum
 
 
 class Tape:
@@ -297,10 +300,16 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 dq = ((hi + 1) // 2, (wi + 1) // 2)
             else:
                 dq = (hi, wi)
-            be.conv_forward(layer.packed_dgrad, g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec)
+            # x = act(norm(y')) of the layer in front and nothing else has contributed to its gradient yet: the store epilogue of this
+            # data gradient also produces that norm's backward reductions (one pass over y' and dx saved); valid only while dx stays
+            # the sole contribution (Act.add_grad drops it otherwise)
+            fuse = x.bn_ctx if (x.grad is None and in_act == L.ACT_NONE) else None
+            nch = be.conv_forward(layer.packed_dgrad, g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, bn=fuse)
             if in_act != L.ACT_NONE:                # relu / lrelu keep the sign: mask from the un-activated input
                 be.act_backward(in_act, dx, x.t, dx)
             x.add_grad(dx)
+            if fuse is not None and nch:
+                x.grad_stats = (nch, be.norm_ws_token())
 
     ctx.tape.record(backward)
     return y
@@ -349,12 +358,16 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
     z = Act(out, y.C, needs)
     if not needs:
         return z
+    if residual is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and y.t.dtype == torch.bfloat16 and y.needs_grad:
+        z.bn_ctx = (y.t, stats, act)
 
     def backward():
         g = z.grad
         z.grad = None
+        gs, z.grad_stats = z.grad_stats, None
         if g is None:
             return
+        ext_b = gs[0] if (gs is not None and gs[1] == be.norm_ws_token()) else 0
         if residual is not None and residual.needs_grad:
             residual.add_grad(g)
         affine = m is not None and m.weight.requires_grad
@@ -362,7 +375,7 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
             dy = empty_like_act(g)
             fuse_bias = y.bias_grad is not None and y.grad is None and not y.bias_done     # dy is y's ONLY gradient contribution
             be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None,
-                             y.bias_grad if fuse_bias else None)
+                             y.bias_grad if fuse_bias else None, ext_nchunks=ext_b)
             if fuse_bias:
                 y.bias_done = True
             if y.needs_grad:

@@ -174,9 +174,18 @@ def conv_tile(co_pad: int):
 def choose_splitk(plan: GatherPlan, n: int, hq: int, wq: int, co_pad: int, target_blocks: int = 512, max_split: int = 32) -> int:
     bm, bn = conv_tile(co_pad)
     blocks = ((n * hq * wq + bm - 1) // bm) * ((co_pad + bn - 1) // bn) * plan.n_phase
+    nk64 = min(round_up(len(t) * plan.cc_pad, 64) // 64 for t in plan.phase_taps)
+    if co_pad % 256 == 0 and plan.cc_pad >= 64:
+        # few pixels, long K (PatchGAN 512->512 at 31 x 31: 61 x 4 tiles of 128 x 128 leave the K loop bound by the bytes staged per MFMA):
+        # 256 x 256 tiles stage half the bytes per MFMA; split K so that every CU gets exactly one workgroup.  Pays only while each
+        # partial still runs a long loop -- the partials cost a 60 MB slab round trip (tools/splitk_probe.py: 139 -> 89 us at 32 steps
+        # per partial, 78 -> 64 us at 16, a loss at 2 partials).  Mirrors big_tile_fills_gpu() in csrc/conv_gemm.hip.
+        t256 = ((n * hq * wq + 255) // 256) * (co_pad // 256) * plan.n_phase
+        sk = 256 // max(t256, 1)
+        if t256 < 224 and sk >= 2 and t256 * sk >= 224 and nk64 // sk >= 24:
+            return sk
     if blocks >= 256:
         return 1
-    nk64 = min(round_up(len(t) * plan.cc_pad, 64) // 64 for t in plan.phase_taps)
     sk = min(max_split, nk64, (target_blocks + blocks - 1) // blocks)
     return max(1, sk)
 

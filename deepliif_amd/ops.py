@@ -40,6 +40,10 @@ def pstride(t: torch.Tensor) -> int:
 
 
 _SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
+# DL_BNSTATS=1: the data gradient's store epilogue also produces the following norm backward's reductions (dl_conv_forward_bnstats).  OFF by
+# default: same-box A/B of the training step (r02) 104.9-105.0 ms with it vs 103.8-104.0 without -- the y tile read sits exposed in the
+# epilogue of a 1-workgroup-per-CU kernel (+37 us per fused ResnetBlock launch) and costs what the saved pass (49 us) was worth.
+_BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
 _NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
@@ -169,11 +173,15 @@ class HipBackend:
 
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
-                     act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False, want_stats: bool = False):
+                     act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False, want_stats: bool = False,
+                     bn=None):
         """raw_out: `out` is an fp32 [N,Ho,Wo,Co] tensor that receives the raw accumulators (narrow-Cout path).
         want_stats: ask the kernel to also leave the per-(image, channel) partial sums of `out` at the start of the shared
         normalisation workspace; returns the chunk count to hand to norm_forward(ext_nchunks=...) -- 0 when the dispatch for
-        this layer cannot produce them (the caller then runs the stand-alone statistics pass)."""
+        this layer cannot produce them (the caller then runs the stand-alone statistics pass).
+        bn = (y, stats, act): `out` is dz for the layer z = act(norm(y)) with statistics `stats` (norm_forward's result) and this conv is its
+        only contribution: let the store epilogue also produce the reductions of that norm's backward (dl_conv_forward_bnstats); returns
+        the chunk count for norm_backward(ext_nchunks=...), 0 when the dispatch cannot (the norm then makes its own pass)."""
         _need_cuda(x, out, bias)
         if raw_out:
             plan = packed.plan
@@ -211,6 +219,21 @@ class HipBackend:
                 nd.ext_nchunks = nch
                 part = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(nd)), x.device)
                 WS.bump_norm_token()
+        if bn is not None and bias is None and splitk == 1 and not want_stats and _BNSTATS:
+            by, bstats, bact = bn
+            nch = int(self.lib.dl_conv_bnstats_chunks(C.byref(d)))
+            if nch > 0 and by.dtype == out.dtype == torch.bfloat16 and by.shape == out.shape:
+                _need_cuda(by, bstats)
+                nd = self._norm_desc(out, cop, L.NORM_BATCH, L.ACT_NONE, -1.0, 8, 8)     # only N/H/W/Cp matter for the size
+                nd.ext_nchunks = nch
+                part = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(nd)), x.device)
+                WS.bump_norm_token()
+                b = L.ConvBnStats(by.data_ptr(), pstride(by), bact, bstats[0].data_ptr(), bstats[1].data_ptr(), bstats[2].data_ptr(),
+                                  bstats[3].data_ptr())
+                L.check(self.lib.dl_conv_forward_bnstats(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(out), _ptr(part),
+                                                         C.byref(b), _stream()), 'dl_conv_forward_bnstats')
+                return nch
+            nch = 0
         L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
                                          _ptr(part), _stream()), 'dl_conv_forward')
         return nch
@@ -272,9 +295,11 @@ class HipBackend:
                                          _ptr(ws), _stream()), 'dl_norm_forward')
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0):
+        """ext_nchunks > 0: the conv that produced dz already left the reductions in the 'norm_ws' workspace (conv_forward(bn=...))"""
         _need_cuda(dz, y, dy, dy_chansum)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
+        d.ext_nchunks = ext_nchunks
         WS.bump_norm_token()
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 101
+#define DL_VERSION 102
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -89,6 +89,22 @@ int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, con
  * (dl_norm_desc.ext_nchunks = chunks, partials at the start of its `ws`) skips its own statistics pass over y.  0 = not
  * available for this descriptor (pass stats_part = NULL). */
 int dl_conv_stats_chunks(const dl_conv_desc *d);
+/* Data gradient with the FOLLOWING normalisation backward's reductions fused into its store epilogue.  The conv's output here is dz,
+ * the gradient with respect to z = act(norm(y)) of the layer in front (networks.py:381-384 Conv2d -> norm -> ReLU; ResnetBlock
+ * :478-500; NLayerDiscriminator :644-652); dl_norm_backward needs  S1 = sum dn  and  S2 = sum dn * xhat  over every image,
+ * dn = dz * act'(y * scale + shift), xhat = (y - mean) * rstd, before it can apply -- normally its own pass over y and dz.  With
+ * `bn` the conv reads the matching y tile next to the dz tile it is about to store and leaves the per-tile partials in
+ * stats_part = fp32 [N][chunks][2][Co] (chunks = dl_conv_bnstats_chunks(d) > 0), which dl_norm_backward consumes through
+ * dl_norm_desc.ext_nchunks (partials at the start of its `ws`).  Valid only when this conv's output is the ONLY contribution to dz. */
+typedef struct dl_conv_bnstats {
+    const void *y;                  /* pre-norm tensor, same N x Ho x Wo pixels and dtype as the conv output          */
+    int32_t y_pstride;
+    int32_t act;                    /* activation behind the norm: DL_ACT_NONE / DL_ACT_RELU / DL_ACT_LRELU             */
+    const float *mean, *rstd, *scale, *shift;      /* [N][Co], as dl_norm_forward left them                            */
+} dl_conv_bnstats;
+int dl_conv_bnstats_chunks(const dl_conv_desc *d);
+int dl_conv_forward_bnstats(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, void *out,
+                            float *stats_part, const dl_conv_bnstats *bn, void *stream);
 /* Name of the kernel dl_conv_forward would launch for `d` (static string, matches the rocprofv3 kernel name up to template
  * arguments).  Diagnostic only: bench.py labels its roofline line with it. */
 const char *dl_conv_kernel_name(const dl_conv_desc *d);
@@ -192,7 +208,8 @@ typedef struct dl_norm_desc {
     int32_t act;
     float eps;
     float momentum;                  /* <0: do not touch running stats                    */
-    int32_t ext_nchunks;             /* >0: `ws` already starts with [N][ext_nchunks][2][Cp] partial sums (dl_conv_forward) */
+    int32_t ext_nchunks;             /* >0: `ws` already starts with [N][ext_nchunks][2][Cp] partial sums: forward -- sum y, sum y^2
+                                        (dl_conv_forward); backward -- sum dn, sum dn*xhat (dl_conv_forward_bnstats)                  */
 } dl_norm_desc;
 
 size_t dl_norm_ws_floats(const dl_norm_desc *d);     /* scratch needed by forward and backward (floats) */

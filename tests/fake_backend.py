@@ -83,7 +83,7 @@ class FakeBackend:
     def norm_ws_token(self):
         return 0
 
-    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False, want_stats=False):
+    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False, want_stats=False, bn=None):
         self._count('conv')
         plan = packed.plan
         xv = _act(in_act, x.float())
@@ -156,7 +156,8 @@ class FakeBackend:
             stats[i] = t.reshape(-1, Cp).expand(N, Cp)
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None):
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0):
+        assert ext_nchunks == 0, 'the emulation never reports fused norm-backward reductions'
         self._count('norm_bwd')
         yv, g = y.float(), dz.float()
         N, H, W, Cp = yv.shape

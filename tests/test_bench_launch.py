@@ -20,7 +20,8 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
                         '--ngf', '8', '--no-cpu-baseline'], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     # the gloo transport itself writes '[Gloo] Rank ...' lines to stdout from C++ (RCCL does not); everything else must be the ONE JSON line
-    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]
+    # (two ranks write those concurrently, so a '[Gloo] Rank' prefix and its '... is connected to 1 peer ranks ...' tail can land on different lines)
+    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]') and 'peer ranks' not in l]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',

@@ -744,3 +744,69 @@ def test_dropout_mask_properties(precname):
     assert torch.all(buf[..., :32] == 1)
     k = float((buf[..., 32:].float() > 0).float().mean())
     assert abs(k - 0.75) < 0.02 and abs(float(buf[..., 32:].float().max()) - 1 / 0.75) < 1e-2
+
+
+@pytest.mark.parametrize('norm_kind,nact', [('instance', L.ACT_RELU), ('batch', L.ACT_LRELU), ('instance', L.ACT_NONE)])
+@pytest.mark.parametrize('c1,c2,k,s,p,n,hw', [
+    (64, 64, 3, 1, 1, 2, 128),       # 128 x 64 tiles, one phase (enough tiles that the dispatch does not split K)
+    (128, 128, 4, 2, 1, 4, 128),     # PatchGAN-like consumer: stride 2 -> the data gradient runs in 4 sub-pixel phases
+    (256, 256, 3, 1, 1, 4, 128),     # the ResnetBlock shape: 256 x 256 tiles (8-phase kernel), 256 tiles
+])
+def test_norm_backward_reductions_fused_into_the_data_gradient(norm_kind, nact, c1, c2, k, s, p, n, hw):
+    """conv_a -> norm -> act -> conv_b: the data gradient of conv_b (dl_conv_forward_bnstats) leaves sum(dn), sum(dn * xhat) of the norm's
+    backward in its store epilogue and dl_norm_backward(ext_nchunks) skips its own pass over y and dz.  Same graph with the fusion
+    switched off (the default route; DL_BNSTATS=1 enables the fusion -- measured break-even to slightly slower on the training step, ops.py): gradients agree to summation order; the fused route must actually have been taken."""
+    if DRY:
+        pytest.skip('needs the HIP library')
+    from deepliif_amd import engine as E
+    prec = Precision.get('bf16')
+    be = hip()
+    spec_a = ConvSpec('conv', c1, c1, 3, 1, 1, L.PAD_ZERO)
+    spec_b = ConvSpec('conv', c1, c2, k, s, p, L.PAD_ZERO)
+    wa0, wb0 = rnd((c1, c1, 3, 3), 1, prec, 0.05), rnd((c2, c1, k, k), 2, prec, 0.05)
+    x0 = rnd((n, hw, hw, c1), 3, prec)
+    ho = spec_b.out_hw(hw, hw)[0]
+    g0 = rnd((n, ho, ho, c2), 4, prec)
+    bn = torch.nn.BatchNorm2d(c1).to(DEV) if norm_kind == 'batch' else None
+    if bn is not None:
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c1, generator=torch.Generator().manual_seed(5)) + 0.5)
+            bn.bias.copy_(torch.randn(c1, generator=torch.Generator().manual_seed(6)) * 0.2)
+    res, taken = {}, {}
+    for fused in (True, False):
+        ops._BNSTATS = fused
+        wa = torch.nn.Parameter(wa0.clone().to(DEV)); wa.grad = torch.zeros_like(wa)
+        wb = torch.nn.Parameter(wb0.clone().to(DEV)); wb.grad = torch.zeros_like(wb)
+        la, lb = E.ConvLayer(spec_a, wa, None), E.ConvLayer(spec_b, wb, None)
+        if bn is not None:
+            bn.weight.grad, bn.bias.grad = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+        tape = E.Tape()
+        ctx = E.Ctx(prec, tape, training=True)
+        xa = E.Act(x0.to(torch.bfloat16).to(DEV), c1, True)
+        y = E.conv(ctx, xa, la, stats=True)
+        z = E.norm_act(ctx, y, E.NormLayer(norm_kind, c1, bn), nact)
+        o = E.conv(ctx, z, lb)
+        seen = []
+        orig = be.norm_backward
+
+        def spy(*a, **kw):
+            seen.append(kw.get('ext_nchunks', 0))
+            return orig(*a, **kw)
+        be.norm_backward = spy
+        try:
+            o.grad = g0.to(torch.bfloat16).to(DEV)
+            tape.backward()
+        finally:
+            be.norm_backward = orig
+        sync()
+        taken[fused] = seen
+        res[fused] = {'dx': xa.grad.float().cpu(), 'dwa': wa.grad.cpu(), 'dwb': wb.grad.cpu()}
+        if bn is not None:
+            res[fused]['dgamma'], res[fused]['dbeta'] = bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone()
+    ops._BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
+    ops._impl = None
+    assert taken[True] and taken[True][0] > 0, taken          # the conv epilogue produced the reductions
+    assert taken[False] == [0], taken
+    for key in res[True]:
+        # identical inputs; the two routes differ in fp32 summation order of the reductions only (then one bf16 rounding of dy)
+        assert rel(res[True][key], res[False][key]) < 4e-3, (key, rel(res[True][key], res[False][key]))
