@@ -53,3 +53,46 @@ def synth_image(w, h, seed):
 def tiler_result_tiles(tile_np):
     """two deterministic 'network outputs' per tile (any per-pixel function of the tile works: it must survive crop + paste)"""
     return {'A': 255 - tile_np, 'B': np.ascontiguousarray(tile_np[..., ::-1] // 2 + 7)}
+
+
+def synth_cells(h: int, w: int, n_cells: int, seed: int):
+    """Seeded synthetic inputs of the post-processing row: (orig, seg, marker) uint8 HxWx3.  seg follows the reference's convention
+    (postprocessing.py:164-190): R = positive probability, B = negative probability, G = boundary (<= 80 inside cells); blobs of
+    random radius, some touching each other or the image border, some with an enclosed hole (pixels below the threshold inside a
+    cell), speckle noise below / around the noise threshold; marker = smooth blobs over positive cells; orig = stained-looking image."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    seg = np.zeros((h, w, 3), dtype=np.float64)
+    seg[..., 1] = rng.randint(0, 60, size=(h, w))
+    marker = rng.randint(0, 25, size=(h, w)).astype(np.float64)
+    orig = np.full((h, w, 3), 225.0) + rng.randint(-12, 12, size=(h, w, 3))
+    for i in range(n_cells):
+        cy, cx = rng.randint(-2, h + 2), rng.randint(-2, w + 2)
+        r = rng.uniform(2.0, 9.0)
+        ell = rng.uniform(0.6, 1.0)
+        d = np.sqrt(((yy - cy) / ell) ** 2 + (xx - cx) ** 2)
+        inside = d <= r
+        pos = rng.rand() < 0.45
+        strong = rng.randint(150, 255)
+        weak = rng.randint(0, 90)
+        seg[..., 0][inside] = strong if pos else weak
+        seg[..., 2][inside] = weak if pos else strong
+        seg[..., 1][inside] = rng.randint(0, 70)
+        if rng.rand() < 0.3 and r > 4.5:                       # enclosed hole: stays "unknown" inside the cell
+            hole = d <= r * 0.3
+            seg[..., 0][hole] = 10
+            seg[..., 2][hole] = 10
+        if rng.rand() < 0.25:                                  # a ring of boundary-coloured pixels (G > 80) cutting the blob
+            ring = np.abs(d - r * 0.6) < 0.7
+            seg[..., 1][ring] = 200
+        if pos:
+            marker[inside] = np.maximum(marker[inside], rng.randint(60, 255) * np.exp(-(d[inside] / (r + 1)) ** 2))
+        orig[inside] = orig[inside] * 0.55 + np.array([120.0, 70.0, 40.0] if pos else [60.0, 80.0, 150.0]) * 0.45
+    speck = rng.rand(h, w) < 0.01                             # isolated bright pixels: cells below the noise threshold
+    seg[..., 0][speck] = 220
+    seg[..., 1][speck] = 0
+    mk = np.repeat(marker[..., None], 3, axis=2)
+    mk[..., 1] *= 0.8
+    mk[..., 2] *= 0.5
+    return (np.clip(orig, 1, 255).astype(np.uint8), np.clip(seg, 0, 255).astype(np.uint8), np.clip(mk, 0, 255).astype(np.uint8))

@@ -1,0 +1,69 @@
+"""Fixtures for the post-processing row: the REFERENCE's deepliif/postprocessing.py run in this container
+(numba stubbed to the identity decorator -> the pure-Python loops) on small synthetic seg / marker / original images.
+
+  python tests/golden/make_golden_post.py        ->  tests/golden/post_cases.npz
+
+numba widens every integer operation to 64 bits, the stubbed pure-Python run would instead wrap numpy's uint8 / uint16 scalars
+(seg[y, x, 0] + seg[y, x, 2] overflows at 256, the optical-density sum of a cell at 65536).  To reproduce what the jitted reference
+computes, the harness hands the images over as int64 arrays and converts create_od_image's uint16 result to int64 (a wrapper around
+the reference's own function) -- values and comparisons are unchanged, only the wrap-around is avoided.
+
+Stored per case: the three uint8 input images and the options, and what the reference returned: the label mask and cell list of
+get_cells_info (postprocessing.py:311-362), the default thresholds, and overlay / refined / scoring of compute_final_results
+(:1223-1304).  Inputs come from golden_util.synth_cells (seeded), so the GPU tests regenerate nothing -- they read this file."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_import import install_stubs          # noqa: E402
+from golden_util import synth_cells            # noqa: E402
+
+CASES = [
+    # name, (H, W), seed, n_cells, kwargs of compute_final_results
+    ('default_40x', (120, 150), 1, 28, dict(resolution='40x')),
+    ('marker_default_20x', (96, 130), 2, 22, dict(resolution='20x', marker_thresh='default')),
+    ('fixed_thresholds', (100, 100), 3, 20, dict(resolution='40x', size_thresh=30, marker_thresh=120, size_thresh_upper=400, noise_thresh=8)),
+    ('large_noise_10x', (90, 160), 4, 26, dict(resolution='10x', large_noise_thresh='default', size_thresh=None)),
+    ('optical_density', (110, 120), 5, 24, dict(resolution='40x', od_thresh_lower=20, od_thresh_upper=140)),
+    ('crowded_touching', (128, 128), 6, 60, dict(resolution='40x', seg_thresh=100)),
+    ('empty', (64, 80), 7, 0, dict(resolution='40x')),
+    ('few_cells', (64, 64), 8, 4, dict(resolution='40x', noise_thresh=2)),
+]
+
+
+def main():
+    install_stubs()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_postprocessing', '/root/reference/deepliif/postprocessing.py')
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    _od = P.create_od_image
+    P.create_od_image = lambda o: _od(o).astype(np.int64)          # numba: uint16 + uint16 -> int64 (see the module docstring)
+    wide = lambda a: a.astype(np.int64)
+    out = {'names': np.array([c[0] for c in CASES])}
+    for name, (h, w), seed, ncell, kw in CASES:
+        orig, seg, marker = synth_cells(h, w, ncell, seed)
+        out[f'{name}/orig'], out[f'{name}/seg'], out[f'{name}/marker'] = orig, seg, marker
+        out[f'{name}/kwargs'] = np.array(repr(kw))
+        # stage results (get_cells_info with the same thresholds compute_final_results derives)
+        noise = kw.get('noise_thresh', P.DEFAULT_NOISE_THRESH)
+        segt = kw.get('seg_thresh', P.DEFAULT_SEG_THRESH)
+        large = P.calculate_large_noise_thresh(kw.get('large_noise_thresh', None), kw['resolution'])
+        use_od = kw.get('od_thresh_lower') is not None or kw.get('od_thresh_upper') is not None
+        mask, cells, defaults = P.get_cells_info(wide(seg), wide(orig if use_od else marker), kw['resolution'], noise, segt, large, use_od=use_od)
+        out[f'{name}/mask_after_mapping'] = np.asarray(mask)
+        out[f'{name}/cells'] = np.array([[int(v) for v in c] for c in cells], dtype=np.int64).reshape(-1, 7)
+        out[f'{name}/default_size_thresh'] = np.int64(defaults['size_thresh'])
+        out[f'{name}/default_marker_thresh'] = np.int64(defaults.get('marker_thresh', -1))
+        overlay, refined, scoring = P.compute_final_results(orig.copy(), wide(seg), (wide(marker) if not use_od else marker.copy()), **kw)
+        out[f'{name}/overlay'], out[f'{name}/refined'] = np.asarray(overlay), np.asarray(refined)
+        out[f'{name}/scoring'] = np.array(repr(scoring))
+        print(name, 'cells', len(cells), 'defaults', defaults, 'scoring', scoring)
+    np.savez_compressed(os.path.join(HERE, 'post_cases.npz'), **out)
+
+
+if __name__ == '__main__':
+    main()
