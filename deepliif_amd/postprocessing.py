@@ -1,0 +1,239 @@
+"""Segmentation post-processing on the GPU -- the seam of deepliif/postprocessing.py.
+
+`compute_final_results(orig, seg, marker, resolution, ...)` keeps the reference's signature and return value
+(deepliif/postprocessing.py:1223-1304: overlay image, refined segmentation image, scoring dictionary) and its byte-exact results; the
+per-pixel work, the two connected-component labellings and the per-cell reductions run in csrc/postproc.hip (dl_pp_cells,
+dl_pp_finish).  What stays on the host is the arithmetic over the CELL LIST (hundreds to thousands of rows): noise thresholds, centroid
+rounding, the default size threshold (a 500-bin KDE of sqrt(size), :365-447, repeated expression by expression so that its float64
+comparisons agree) and the default marker threshold (:450-488, from a 256-bin histogram the GPU produces instead of np.percentile over
+the image).  There is no CPU fallback: without the HIP library this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+DEFAULT_SEG_THRESH = 120          # postprocessing.py:83
+DEFAULT_NOISE_THRESH = 4          # postprocessing.py:84
+_OD_LUT = [math.log10(255 / max(i, 1)) for i in range(256)]          # create_od_image's table (:123-130): entry 0 takes entry 1's value
+
+
+def _to_u8_cuda(img, device) -> torch.Tensor:
+    """PIL image / ndarray / tensor -> uint8 [H][W][3] CUDA tensor (to_array, :98-120: non-RGB PIL images are converted to RGB)"""
+    if isinstance(img, torch.Tensor):
+        t = img
+    else:
+        try:
+            from PIL import Image
+            if isinstance(img, Image.Image):
+                img = np.asarray(img if img.mode == 'RGB' else img.convert('RGB'))
+        except ImportError:
+            pass
+        t = torch.from_numpy(np.array(img, copy=True))            # (PIL-backed arrays are read-only)
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError(f'expected a uint8 H x W x 3 image, got {tuple(t.shape)} {t.dtype}')
+    t = t.to(device)
+    return t if t.stride(2) == 1 and t.stride(1) == 3 else t.contiguous()
+
+
+def calculate_large_noise_thresh(large_noise_thresh, resolution):
+    """postprocessing.py:1125-1133"""
+    if large_noise_thresh != 'default':
+        return large_noise_thresh
+    return {'10x': 1000, '20x': 4000}.get(resolution, 16000)
+
+
+def calculate_default_size_threshold(cell_sizes, resolution='40x') -> int:
+    """postprocessing.py:406-447 (+ create_kde :365-403): first local minimum of a Gaussian KDE (500 bins, bandwidth 1) of sqrt(size),
+    clamped to the resolution's allowed range.  Same float64 expressions in the same order as the reference's loops."""
+    sizes = np.asarray(cell_sizes, dtype=np.int64)
+    if sizes.shape[0] <= 1:
+        return 0
+    values = [float(v) for v in np.sqrt(sizes)]
+    count, inv = 500, 1 / math.sqrt(2 * math.pi)
+    step = (max(values) + 1) / count
+    n = len(values)
+    kde = np.zeros(count, dtype=np.float32)
+    exp = math.exp
+    for i in range(count):
+        x = i * step
+        total = 0
+        for v in values:
+            d = (x - v) * 1.0
+            total += exp(-(d * d / 2)) * inv
+        kde[i] = total / (n * 1.0)
+    idx = 1
+    for i in range(1, count - 1):
+        if kde[i] < kde[i - 1] and kde[i] < kde[i + 1]:
+            idx = i
+            break
+    t = (idx - 1) * step
+    lo, dflt, hi = {'20x': (3, 4, 6), '10x': (2, 2, 3)}.get(resolution, (4, 7, 10))
+    if t < lo:
+        t = lo
+    elif t > hi:
+        t = dflt
+    return round(t * t)
+
+
+def percentile_from_histogram(hist, q: float) -> float:
+    """np.percentile(values, q) (default 'linear' method) of the multiset {v repeated hist[v] times}, computed from the histogram the way
+    numpy computes it from the sorted array (numpy/lib/_function_base_impl.py: _quantile, _get_indexes, _lerp): virtual index
+    (n - 1) * (q / 100), neighbours at floor and floor + 1 (both the last element at or beyond the end), weight g = virtual - floor,
+    a + (b - a) * g, taken from the far end (b - (b - a) * (1 - g)) when g >= 0.5."""
+    hist = np.asarray(hist, dtype=np.int64)
+    n = int(hist.sum())
+    virtual = (n - 1) * np.true_divide(q, 100)
+    prev = int(math.floor(virtual))
+    nxt = prev + 1
+    if virtual >= n - 1:
+        prev = nxt = n - 1
+    if virtual < 0:
+        prev = nxt = 0
+    gamma = virtual - (prev if virtual < n - 1 else -1)
+    cum = np.cumsum(hist)
+    a = float(np.searchsorted(cum, prev, side='right'))
+    b = float(np.searchsorted(cum, nxt, side='right'))
+    diff = b - a
+    out = a + diff * gamma
+    if gamma >= 0.5:
+        out = b - diff * (1 - gamma)
+    return float(out)
+
+
+def calculate_default_marker_threshold(hist) -> int:
+    """postprocessing.py:450-488 on the histogram of the gray marker image: 90 % of the 0.1 .. 99.9 percentile range of its non-zero pixels"""
+    h = np.asarray(hist, dtype=np.int64).copy()
+    h[0] = 0
+    if int(h.sum()) == 0:
+        lo = hi = 0
+    else:
+        lo, hi = round(percentile_from_histogram(h, 0.1)), round(percentile_from_histogram(h, 99.9))
+    return round((hi - lo) * 0.9) + lo
+
+
+class CellMap:
+    """Device-side result of the cell mapping (get_cells_info, :311-362) plus the host-side cell list."""
+
+    def __init__(self, mask, label, ws, rows, keep, cells, defaults, shape):
+        self.mask, self.label, self.ws = mask, label, ws          # uint8 [H][W], int32 [H][W], workspace shared with dl_pp_finish
+        self.rows, self.keep = rows, keep                         # every component's reductions (int64 [n][8]); which of them are cells
+        self.cells, self.defaults, self.shape = cells, defaults, shape
+
+
+def get_cells_info(seg, marker, resolution, noise_thresh, seg_thresh, large_noise_thresh, use_od=False, device=None) -> CellMap:
+    """postprocessing.py:311-362.  `cells` = [(size, positive, marker value, first x, first y, centre x, centre y)] like the reference's."""
+    be = ops.impl()
+    lib = be.lib
+    dev = torch.device(device) if device is not None else (seg.device if isinstance(seg, torch.Tensor) and seg.is_cuda else torch.device('cuda', torch.cuda.current_device()))
+    seg_t = _to_u8_cuda(seg, dev)
+    mk_t = _to_u8_cuda(marker, dev) if marker is not None else None
+    H, W = int(seg_t.shape[0]), int(seg_t.shape[1])
+    if mk_t is not None and tuple(mk_t.shape) != tuple(seg_t.shape):
+        raise ValueError('seg and marker images differ in size')
+    ops._need_cuda(seg_t, mk_t)
+    nbytes = int(lib.dl_pp_ws_bytes(H, W))
+    if nbytes == 0:
+        raise RuntimeError('dl_pp_ws_bytes failed (empty or too large image)')
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    label = torch.empty((H, W), dtype=torch.int32, device=dev)
+    max_cells = min(H * W // 4 + 8, 1 << 22)                      # 8-connected components are at least two pixels apart
+    rows_d = torch.empty((max_cells, 8), dtype=torch.int64, device=dev)
+    n_d = torch.zeros(1, dtype=torch.int32, device=dev)
+    hist_d = torch.zeros(256, dtype=torch.int64, device=dev) if (mk_t is not None and not use_od) else None
+    lut_d = torch.tensor(_OD_LUT, dtype=torch.float64, device=dev) if (use_od and mk_t is not None) else None
+    p = ops._ptr
+    L.check(lib.dl_pp_cells(p(seg_t), seg_t.stride(0), p(mk_t), mk_t.stride(0) if mk_t is not None else 0, p(lut_d), H, W, int(seg_thresh),
+                            p(mask), p(label), p(ws), p(rows_d), max_cells, p(n_d), p(hist_d), ops._stream()), 'dl_pp_cells')
+    n = int(n_d.item())
+    if n > max_cells:
+        raise RuntimeError(f'{n} connected components exceed the cell table ({max_cells})')
+    rows = rows_d[:n].cpu().numpy()
+    count = rows[:, 0]
+    keep = count > noise_thresh
+    if large_noise_thresh is not None:
+        keep &= count < large_noise_thresh
+    k = rows[keep]
+    kc = k[:, 0]
+    # int(round(sum / count)): Python's round of the float64 quotient, i.e. round-half-even = np.rint of the same quotient
+    cx, cy = np.rint(k[:, 6] / kc).astype(np.int64), np.rint(k[:, 7] / kc).astype(np.int64)
+    if mk_t is None:
+        mval = np.zeros(len(k), dtype=np.int64)
+    elif use_od:
+        mval = np.rint(k[:, 3] / kc).astype(np.int64)
+    else:
+        mval = k[:, 3]
+    pos = k[:, 1] >= k[:, 2]
+    cells = [(int(a), bool(b), int(c), int(d), int(e), int(f), int(g)) for a, b, c, d, e, f, g in zip(kc, pos, mval, k[:, 4], k[:, 5], cx, cy)]
+    defaults = {'size_thresh': calculate_default_size_threshold([c[0] for c in cells], resolution)}
+    if hist_d is not None:
+        defaults['marker_thresh'] = calculate_default_marker_threshold(hist_d.cpu().numpy())
+    return CellMap(mask, label, ws, rows, keep, cells, defaults, (H, W))
+
+
+def create_cell_classification(cm: CellMap, size_thresh=0, marker_thresh=None, size_thresh_upper=None, od_thresh_lower=None, od_thresh_upper=None):
+    """The per-cell decisions of postprocessing.py:923-1000 -> (code per component for dl_pp_finish, counts)"""
+    code = np.zeros(len(cm.keep), dtype=np.uint8)
+    num_pos = num_neg = 0
+    it = iter(cm.cells)
+    for i, kept in enumerate(cm.keep):
+        if not kept:
+            continue
+        cell = next(it)
+        if not (cell[0] > size_thresh and (size_thresh_upper is None or cell[0] < size_thresh_upper)):
+            continue
+        pos = cell[1]
+        if marker_thresh is not None and cell[2] > marker_thresh:
+            pos = True
+        if od_thresh_lower is not None and cell[2] < od_thresh_lower:
+            pos = False
+        elif od_thresh_upper is not None and cell[2] > od_thresh_upper:
+            pos = False
+        code[i] = 1 if pos else 2
+        num_pos, num_neg = num_pos + (1 if pos else 0), num_neg + (0 if pos else 1)
+    return code, {'num_total': num_pos + num_neg, 'num_pos': num_pos, 'num_neg': num_neg}
+
+
+def compute_final_results(orig, seg, marker, resolution, size_thresh='default', marker_thresh=None, size_thresh_upper=None,
+                          seg_thresh=DEFAULT_SEG_THRESH, noise_thresh=DEFAULT_NOISE_THRESH, large_noise_thresh=None,
+                          od_thresh_lower=None, od_thresh_upper=None, return_tensors: bool = False, device=None):
+    """deepliif/postprocessing.py:1223-1304 -> (overlay, refined, scoring).  Images may be PIL images, uint8 ndarrays or uint8 CUDA
+    tensors (H x W x 3); the results are ndarrays like the reference's unless return_tensors (then CUDA tensors, no device->host copy)."""
+    large = calculate_large_noise_thresh(large_noise_thresh, resolution)
+    use_od = od_thresh_lower is not None or od_thresh_upper is not None
+    cm = get_cells_info(seg, orig if use_od else marker, resolution, noise_thresh, seg_thresh, large, use_od=use_od, device=device)
+    if size_thresh is None:
+        size_thresh = 0
+    elif size_thresh == 'default':
+        size_thresh = cm.defaults['size_thresh']
+    if marker_thresh == 'default':
+        marker_thresh = cm.defaults['marker_thresh']
+    code, counts = create_cell_classification(cm, size_thresh, marker_thresh, size_thresh_upper, od_thresh_lower, od_thresh_upper)
+    dev = cm.mask.device
+    H, W = cm.shape
+    orig_t = _to_u8_cuda(orig, dev)
+    if tuple(orig_t.shape[:2]) != (H, W):
+        raise ValueError('orig and seg images differ in size')
+    overlay = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    refined = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    code_d = torch.from_numpy(code).to(dev) if len(code) else None
+    p = ops._ptr
+    L.check(ops.impl().lib.dl_pp_finish(p(orig_t), orig_t.stride(0), p(cm.mask), p(cm.label), p(cm.ws), p(code_d), len(code), H, W,
+                                        p(overlay), overlay.stride(0), p(refined), refined.stride(0), ops._stream()), 'dl_pp_finish')
+    scoring = {
+        'num_total': counts['num_total'], 'num_pos': counts['num_pos'], 'num_neg': counts['num_neg'],
+        'percent_pos': round(counts['num_pos'] / counts['num_total'] * 100, 1) if counts['num_pos'] > 0 else 0,
+        'seg_thresh': seg_thresh, 'size_thresh': size_thresh, 'size_thresh_upper': size_thresh_upper,
+        'marker_thresh': marker_thresh if marker is not None else None,
+    }
+    if return_tensors:
+        return overlay, refined, scoring
+    return overlay.cpu().numpy(), refined.cpu().numpy(), scoring

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 102
+#define DL_VERSION 103
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -316,6 +316,28 @@ int dl_tile_paste_u8(int in_dtype, const void *tiles, int in_pstride, int tile, 
 /* hardware probes used by the GPU test-suite (MFMA fragment layouts, ds_read_b64_tr_b16 semantics) */
 int dl_probe_mfma16(const uint16_t *a /*16x32 bf16 row-major*/, const uint16_t *b /*32x16*/, float *d /*16x16*/, void *stream);
 int dl_probe_trread(const uint16_t *src /*64 rows x 16 cols bf16*/, uint16_t *dst /*64 lanes x 4*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Segmentation post-processing (deepliif/postprocessing.py: get_cells_info :311-362 = create_posneg_mask :163-190 + mark_background
+ * :193-232 + compute_cell_mapping :235-308; create_cell_classification :923-1000, enlarge_cell_boundaries :1003-1030,
+ * create_final_images :1033-1071; driven by compute_final_results :1223-1304).  uint8 H x W x 3 images with a row stride in bytes;
+ * bit-exact with the reference (integer work): connected components by union-find, "first in raster order" rules as index minima.
+ *
+ * dl_pp_cells: seg (+ marker, or the original image together with od_lut[256] = log10(255/i) for the optical-density variant) ->
+ *   mask  uint8 [H][W]: BACKGROUND 0 / CELL 100 (the reference's labels after the cell mapping),
+ *   label int32 [H][W]: smallest pixel index of the pixel's cell (-1 on background) = the cell's first pixel in raster order,
+ *   cells int64 [n][8] in list order: {size, positive pixels, negative pixels, marker max (or optical-density sum), first x, first y,
+ *         sum of x, sum of y} for EVERY component (the host applies the noise thresholds and rounds the centroid), at most max_cells rows,
+ *   n_cells (device int): number of components, hist (device u64[256], may be NULL): histogram of the gray marker values.
+ * dl_pp_finish: code[n_cells] (0 = not counted, 1 = positive, 2 = negative, in the order of `cells`) -> final label mask (in place),
+ *   overlay and refined images.  `ws` (dl_pp_ws_bytes) must be the SAME buffer in both calls.
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t dl_pp_ws_bytes(int H, int W);
+int dl_pp_cells(const void *seg, size_t seg_row_stride, const void *marker, size_t marker_row_stride, const double *od_lut,
+                int H, int W, int seg_thresh, void *mask, int *label, void *ws, long long *cells, int max_cells,
+                int *n_cells, unsigned long long *hist, void *stream);
+int dl_pp_finish(const void *orig, size_t orig_row_stride, void *mask, const int *label, const void *ws, const void *code, int n_cells,
+                 int H, int W, void *overlay, size_t overlay_row_stride, void *refined, size_t refined_row_stride, void *stream);
 
 #ifdef __cplusplus
 }

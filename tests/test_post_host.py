@@ -1,0 +1,39 @@
+"""Host-side arithmetic of deepliif_amd/postprocessing.py (no GPU): the default thresholds computed from the cell list / the marker
+histogram must equal the reference's values (fixtures) and numpy's percentile."""
+import os
+
+import numpy as np
+import pytest
+
+from deepliif_amd import postprocessing as PP
+
+Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'post_cases.npz'))
+NAMES = [str(n) for n in Z['names']]
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_default_thresholds_from_reference_cell_lists(name):
+    kw = eval(str(Z[f'{name}/kwargs']))
+    cells = Z[f'{name}/cells']
+    assert PP.calculate_default_size_threshold(cells[:, 0], kw['resolution']) == int(Z[f'{name}/default_size_thresh'])
+    want = int(Z[f'{name}/default_marker_thresh'])
+    if want >= 0:
+        gray = Z[f'{name}/marker'].max(axis=-1)
+        hist = np.bincount(gray.ravel(), minlength=256)
+        assert PP.calculate_default_marker_threshold(hist) == want
+
+
+def test_percentile_from_histogram_is_numpys_percentile():
+    rng = np.random.RandomState(0)
+    for trial in range(300):
+        n = int(rng.choice([1, 2, 3, 7, 100, 1001, 5000]))
+        lo, hi = sorted(rng.randint(1, 256, size=2))
+        v = rng.randint(lo, hi + 1, size=n).astype(np.uint8)
+        hist = np.bincount(v, minlength=256)
+        for q in (0.1, 99.9, 50.0, 25.0, 0.0, 100.0):
+            assert PP.percentile_from_histogram(hist, q) == float(np.percentile(v, q)), (n, q)
+
+
+def test_large_noise_threshold_table():
+    assert [PP.calculate_large_noise_thresh('default', r) for r in ('10x', '20x', '40x')] == [1000, 4000, 16000]
+    assert PP.calculate_large_noise_thresh(None, '40x') is None and PP.calculate_large_noise_thresh(123, '10x') == 123

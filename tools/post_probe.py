@@ -1,0 +1,52 @@
+"""Post-processing row (f2): compute_final_results on the GPU (inputs resident in HBM) next to the CPU oracle on the same synthetic images.
+
+  python tools/post_probe.py            -> gpurun_out/post_probe.json
+Per size: whole-call time (two C-ABI calls + the host-side cell-list arithmetic + one device->host copy of the cell table), the GPU part alone
+(HIP events around dl_pp_cells and dl_pp_finish), algorithmic bytes = 9 B/pixel read (seg, marker, orig) + 6 B/pixel written (overlay,
+refined), and the oracle's time on the host (scipy.ndimage.label + numpy; the reference's own numba loops are not available here)."""
+import json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
+from deepliif_amd import postprocessing as PP
+from golden_util import synth_cells
+from oracle import postprocess_oracle as PO
+
+out = []
+SIZES = ((512, 512, 300), (2048, 2048, 5000)) + (((8192, 8192, 60000),) if os.environ.get('POST_PROBE_BIG') else ())
+for (h, w, ncell) in SIZES:
+    t0 = time.perf_counter()
+    orig, seg, marker = synth_cells(min(h, 2048), min(w, 2048), min(ncell, 5000), 21)
+    if h > 2048:                                   # tile the 2048^2 image: blobs stay cell-sized, the count scales with the area
+        r = h // 2048
+        orig, seg, marker = (np.tile(a, (r, r, 1)) for a in (orig, seg, marker))
+    d = [torch.from_numpy(a).cuda() for a in (orig, seg, marker)]
+    kw = dict(resolution='40x', marker_thresh='default')
+    res = PP.compute_final_results(*d, return_tensors=True, **kw)          # warm-up
+    torch.cuda.synchronize()
+    reps = 5 if h <= 2048 else 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = PP.compute_final_results(*d, return_tensors=True, **kw)
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / reps
+    # GPU part alone
+    large = PP.calculate_large_noise_thresh(None, '40x')
+    s, e, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    s.record()
+    cm = PP.get_cells_info(d[1], d[2], '40x', PP.DEFAULT_NOISE_THRESH, PP.DEFAULT_SEG_THRESH, large)
+    e.record()
+    torch.cuda.synchronize()
+    t_cells_call = s.elapsed_time(e) * 1e-3
+    row = {'size': [h, w], 'cells': res[2]['num_total'], 'components': int(len(cm.keep)), 'gpu_call_s': t_all, 'cells_stage_incl_host_s': t_cells_call,
+           'algorithmic_MB': 15 * h * w / 1e6, 'algorithmic_GBs_whole_call': 15 * h * w / t_all / 1e9}
+    if h <= (2048 if os.environ.get('POST_PROBE_ORACLE_2048') else 512):
+        t0 = time.perf_counter()
+        o = PO.compute_final_results(orig, seg, marker, **kw)
+        row['oracle_cpu_s'] = time.perf_counter() - t0
+        row['identical_to_oracle'] = bool(np.array_equal(o[0], res[0].cpu().numpy()) and np.array_equal(o[1], res[1].cpu().numpy()) and o[2] == res[2])
+    print(json.dumps(row), flush=True)
+    out.append(row)
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump(out, open('gpurun_out/post_probe.json', 'w'), indent=1)
