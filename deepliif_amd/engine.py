@@ -40,7 +40,7 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -50,6 +50,7 @@ class Act:
         self.bias_grad: Optional[torch.Tensor] = None     # conv output: where the producer's bias gradient accumulates
         self.bias_done = False                            # set when a consumer's backward already added sum(dy) to it
         self.stats = None                                 # conv output: (chunks, workspace token) of fused norm statistics
+        self.norm_only = False                            # conv output handed straight to ONE norm_act and to nothing else (conv(stats=True))
         self.bn_ctx = None                                # norm_act output z = act(norm(y)): (y tensor, statistics, act) for a consumer conv's backward
         self.grad_stats = None                            # (chunks, workspace token): the ONLY contribution to .grad also left the norm-backward reductions
 
@@ -211,7 +212,8 @@ class Ctx:
 def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
          stats: bool = False) -> Act:
     """y = act(conv(in_act(x)) + bias).  `out` may be a channel-slice view of a concat buffer.
-    stats: the caller feeds y straight into norm_act -- let the conv epilogue produce the norm statistics when it can."""
+    stats: the caller feeds y straight into ONE norm_act and into nothing else -- let the conv epilogue produce the norm statistics when
+    it can, and let that norm's backward add sum(dy) to this conv's bias gradient (dy is then the only gradient y ever receives)."""
     be = ops.impl()
     spec = layer.spec
     n, hi, wi, _ = x.t.shape
@@ -248,6 +250,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                               ctx.prec.prec, want_stats=stats and act == L.ACT_NONE)
         del xin
     y = Act(out, spec.cout, x_needs or w_needs)
+    y.norm_only = bool(stats)       # the caller's promise (see the docstring); norm_act's bias-gradient fusion relies on it
     if nch:
         y.stats = (nch, be.norm_ws_token())
     if not (x_needs or w_needs):
@@ -373,7 +376,9 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
         affine = m is not None and m.weight.requires_grad
         if y.needs_grad or affine:
             dy = empty_like_act(g)
-            fuse_bias = y.bias_grad is not None and y.grad is None and not y.bias_done     # dy is y's ONLY gradient contribution
+            # dy is y's ONLY gradient contribution: promised by the producer (conv(stats=True) -> norm_only), not inferred from the moment's
+            # y.grad (a consumer recorded EARLIER on the tape would contribute later and its share of the bias gradient would be lost)
+            fuse_bias = y.bias_grad is not None and y.norm_only and y.grad is None and not y.bias_done
             be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None,
                              y.bias_grad if fuse_bias else None, ext_nchunks=ext_b)
             if fuse_bias:
