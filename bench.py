@@ -38,7 +38,7 @@ GF_PER_TILE_INFER = 1828.0
 GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 + 5 UNet-512 generators, 9 NLayerD) step
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = os.path.join('r01', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
+PMC_FILE = os.path.join('r02', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
 def make_opt(args, device_index, M=5, seg_gen=False):

@@ -354,7 +354,10 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
                                                   int oh, int ow, int wm, int wn, int lane, int tid, char *smem_raw) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
-    constexpr int UNITS = BN / 4, SWZ = (UNITS - 1) & ~3;       // 8-byte units per tile row; unit bits the pixel index is XORed into
+    // 8-byte units per tile row; unit bits the pixel index is XORed into.  Bit 0 stays (a 16-byte read needs units 2c, 2c+1 adjacent);
+    // bits 1-4 select the bank pair, so XORing the pixel's low 4 bits there spreads the 16 lanes of a DPP row (16 pixels, same channels)
+    // over all 32 bank pairs -- XORing into bits 2-5 left pixels p and p+8 on the same banks (1.6 M conflict cycles per launch by PMC)
+    constexpr int UNITS = BN / 4, SWZ = (UNITS - 1) & ~1;
     constexpr int CH = BN / 8;                                  // 16-byte chunks per tile row
     char *tile = smem_raw;
     int *rowtab = reinterpret_cast<int *>(smem_raw + (size_t)BM * BN * 2);
@@ -396,7 +399,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
             for (int r = 0; r < 4; ++r) bias[r] = (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
         }
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int unit = (cl >> 2) ^ ((fr << 2) & SWZ);
+        const int unit = (cl >> 2) ^ ((fr << 1) & SWZ);
         char *dst = tile + (size_t)(wm * PM + fr) * (BN * 2) + unit * 8;
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
@@ -439,7 +442,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
             const int opix = rowtab[row];
             const int co = tn * BN + c * 8;
             if (opix < 0 || co >= a.Co) continue;
-            const int unit = (c * 2) ^ ((row << 2) & SWZ);
+            const int unit = (c * 2) ^ (((row & 15) << 1) & SWZ);
             const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
             *reinterpret_cast<u32x4_t *>(out + (size_t)opix * a.out_pstride + co) = v;
         }
@@ -476,7 +479,7 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
         for (int it = 0; it < ITER; ++it) {
             if (opx[it] < 0) continue;
             const int row = rg + it * RG;
-            const int unit = (c * 2) ^ ((row << 2) & SWZ);
+            const int unit = (c * 2) ^ (((row & 15) << 1) & SWZ);
             const u32x4_t v = *reinterpret_cast<const u32x4_t *>(tile + (size_t)row * (BN * 2) + unit * 8);
             *reinterpret_cast<u32x4_t *>(out + (size_t)opx[it] * a.out_pstride + co) = v;
 #pragma unroll
