@@ -441,34 +441,22 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
 }
 
 // grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b].  Threads walk the slab in its own (contiguous) order so the reads
-// coalesce; the (small) gradient tensor takes the strided writes.  Four adjacent lanes share one float4 column: lane q adds the partials
-// q, q + 4, ... in index order with all of its loads in flight (28 partials of the ResnetBlock shape = 7 per lane), then the four lane
-// sums are combined as (s0 + s1) + (s2 + s3) with two DPP quad permutes -- a fixed summation tree, so the result is deterministic.  One
-// lane per column with `unroll 4` (r01) kept 36 KB per CU in flight and ran at 3 TB/s on the 66 MB slab.
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));     // lanes 1,0,3,2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));     // lanes 2,3,0,1
-    return v;
-}
+// coalesce; the (small) gradient tensor takes the strided writes.  (A 4-lanes-per-column variant with every load in flight was tried in
+// r02: 22.9 vs 21.6 us on the 66 MB ResnetBlock slab -- the pass is bound by reading partials the previous kernel has just written,
+// not by loads in flight -- so the sequential summation order stayed.)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate, int stack_kw) {
     const int J4 = J / 4;
     const size_t total = (size_t)CA * J4;
     const size_t kstride = (size_t)CAp * J;
-    const int sub = threadIdx.x & 3;
-    // every lane of a quad runs the same number of iterations (the DPP permutes need all four lanes alive)
-    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2; i < ((total + 63) / 64) * 64; i += ((size_t)gridDim.x * blockDim.x) >> 2) {
-        const bool live = i < total;
-        const size_t ii = live ? i : 0;
-        const int ca = (int)(ii / J4), j = (int)(ii % J4) * 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ca = (int)(i / J4), j = (int)(i % J4) * 4;
         const float *src = slab + (size_t)ca * J + j;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int k = sub; k < splitk; k += 4) s += *reinterpret_cast<const f32x4_t *>(src + k * kstride);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = quad_sum(s[e]);
+#pragma unroll 4
+        for (int k = 0; k < splitk; ++k) s += *reinterpret_cast<const f32x4_t *>(src + k * kstride);
         const int t = j / CBp, b0 = j % CBp;            // 4 consecutive j share the tap (CBp is a multiple of 8)
-        if (!live || sub != 0 || t >= KK) continue;
+        if (t >= KK) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = b0 + e;
@@ -555,7 +543,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
 
     const int KK = d->KH * d->KW;
     const size_t total = (size_t)d->CA * (a.J / 4);
-    const int blocks = (int)min((size_t)8192, (total + 63) / 64);          // 64 float4 columns per 256-thread block (4 lanes each)
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
                        grad, d->accumulate, d->stack_kw);
     DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");
