@@ -420,6 +420,233 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Four-phase schedule of the 256 x 256 x 64 weight-gradient tile (the ResnetBlock shape; same tile, LDS image and fragment reads as
+// wgrad_glds_kernel<256, 2, 4> above, different schedule -- the one conv_gemm_8ph_kernel uses for the forward / data gradient):
+//   * a K step (64 pixels) is cut into four phases of 16 MFMAs: (pixels 0-31 | 32-63) x (the wave's lower | upper 64 of its 128 P channels),
+//     two raw s_barriers per phase; waves 4-7 run ONE barrier behind waves 0-3 (wave w and w + 4 share a SIMD), so on every SIMD one wave
+//     multiplies while the other one issues its transposing LDS reads and its DMA instead of all eight waves doing each in lock step;
+//   * the operands of a K step are two 32-pixel halves H0, H1 (P and Q rows, 32 KB each) that are dead after phases 1 and 3: a half is
+//     refilled TWO phases after its last read (the reads are only known to be complete once the MFMAs that consume them have run, i.e. at
+//     the reading phase's second barrier; forcing them complete before its first barrier with lgkmcnt(0) exposed the LDS latency in
+//     every phase: 225 vs 192 us), five phases ahead of its next use, and never waited for with vmcnt(0) in the steady state:
+//         phase of step t    reads                                      stages (4 DMA instructions per wave), then waits
+//               0            Q(H0): 4 fragments, P(H0) lower: 4         -
+//               1            P(H0) upper: 4                             H1 of step t+1 (other buffer);  vmcnt(8): H1(t) has landed
+//               2            Q(H1): 4, P(H1) lower: 4                   -
+//               3            P(H1) upper: 4                             H0 of step t+2 (this buffer);   vmcnt(8): H0(t+1) has landed
+// ------------------------------------------------------------------------------------------------------------------
+#define DL_WBAR() asm volatile("s_barrier" ::: "memory")
+template <int V> struct IC { static constexpr int value = V; };
+__global__ void __launch_bounds__(512) wgrad_8ph_kernel(const WgradArgs a) {
+    constexpr int BA = 256, BJ = 256, BP = 64, HP = 32;
+    constexpr int ROWA = BA * 2, ROWJ = BJ * 2;             // row bytes
+    constexpr int TA = BP * BA, TJ = BP * BJ, BUF = TA + TJ; // elements
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *smem = reinterpret_cast<bf16_t *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wj = wave >> 1;
+    const bool grp1 = wave >= 4;
+    int bid, ks;
+    if (a.xcd_group) {
+        const int ntile = gridDim.x;
+        const int logical = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
+        ks = logical / ntile;
+        bid = logical - ks * ntile;
+    } else {
+        bid = xcd_remap(blockIdx.x, gridDim.x);
+        ks = blockIdx.y;
+    }
+    const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
+    const int p_begin = ks * a.pchunk;
+    const int p_end = min(a.Ptot, p_begin + a.pchunk);
+    const int T = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const bf16_t *P = reinterpret_cast<const bf16_t *>(a.P);
+    const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.Q);
+    const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_wzero_page);
+
+    // ---- staging geometry: instruction (h, i) of this wave fills rows h*32 + wave*4 + i*2 + {0, 1} of the P and of the Q tile
+    const bf16_t *p_src[2][2];
+    int p_row[2][2];
+    int q_row[2][2], q_n[2][2], q_h[2][2], q_w[2][2], q_kh[2][2], q_kw[2][2], q_cb[2][2];
+    bool q_tap_ok[2][2];
+    const int HWp = a.Hp * a.Wp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = h * HP + wave * 4 + i * 2 + (lane >> 5);          // 32 lanes x 16 B = one 512-byte row
+            const int cpos = lane & 31;                                       // 16-byte position inside the LDS row
+            const int c = (((cpos >> 1) ^ wswz(row)) << 1) | (cpos & 1);      // global chunk that belongs there
+            p_row[h][i] = row;
+            p_src[h][i] = P + (size_t)(p_begin + row) * a.p_pstride + ta * BA + c * 8;
+            const int j0 = tj * BJ + c * 8;
+            const int tap = j0 >> a.log2CB;
+            q_row[h][i] = row;
+            q_cb[h][i] = j0 & (a.CBp - 1);
+            q_tap_ok[h][i] = tap < a.KH * a.KW;
+            q_kh[h][i] = q_tap_ok[h][i] ? tap / a.KW : 0;
+            q_kw[h][i] = q_tap_ok[h][i] ? tap - q_kh[h][i] * a.KW : 0;
+            const int p = p_begin + row;
+            q_n[h][i] = p / HWp;
+            const int rem = p - q_n[h][i] * HWp;
+            q_h[h][i] = rem / a.Wp;
+            q_w[h][i] = rem - q_h[h][i] * a.Wp;
+        }
+
+    // Staging a half = prep (addresses + validity of this lane's 2 P and 2 Q pieces; advances the lane's Q pixels of that half by 64) and
+    // issue (the 4 DMA instructions).  The prep runs in the shadow of the wave's own MFMAs one phase before the issue: with the address
+    // arithmetic inside the read sections (between the barriers, where the partner wave's MFMAs only cover ~256 clocks) the four-phase
+    // schedule was SLOWER than the one-barrier kernel (218 vs 191 us).
+    const bf16_t *srcP[2], *srcQ[2];
+    auto prep_half = [&](auto HH, int kt) __attribute__((always_inline)) {
+        constexpr int h = decltype(HH)::value;
+        const int pbase = p_begin + kt * BP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            srcP[i] = (pbase + p_row[h][i] < p_end) ? p_src[h][i] + (size_t)kt * BP * a.p_pstride : zero;
+            const int hh = q_h[h][i] * a.step - a.pad + q_kh[h][i], ww = q_w[h][i] * a.step - a.pad_w + q_kw[h][i];
+            const bool ok = q_tap_ok[h][i] && (pbase + q_row[h][i] < p_end) && ((unsigned)hh < (unsigned)a.Hq) && ((unsigned)ww < (unsigned)a.Wq);
+            srcQ[i] = ok ? Q + ((size_t)(q_n[h][i] * a.Hq + hh) * a.Wq + ww) * a.q_pstride + q_cb[h][i] : zero;
+            q_w[h][i] += a.dw;
+            const int cw = q_w[h][i] >= a.Wp;
+            q_w[h][i] -= cw ? a.Wp : 0;
+            q_h[h][i] += a.dh + cw;
+            const int chh = q_h[h][i] >= a.Hp;
+            q_h[h][i] -= chh ? a.Hp : 0;
+            q_n[h][i] += a.dn + chh;
+        }
+    };
+    auto issue_half = [&](auto HH, int bufi) __attribute__((always_inline)) {
+        constexpr int h = decltype(HH)::value;
+        bf16_t *base = smem + bufi * BUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcP[i],
+                                             (__attribute__((address_space(3))) void *)(base + (h * HP + wave * 4 + i * 2) * BA), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcQ[i],
+                                             (__attribute__((address_space(3))) void *)(base + TA + (h * HP + wave * 4 + i * 2) * BJ), 16, 0, 0);
+    };
+    auto stage_half = [&](auto HH, int kt, int bufi) __attribute__((always_inline)) { prep_half(HH, kt); issue_half(HH, bufi); };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: H0(0), H1(0), H0(1) -- H1(1) is staged by phase 1 of step 0.  The staging ORDER per half is kt = 0, 1, 2, ... (the
+    // pixel advance is stateful)
+    if (T > 0) { stage_half(IC<0>{}, 0, 0); stage_half(IC<1>{}, 0, 0); }
+    if (T > 1) {
+        stage_half(IC<0>{}, 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // H0(0) has landed; H1(0), H0(1) stay in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DL_WBAR();
+    if (grp1) DL_WBAR();          // stagger: waves 4-7 run one barrier behind
+
+    bf16x8_t bq[4], ap[4];
+    auto read_q = [&](const bf16_t *Qs, int prow0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = tr_fragment_swz<ROWJ>(Qs, prow0, wj * 4 + j, lane);
+    };
+    auto read_p = [&](const bf16_t *Ps, int prow0, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ap[i] = tr_fragment_swz<ROWA>(Ps, prow0, wa * 8 + half * 4 + i, lane);
+    };
+    auto mma = [&](auto HALF) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(HALF)::value * 4;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i], bq[j], acc[i0 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // first barrier, the 16 MFMAs of this phase (+ PREP: next half's addresses, independent VALU work issued between them), second barrier
+#define DL_W_PHASE_SYNC_MMA(HALF, PREP)                        \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    DL_WBAR();                                                 \
+    mma(IC<HALF>{});                                           \
+    PREP;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    DL_WBAR();
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        const bf16_t *Ps = smem + cur * BUF, *Qs = Ps + TA;
+        const bool more1 = t + 1 < T, more2 = t + 2 < T;
+        // ---- phase 0
+        read_q(Qs, 0);
+        read_p(Ps, 0, 0);
+        DL_W_PHASE_SYNC_MMA(0, if (more1) prep_half(IC<1>{}, t + 1))
+        // ---- phase 1
+        read_p(Ps, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) {
+            issue_half(IC<1>{}, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // H1(t) has landed; H0(t+1), H1(t+1) stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        DL_W_PHASE_SYNC_MMA(1, (void)0)
+        // ---- phase 2
+        read_q(Qs, HP);
+        read_p(Ps, HP, 0);
+        DL_W_PHASE_SYNC_MMA(0, if (more2) prep_half(IC<0>{}, t + 2))
+        // ---- phase 3
+        read_p(Ps, HP, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) {
+            issue_half(IC<0>{}, cur);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // H0(t+1) has landed; H1(t+1), H0(t+2) stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        DL_W_PHASE_SYNC_MMA(1, (void)0)
+    }
+    if (!grp1) DL_WBAR();         // pairs with the last barrier of the trailing group
+
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = tj * BJ + wj * 64 + j * 16 + fr;
+            if (jj >= a.J) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ca = ta * BA + wa * 128 + i * 16 + fg * 4 + r;
+                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+            }
+        }
+}
+
+static int launch_wgrad_8ph(WgradArgs a, hipStream_t stream) {
+    constexpr size_t smem = (size_t)2 * 64 * (256 + 256) * sizeof(bf16_t);
+    a.tiles_a = a.CAp / 256;
+    a.tiles_j = (a.J + 255) / 256;
+    a.pchunk = ((a.Ptot + a.splitk - 1) / a.splitk + 63) / 64 * 64;
+    const int hw = a.Hp * a.Wp;
+    a.dn = 64 / hw; a.dh = (64 % hw) / a.Wp; a.dw = (64 % hw) % a.Wp;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_8ph_kernel, dim3(a.tiles_a * a.tiles_j, a.splitk), dim3(512), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(8-phase)");
+    return 0;
+}
+
 template <int BA, int WA, int WJ>
 static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 64 * (BA + 256) * sizeof(bf16_t);
@@ -533,7 +760,13 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
     const bool fast = d->dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->p_act == DL_ACT_NONE && d->q_act == DL_ACT_NONE &&
                       d->pad_mode == DL_PAD_ZERO && a.J >= 256 && a.Ptot >= 64 * d->splitk && !no_glds;
-    if (fast && (d->CAp % 256) == 0) rc = launch_wgrad_glds<256, 2, 4>(a, stream);
+    // "1": the four-phase schedule (wgrad_8ph_kernel).  OFF by default -- measured r02, same box, ResnetBlock shape, kernel + reduce:
+    // 217-225 us vs 191-193 us for the one-barrier kernel in all three variants tried (reads retired before the first barrier; restage
+    // two phases later without forced waits; address arithmetic moved into the MFMA shadow).  The one-barrier kernel alone is 172 us,
+    // within 8 % of the forward's 8-phase kernel (155-160 us), so there was little left to win here.
+    static const char *w8 = getenv("DL_WGRAD_8PH");
+    if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') rc = launch_wgrad_8ph(a, stream);
+    else if (fast && (d->CAp % 256) == 0) rc = launch_wgrad_glds<256, 2, 4>(a, stream);
     else if (fast && (d->CAp % 128) == 0) rc = launch_wgrad_glds<128, 2, 4>(a, stream);
     else if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
     else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
