@@ -525,3 +525,57 @@ def _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mo
                 tile = tensor_to_pil(v[i:i + 1]).resize((tile_size, tile_size))
                 put(k, np.asarray(tile), t)
     return {k: Image.fromarray(v[:h, :w]) for k, v in out.items()}
+
+
+def find_marker_key(dictionary):
+    """deepliif/models/__init__.py:950-954"""
+    for key in dictionary:
+        if key.endswith('Marker'):
+            return key
+    return None
+
+
+def postprocess(orig, images, tile_size, model, seg_thresh=120, size_thresh='default', marker_thresh=None, size_thresh_upper=None):
+    """Drop-in for deepliif.models.postprocess (deepliif/models/__init__.py:582-610): the stitched Seg (+ Marker) images -> overlay / refined
+    images and the scoring dictionary, through the GPU post-processing (deepliif_amd/postprocessing.py) instead of the numba loops."""
+    from PIL import Image
+    from .postprocessing import compute_final_results
+    if model in ('DeepLIIF', 'DeepLIIFKD'):
+        resolution = '40x' if tile_size > 384 else ('20x' if tile_size > 192 else '10x')
+        mk = find_marker_key(images)
+        overlay, refined, scoring = compute_final_results(orig, images['Seg'], images.get(mk) if mk is not None else None, resolution,
+                                                          size_thresh, marker_thresh, size_thresh_upper, seg_thresh)
+        return {'SegOverlaid': Image.fromarray(overlay), 'SegRefined': Image.fromarray(refined)}, scoring
+    if model in ('DeepLIIFExt', 'SDG'):
+        resolution = '40x' if tile_size > 768 else ('20x' if tile_size > 384 else '10x')
+        processed, scoring = {}, {}
+        for name in list(images.keys()):
+            if 'Seg' in name:
+                overlay, refined, score = compute_final_results(orig, images[name], None, resolution, size_thresh, marker_thresh, size_thresh_upper,
+                                                                seg_thresh)
+                processed[name + '_Overlaid'], processed[name + '_Refined'] = Image.fromarray(overlay), Image.fromarray(refined)
+                scoring[name] = score
+        return processed, scoring
+    raise Exception(f'postprocess() not implemented for model {model}')
+
+
+def infer_modalities(img, tile_size, model_dir, eager_mode=False, color_dapi=False, color_marker=False, opt=None, return_seg_intermediate=False,
+                     seg_only=False, mod_only=False, seg_weights=None, nets=None, batch_size=8):
+    """Drop-in for deepliif.models.infer_modalities (deepliif/models/__init__.py:613-660): inference() with overlap tile_size // 16, then
+    postprocess() when the model has a segmentation branch.  -> (images, scoring)"""
+    if opt is None:
+        opt = get_opt(model_dir)
+        opt.use_dp = False
+    images = inference(img, tile_size=tile_size, overlap_size=tile_size // 16, model_path=model_dir, eager_mode=eager_mode, color_dapi=color_dapi,
+                       color_marker=color_marker, opt=opt, return_seg_intermediate=return_seg_intermediate, seg_only=seg_only, mod_only=mod_only,
+                       seg_weights=seg_weights, nets=nets, batch_size=batch_size)
+    if not hasattr(opt, 'seg_gen') or opt.seg_gen:
+        if not mod_only:
+            post_images, scoring = postprocess(img, images, tile_size, opt.model)
+            images = {**images, **post_images}
+            if seg_only:
+                for name in [k for k in images.keys() if 'Seg' not in k]:
+                    del images[name]
+            return images, scoring
+        return images, None
+    return images, None

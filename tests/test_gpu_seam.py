@@ -97,3 +97,24 @@ def test_model_on_second_argument_device_uses_that_devices_stream():
         out = nets['G1'](x.cuda())
     side.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_infer_modalities_adds_postprocessed_images_and_scoring(tmp_path):
+    """infer_modalities = inference() + postprocess() (deepliif/models/__init__.py:582-660): the glue picks Seg / Marker, derives the resolution
+    from the tile size and returns SegOverlaid / SegRefined + the scoring dictionary; the post-processing of the INFERRED images must equal the
+    pinned oracle's post-processing of the same images byte for byte."""
+    from deepliif_amd import inference as I
+    from oracle import postprocess_oracle as PO
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    opt = _opt(mdir, 'fp32')
+    _, img2 = _images()
+    images, scoring = I.infer_modalities(img2, 64, mdir, eager_mode=True, opt=opt)
+    assert 'SegOverlaid' in images and 'SegRefined' in images and images['SegOverlaid'].size == img2.size
+    mk = I.find_marker_key(images)
+    o_overlay, o_refined, o_scoring = PO.compute_final_results(np.asarray(img2), np.asarray(images['Seg']), np.asarray(images[mk]) if mk else None, '10x')
+    assert np.array_equal(np.asarray(images['SegOverlaid']), o_overlay) and np.array_equal(np.asarray(images['SegRefined']), o_refined)
+    assert scoring == o_scoring
+    only_seg, _ = I.infer_modalities(img2, 64, mdir, eager_mode=True, opt=opt, seg_only=True)
+    assert all('Seg' in k for k in only_seg)
+    mods, none = I.infer_modalities(img2, 64, mdir, eager_mode=True, opt=opt, mod_only=True)
+    assert none is None and 'SegOverlaid' not in mods

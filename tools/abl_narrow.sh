@@ -1,2 +1,2 @@
 # scratch driver for the probe of the moment (rewritten per experiment)
-timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_seam.py tests/test_gpu_post.py -q -m gpu -x 2>&1 | tail -6
