@@ -66,6 +66,7 @@ SIGNATURES = {
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
     'dl_conv_bnstats_chunks': (_i, [C.POINTER(ConvDesc)]),
     'dl_pp_ws_bytes': (C.c_size_t, [_i, _i]),
+    'dl_pp_kde_first_minimum': (_i, [_vp, _i, _i, _vp, _vp]),
     'dl_pp_cells': (_i, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'dl_pp_finish': (_i, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     'dl_conv_forward_bnstats': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvBnStats), _vp]),

@@ -344,3 +344,36 @@ extern "C" int dl_pp_finish(const void *orig, size_t orig_row_stride, void *mask
     DL_CHECK_LAUNCH("dl_pp_finish");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------- host-only helper
+// calculate_default_size_threshold's kernel density estimate (postprocessing.py:365-447) over the cell list: count bins, bandwidth 1,
+// kde[i] = float32( sum_j exp(-((i*step - v_j)^2 / 2)) / sqrt(2 pi)  / n ), summed over j in list order in float64 -- the reference's
+// loop, expression by expression (libm exp, no contraction), because its float32 comparisons kde[i] < kde[i-1] decide the threshold.
+// Plain host code (no GPU): the Python loop it replaces spent 115 ms on 2 648 cells.  Returns the index of the first local minimum
+// (1 if there is none) and the step through *step_out.
+#include <math.h>
+extern "C" int dl_pp_kde_first_minimum(const double *values, int n, int count, double *step_out, float *kde_out) {
+#pragma clang fp contract(off)
+    if (!values || n <= 0 || count < 3 || !step_out) DL_FAIL("dl_pp_kde_first_minimum: bad argument");
+    const double inv = 1 / sqrt(2 * M_PI);
+    double vmax = values[0];
+    for (int j = 1; j < n; ++j) vmax = values[j] > vmax ? values[j] : vmax;
+    const double step = (vmax + 1) / count;
+    float *kde = kde_out ? kde_out : (float *)malloc(sizeof(float) * (size_t)count);
+    if (!kde) DL_FAIL("dl_pp_kde_first_minimum: out of memory");
+    for (int i = 0; i < count; ++i) {
+        const double x = i * step;
+        double total = 0;
+        for (int j = 0; j < n; ++j) {
+            const double val = (x - values[j]) * 1.0;
+            total += exp(-(val * val / 2)) * inv;
+        }
+        kde[i] = (float)(total / (n * 1.0));
+    }
+    int idx = 1;
+    for (int i = 1; i < count - 1; ++i)
+        if (kde[i] < kde[i - 1] && kde[i] < kde[i + 1]) { idx = i; break; }
+    if (!kde_out) free(kde);
+    *step_out = step;
+    return idx;
+}

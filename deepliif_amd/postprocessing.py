@@ -56,24 +56,13 @@ def calculate_default_size_threshold(cell_sizes, resolution='40x') -> int:
     sizes = np.asarray(cell_sizes, dtype=np.int64)
     if sizes.shape[0] <= 1:
         return 0
-    values = [float(v) for v in np.sqrt(sizes)]
-    count, inv = 500, 1 / math.sqrt(2 * math.pi)
-    step = (max(values) + 1) / count
-    n = len(values)
-    kde = np.zeros(count, dtype=np.float32)
-    exp = math.exp
-    for i in range(count):
-        x = i * step
-        total = 0
-        for v in values:
-            d = (x - v) * 1.0
-            total += exp(-(d * d / 2)) * inv
-        kde[i] = total / (n * 1.0)
-    idx = 1
-    for i in range(1, count - 1):
-        if kde[i] < kde[i - 1] and kde[i] < kde[i + 1]:
-            idx = i
-            break
+    values = np.ascontiguousarray(np.sqrt(sizes), dtype=np.float64)
+    # the KDE loop itself (n x 500 exp calls in the reference's summation order) is host code inside the library: dl_pp_kde_first_minimum
+    step = C.c_double(0.0)
+    idx = int(L.load().dl_pp_kde_first_minimum(values.ctypes.data_as(C.c_void_p), int(values.shape[0]), 500, C.byref(step), None))
+    if idx < 0:
+        L.check(idx, 'dl_pp_kde_first_minimum')
+    step = step.value
     t = (idx - 1) * step
     lo, dflt, hi = {'20x': (3, 4, 6), '10x': (2, 2, 3)}.get(resolution, (4, 7, 10))
     if t < lo:

@@ -336,6 +336,10 @@ size_t dl_pp_ws_bytes(int H, int W);
 int dl_pp_cells(const void *seg, size_t seg_row_stride, const void *marker, size_t marker_row_stride, const double *od_lut,
                 int H, int W, int seg_thresh, void *mask, int *label, void *ws, long long *cells, int max_cells,
                 int *n_cells, unsigned long long *hist, void *stream);
+/* Host-only (no GPU work): the 500-bin Gaussian KDE of calculate_default_size_threshold (postprocessing.py:365-447) over values =
+ * sqrt(cell size), in the reference's float64 summation order; returns the index of the first local minimum (1 if none), the bin step
+ * through *step, optionally the float32 KDE itself through kde (count entries, may be NULL). */
+int dl_pp_kde_first_minimum(const double *values, int n, int count, double *step, float *kde);
 int dl_pp_finish(const void *orig, size_t orig_row_stride, void *mask, const int *label, const void *ws, const void *code, int n_cells,
                  int H, int W, void *overlay, size_t overlay_row_stride, void *refined, size_t refined_row_stride, void *stream);
 

@@ -37,3 +37,33 @@ def test_percentile_from_histogram_is_numpys_percentile():
 def test_large_noise_threshold_table():
     assert [PP.calculate_large_noise_thresh('default', r) for r in ('10x', '20x', '40x')] == [1000, 4000, 16000]
     assert PP.calculate_large_noise_thresh(None, '40x') is None and PP.calculate_large_noise_thresh(123, '10x') == 123
+
+
+def test_library_kde_is_the_reference_loop_bit_for_bit():
+    """dl_pp_kde_first_minimum (host code in the library, libm exp) against the expression-by-expression Python loop of the pinned oracle:
+    same threshold for random cell lists, and the float32 KDE itself identical in every bin."""
+    import ctypes as C
+    import math
+    from deepliif_amd import _lib as L
+    from oracle import postprocess_oracle as PO
+    rng = np.random.RandomState(3)
+    for trial in range(12):
+        n = int(rng.choice([2, 3, 17, 200, 1500]))
+        sizes = np.maximum(1, (rng.gamma(2.0, 40.0, size=n)).astype(np.int64))
+        for res in ('40x', '20x', '10x'):
+            assert PP.calculate_default_size_threshold(sizes, res) == PO.default_size_threshold(sizes, res)
+    sizes = np.maximum(1, (rng.gamma(2.0, 40.0, size=300)).astype(np.int64))
+    values = np.ascontiguousarray(np.sqrt(sizes), dtype=np.float64)
+    kde = np.zeros(500, dtype=np.float32)
+    step = C.c_double(0.0)
+    L.load().dl_pp_kde_first_minimum(values.ctypes.data_as(C.c_void_p), 300, 500, C.byref(step), kde.ctypes.data_as(C.c_void_p))
+    inv = 1 / math.sqrt(2 * math.pi)
+    want = np.zeros(500, dtype=np.float32)
+    st = (float(values.max()) + 1) / 500
+    for i in range(500):
+        x, total = i * st, 0
+        for v in values:
+            val = (x - v) * 1.0
+            total += math.exp(-(val * val / 2)) * inv
+        want[i] = total / (300 * 1.0)
+    assert step.value == st and np.array_equal(kde.view(np.uint32), want.view(np.uint32))

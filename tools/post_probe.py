@@ -17,10 +17,10 @@ out = []
 SIZES = ((512, 512, 300), (2048, 2048, 5000)) + (((8192, 8192, 60000),) if os.environ.get('POST_PROBE_BIG') else ())
 for (h, w, ncell) in SIZES:
     t0 = time.perf_counter()
-    orig, seg, marker = synth_cells(min(h, 2048), min(w, 2048), min(ncell, 5000), 21)
-    if h > 2048:                                   # tile the 2048^2 image: blobs stay cell-sized, the count scales with the area
-        r = h // 2048
-        orig, seg, marker = (np.tile(a, (r, r, 1)) for a in (orig, seg, marker))
+    orig, seg, marker = synth_cells(512, 512, 300, 21)
+    if h > 512:                                    # tile the 512^2 image (the generator is O(cells x pixels)): blobs stay cell-sized, the count scales with the area
+        r = h // 512
+        orig, seg, marker = (np.ascontiguousarray(np.tile(a, (r, r, 1))) for a in (orig, seg, marker))
     d = [torch.from_numpy(a).cuda() for a in (orig, seg, marker)]
     kw = dict(resolution='40x', marker_thresh='default')
     res = PP.compute_final_results(*d, return_tensors=True, **kw)          # warm-up
