@@ -2,7 +2,8 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
 (deepliif_amd/postprocessing.py -> csrc/postproc.hip) never does.  Pinned by tests/golden/post_cases.npz, which holds what the
-reference itself returned for seeded synthetic images (tests/golden/make_golden_post.py), stage by stage.
+reference itself returned for seeded synthetic images (tests/golden/make_golden_post.py), stage by stage, and the reference's own shipped
+known answers (Datasets/Sample_Dataset/val/metrics.json: cell counts of its two validation images).
 
 The reference is sequential in-place code (numba loops, explicit flood-fill stacks).  This restatement is written declaratively --
 connected components (scipy.ndimage.label), per-component reductions, neighbourhood tests -- with the order-dependent corners of the

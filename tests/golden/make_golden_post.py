@@ -10,7 +10,9 @@ the reference's own function) -- values and comparisons are unchanged, only the 
 
 Stored per case: the three uint8 input images and the options, and what the reference returned: the label mask and cell list of
 get_cells_info (postprocessing.py:311-362), the default thresholds, and overlay / refined / scoring of compute_final_results
-(:1223-1304).  Inputs come from golden_util.synth_cells (seeded), so the GPU tests regenerate nothing -- they read this file."""
+(:1223-1304).  Inputs come from golden_util.synth_cells (seeded), so the GPU tests regenerate nothing -- they read this file.
+Two more cases are the reference's own test data: the two validation images of Datasets/Sample_Dataset/val with the cell counts recorded in
+its metrics.json (a known-answer test the reference ships; the images are data files, stored here as arrays)."""
 import os
 import sys
 
@@ -62,6 +64,35 @@ def main():
         out[f'{name}/overlay'], out[f'{name}/refined'] = np.asarray(overlay), np.asarray(refined)
         out[f'{name}/scoring'] = np.array(repr(scoring))
         print(name, 'cells', len(cells), 'defaults', defaults, 'scoring', scoring)
+    # ---- the reference's own known answers: Datasets/Sample_Dataset/val/{Lung1,Bladder1}.png are 6 tiles side by side (IHC, Hema, DAPI,
+    # Lap2, Marker, Seg) and val/metrics.json holds the cell counts its postprocess produced for them (prob_thresh = seg_thresh = 150)
+    import json
+    from PIL import Image
+    val = '/root/reference/Datasets/Sample_Dataset/val'
+    metrics = json.load(open(os.path.join(val, 'metrics.json')))
+    names = list(out['names'])
+    for n in ('Lung1', 'Bladder1'):
+        im = np.asarray(Image.open(os.path.join(val, n + '.png')).convert('RGB'))
+        orig, marker, seg = (np.ascontiguousarray(im[:, i * 512:(i + 1) * 512]) for i in (0, 4, 5))
+        name = 'sample_' + n
+        kw = dict(resolution='40x', size_thresh=metrics[n]['size_thresh'], seg_thresh=metrics[n]['prob_thresh'])
+        out[f'{name}/orig'], out[f'{name}/seg'], out[f'{name}/marker'] = orig, seg, marker
+        out[f'{name}/kwargs'] = np.array(repr(kw))
+        large = P.calculate_large_noise_thresh(None, '40x')
+        mask, cells, defaults = P.get_cells_info(wide(seg), wide(marker), '40x', P.DEFAULT_NOISE_THRESH, kw['seg_thresh'], large, use_od=False)
+        out[f'{name}/mask_after_mapping'] = np.asarray(mask)
+        out[f'{name}/cells'] = np.array([[int(v) for v in c] for c in cells], dtype=np.int64).reshape(-1, 7)
+        out[f'{name}/default_size_thresh'] = np.int64(defaults['size_thresh'])
+        out[f'{name}/default_marker_thresh'] = np.int64(defaults.get('marker_thresh', -1))
+        overlay, refined, scoring = P.compute_final_results(orig.copy(), wide(seg), wide(marker), **kw)
+        out[f'{name}/overlay'], out[f'{name}/refined'] = np.asarray(overlay), np.asarray(refined)
+        out[f'{name}/scoring'] = np.array(repr(scoring))
+        out[f'{name}/metrics_json'] = np.array(repr(metrics[n]))
+        for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos'):
+            assert scoring[k] == metrics[n][k], (n, k, scoring[k], metrics[n][k])          # today's reference code reproduces its recorded counts
+        names.append(name)
+        print(name, 'cells', len(cells), 'scoring', scoring, '== metrics.json', metrics[n])
+    out['names'] = np.array(names)
     np.savez_compressed(os.path.join(HERE, 'post_cases.npz'), **out)
 
 

@@ -74,3 +74,12 @@ def test_pil_inputs_and_tensor_outputs():
     assert overlay.is_cuda and refined.is_cuda and overlay.dtype == torch.uint8
     assert np.array_equal(overlay.cpu().numpy(), Z[f'{name}/overlay']) and np.array_equal(refined.cpu().numpy(), Z[f'{name}/refined'])
     assert scoring == eval(str(Z[f'{name}/scoring']))
+
+
+@pytest.mark.parametrize('name', [n for n in NAMES if n.startswith('sample_')])
+def test_known_answers_of_the_reference_sample_dataset(name):
+    """The reference's own recorded cell counts (Datasets/Sample_Dataset/val/metrics.json) through the GPU path"""
+    kw = eval(str(Z[f'{name}/kwargs']))
+    want = eval(str(Z[f'{name}/metrics_json']))
+    _, _, scoring = PP.compute_final_results(Z[f'{name}/orig'], Z[f'{name}/seg'], Z[f'{name}/marker'], **kw)
+    assert {k: scoring[k] for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos')} == {k: want[k] for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos')}
