@@ -17,7 +17,7 @@ import torch
 
 from . import engine as E
 from . import networks
-from .models import _get, init_input_and_mod_id
+from .models import _get
 
 
 def read_model_params(path):

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import os
 from collections import OrderedDict
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 
@@ -20,7 +20,6 @@ from . import _lib as L
 from . import engine as E
 from . import networks
 from .distributed import GradExchanger
-from .optim import FusedAdam
 
 
 def _get(opt, name, default):

@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional
 
 import numpy as np
 import torch
