@@ -225,3 +225,154 @@ def compute_final_results(orig, seg, marker, resolution, size_thresh='default', 
     if return_tensors:
         return overlay, refined, scoring
     return overlay.cpu().numpy(), refined.cpu().numpy(), scoring
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-cell export (compute_cell_results, postprocessing.py:1136-1220): host code over the label mask the GPU produced.  Boundary
+# tracing is pointer chasing along each cell's outline (a few dozen steps per cell); the "v4" strings are DeepLIIF's wire format
+# for cell lists (base-92 numbers + Freeman chain code), so their layout below is a contract, not a choice.
+# ---------------------------------------------------------------------------------------------------------------
+_RING = ((-1, -1), (0, -1), (1, -1), (1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0))        # (dx, dy), clockwise from the upper-left neighbour
+_RING_INDEX = {d: i for i, d in enumerate(_RING)}
+
+
+def get_cell_boundary(mask, x, y):
+    """postprocessing.py:491-581: Moore-neighbour trace of the cell whose first pixel (raster order) is (x, y), clockwise, ending when the
+    start pixel is re-entered from the pixel that precedes it on the outline.  mask: 2-D array, 0 = background.
+    -> ([(min x, min y), (max x, max y)], [(x, y), ...])"""
+    h, w = mask.shape
+    if not (0 <= y < h and 0 <= x < w) or mask[y, x] == 0:
+        return None, None
+
+    def cell(px, py):
+        return 0 <= px < w and 0 <= py < h and mask[py, px] != 0
+
+    # the pixel that precedes the start on a clockwise outline: first cell neighbour met going COUNTER-clockwise from the lower-left one
+    k = 6
+    while k >= 0 and not cell(x + _RING[k][0], y + _RING[k][1]):
+        k -= 1
+    if k < 0:
+        return [(x, y), (x, y)], [(x, y)]
+    first_prev = (x + _RING[k][0], y + _RING[k][1])
+    start = (x, y)
+    prev, cur = first_prev, start
+    outline = [start]
+    x0 = x1 = x
+    y0 = y1 = y
+    while True:
+        k = (_RING_INDEX[(prev[0] - cur[0], prev[1] - cur[1])] + 1) % 8          # continue clockwise just past where we came from
+        while not cell(cur[0] + _RING[k][0], cur[1] + _RING[k][1]):
+            k = (k + 1) % 8
+        prev, cur = cur, (cur[0] + _RING[k][0], cur[1] + _RING[k][1])
+        if prev == first_prev and cur == start:          # closed: the reference's list ends here too (it drops this closing pair)
+            break
+        outline.append(cur)
+        x0, x1 = min(x0, cur[0]), max(x1, cur[0])
+        y0, y1 = min(y0, cur[1]), max(y1, cur[1])
+    return [(x0, y0), (x1, y1)], outline
+
+
+def make_simple_contour(points):
+    """postprocessing.py:584-634: drop the interior points of straight runs (the direction signs before and after a point agree); the last
+    point is compared against the wrap-around to the first"""
+    pts = [(int(p[0]), int(p[1])) for p in points]
+    if len(pts) == 1:
+        return pts[:]
+    sgn = lambda v: (v > 0) - (v < 0)
+    keep = [pts[0]]
+    n = len(pts)
+    for i in range(1, n):
+        a, b, c = pts[i - 1], pts[i], pts[(i + 1) % n]
+        if (sgn(b[0] - a[0]), sgn(b[1] - a[1])) != (sgn(c[0] - b[0]), sgn(c[1] - b[1])):
+            keep.append(b)
+    return keep
+
+
+def to_base92(values, min_len=1):
+    """postprocessing.py:685-727: big-endian base-92 digits as characters 35..126; several values share one width (>= min_len, padded with
+    chr(35) = the digit 0)"""
+    single = not isinstance(values, (list, tuple))
+    vals = [values] if single else list(values)
+    digits = []
+    for v in vals:
+        v = int(v)
+        d = ''
+        while v > 0:
+            d = chr(v % 92 + 35) + d
+            v //= 92
+        digits.append(d)
+    width = max(max(len(d) for d in digits), min_len)
+    out = [d.rjust(width, chr(35)) for d in digits]
+    return out[0] if single else out
+
+
+def from_base92(val):
+    """postprocessing.py:730-749"""
+    res = 0
+    for ch in val:
+        res = res * 92 + (ord(ch) - 35)
+    return res
+
+
+_FREEMAN = {(1, 0): 0, (1, -1): 1, (0, -1): 2, (-1, -1): 3, (-1, 0): 4, (-1, 1): 5, (0, 1): 6, (1, 1): 7}      # (sign dx, sign dy) -> code
+
+
+def encode_cell_data_v4(data, v6=False):
+    """postprocessing.py:752-848.  Layout: [lengths byte] size | classification (2 digits: marker * 2 + positive) | bbox top-left x, y |
+    offsets from it of: bbox bottom-right, centroid, first boundary point (6 numbers, one width) | Freeman chain of the remaining boundary
+    points, one character per run of <= 10 steps: chr(35 + 8 * steps + direction).  lengths byte = chr(35 + 16 (|size| - 1) + 4 (|top-left| - 1)
+    + (|offsets| - 1))."""
+    size = to_base92(data['size'])
+    marker = data['od'] if v6 else data['marker']
+    body = size + to_base92(int(marker) * 2 + int(data['positive']), 2)
+    (ax, ay), (bx, by) = data['bbox']
+    topleft = to_base92([ax, ay])
+    body += topleft[0] + topleft[1]
+    cx, cy = data['centroid']
+    fx, fy = data['boundary'][0]
+    offs = to_base92([bx - ax, by - ay, cx - ax, cy - ay, fx - ax, fy - ay])
+    body += ''.join(offs)
+    head = chr(35 + (len(size) - 1) * 16 + (len(topleft[0]) - 1) * 4 + (len(offs[0]) - 1))
+    chain = []
+    pts = data['boundary']
+    for j in range(1, len(pts)):
+        dx, dy = pts[j][0] - pts[j - 1][0], pts[j][1] - pts[j - 1][1]
+        steps = max(abs(dx), abs(dy))
+        if steps == 0:
+            continue
+        code = _FREEMAN[((dx > 0) - (dx < 0), (dy > 0) - (dy < 0))]
+        while steps > 10:
+            chain.append(chr(35 + 80 + code))
+            steps -= 10
+        chain.append(chr(35 + steps * 8 + code))
+    return head + body + ''.join(chain)
+
+
+def cell_results_from_mapping(mask, cells, defaults, version, seg_thresh, noise_thresh, large_noise_thresh):
+    """The host half of compute_cell_results (:1170-1220): per-cell boundary, bbox and (for versions 4 / 6) the encoded string.
+    mask: 2-D uint8 ndarray after the cell mapping (0 = background), cells / defaults as get_cells_info returns them."""
+    od = version in (5, 6)
+    out = []
+    for c in cells:
+        bbox, boundary = get_cell_boundary(mask, c[3], c[4])
+        data = {'size': c[0], 'positive': c[1], ('od' if od else 'marker'): c[2], 'bbox': bbox, 'centroid': (c[5], c[6]),
+                'boundary': make_simple_contour(boundary)}
+        out.append(encode_cell_data_v4(data, v6=(version == 6)) if version in (4, 6) else data)
+    settings = {'default_size_thresh': defaults['size_thresh'], 'noise_thresh': noise_thresh, 'large_noise_thresh': large_noise_thresh,
+                'seg_thresh': seg_thresh}
+    if not od:
+        settings['default_marker_thresh'] = defaults['marker_thresh'] if 'marker_thresh' in defaults else None
+    return {'cells': out, 'settings': settings, 'dataVersion': version}
+
+
+def compute_cell_results(seg, marker, resolution, version=3, seg_thresh=DEFAULT_SEG_THRESH, noise_thresh=DEFAULT_NOISE_THRESH,
+                         large_noise_thresh=None, device=None):
+    """deepliif/postprocessing.py:1136-1220: individual cell data.  Versions 3 / 4 take the inferred marker image, 5 / 6 the ORIGINAL image
+    (optical density); 4 / 6 return every cell as one encoded ASCII string."""
+    import warnings
+    if version not in (3, 4, 5, 6):
+        warnings.warn('Invalid cell data version provided, defaulting to version 3.')
+        version = 3
+    large = calculate_large_noise_thresh(large_noise_thresh, resolution)
+    cm = get_cells_info(seg, marker, resolution, noise_thresh, seg_thresh, large, use_od=version in (5, 6), device=device)
+    return cell_results_from_mapping(cm.mask.cpu().numpy(), cm.cells, cm.defaults, version, seg_thresh, noise_thresh, large)

@@ -36,6 +36,16 @@ CASES = [
 ]
 
 
+def cell_results(P, out, name, orig, seg, marker, kw, wide):
+    """compute_cell_results (postprocessing.py:1136-1220) for data versions 3 (dicts), 4 (base-92 strings), 5 / 6 (optical density from the
+    original image): stored as repr() strings"""
+    ckw = {k: kw[k] for k in ('seg_thresh', 'noise_thresh', 'large_noise_thresh') if k in kw}
+    for version in (3, 4, 5, 6):
+        mk = orig.copy() if version >= 5 else wide(marker)
+        res = P.compute_cell_results(wide(seg), mk, kw['resolution'], version=version, **ckw)
+        out[f'{name}/cell_results_v{version}'] = np.array(repr(res))
+
+
 def main():
     install_stubs()
     import importlib.util
@@ -63,6 +73,7 @@ def main():
         overlay, refined, scoring = P.compute_final_results(orig.copy(), wide(seg), (wide(marker) if not use_od else marker.copy()), **kw)
         out[f'{name}/overlay'], out[f'{name}/refined'] = np.asarray(overlay), np.asarray(refined)
         out[f'{name}/scoring'] = np.array(repr(scoring))
+        cell_results(P, out, name, orig, seg, marker, kw, wide)
         print(name, 'cells', len(cells), 'defaults', defaults, 'scoring', scoring)
     # ---- the reference's own known answers: Datasets/Sample_Dataset/val/{Lung1,Bladder1}.png are 6 tiles side by side (IHC, Hema, DAPI,
     # Lap2, Marker, Seg) and val/metrics.json holds the cell counts its postprocess produced for them (prob_thresh = seg_thresh = 150)
@@ -88,6 +99,7 @@ def main():
         out[f'{name}/overlay'], out[f'{name}/refined'] = np.asarray(overlay), np.asarray(refined)
         out[f'{name}/scoring'] = np.array(repr(scoring))
         out[f'{name}/metrics_json'] = np.array(repr(metrics[n]))
+        cell_results(P, out, name, orig, seg, marker, kw, wide)
         for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos'):
             assert scoring[k] == metrics[n][k], (n, k, scoring[k], metrics[n][k])          # today's reference code reproduces its recorded counts
         names.append(name)

@@ -83,3 +83,13 @@ def test_known_answers_of_the_reference_sample_dataset(name):
     want = eval(str(Z[f'{name}/metrics_json']))
     _, _, scoring = PP.compute_final_results(Z[f'{name}/orig'], Z[f'{name}/seg'], Z[f'{name}/marker'], **kw)
     assert {k: scoring[k] for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos')} == {k: want[k] for k in ('num_total', 'num_pos', 'num_neg', 'percent_pos')}
+
+
+@pytest.mark.parametrize('version', [3, 4, 5, 6])
+@pytest.mark.parametrize('name', NAMES)
+def test_compute_cell_results_against_reference_fixture(name, version):
+    """compute_cell_results end to end (GPU cell mapping + host-side boundaries / encoding) vs the reference's own output"""
+    kw = eval(str(Z[f'{name}/kwargs']))
+    ckw = {k: kw[k] for k in ('seg_thresh', 'noise_thresh', 'large_noise_thresh') if k in kw}
+    got = PP.compute_cell_results(Z[f'{name}/seg'], Z[f'{name}/orig'] if version >= 5 else Z[f'{name}/marker'], kw['resolution'], version=version, **ckw)
+    assert got == eval(str(Z[f'{name}/cell_results_v{version}']))

@@ -67,3 +67,27 @@ def test_library_kde_is_the_reference_loop_bit_for_bit():
             total += math.exp(-(val * val / 2)) * inv
         want[i] = total / (300 * 1.0)
     assert step.value == st and np.array_equal(kde.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize('version', [3, 4, 5, 6])
+@pytest.mark.parametrize('name', NAMES)
+def test_cell_results_host_half_against_reference(name, version):
+    """compute_cell_results (postprocessing.py:1136-1220) = GPU cell mapping + host-side boundary tracing / contour simplification / v4
+    base-92 encoding.  The host half, fed with the pinned oracle's mapping, must reproduce what the reference returned (dicts for versions 3 / 5,
+    encoded strings for 4 / 6) exactly."""
+    from oracle import postprocess_oracle as PO
+    kw = eval(str(Z[f'{name}/kwargs']))
+    ckw = {k: kw[k] for k in ('seg_thresh', 'noise_thresh', 'large_noise_thresh') if k in kw}
+    large = PO.large_noise_threshold(ckw.get('large_noise_thresh'), kw['resolution'])
+    use_od = version >= 5
+    mask, cells, defaults, _, _ = PO.cells_info(Z[f'{name}/seg'], Z[f'{name}/orig'] if use_od else Z[f'{name}/marker'], kw['resolution'],
+                                                ckw.get('noise_thresh', 4), ckw.get('seg_thresh', 120), large, use_od)
+    got = PP.cell_results_from_mapping(mask, cells, defaults, version, ckw.get('seg_thresh', 120), ckw.get('noise_thresh', 4), large)
+    assert got == eval(str(Z[f'{name}/cell_results_v{version}']))
+
+
+def test_base92_round_trip_and_padding():
+    assert PP.to_base92(0) == '#' and PP.to_base92(91) == '~' and PP.to_base92(92) == '$#' and PP.to_base92(5, 2) == '#(' 
+    assert PP.to_base92([1, 92 * 92]) == ['##$', '$##']
+    for v in (0, 1, 91, 92, 8463, 778687, 12345678):
+        assert PP.from_base92(PP.to_base92(v)) == v

@@ -1,2 +1,2 @@
 # scratch driver for the probe of the moment (rewritten per experiment)
-timeout 300 python tools/layer_budget.py r02j 2>&1 | grep -E "^norm"
+timeout 600 python -m pytest tests/test_gpu_post.py -q -m gpu -x 2>&1 | tail -3
