@@ -178,6 +178,17 @@ class BaseModel:
             sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
             torch.save(sd, os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name)))
 
+    def save_optimizers(self, epoch):
+        """<epoch>_optimizer_<i>.pth per optimizer, in torch.optim's checkpoint layout (the reference saves no optimizer state,
+        base_model.py:190-208 -- an extension).  Schedulers are a pure function of the epoch count and are not stored."""
+        os.makedirs(self.save_dir, exist_ok=True)
+        for i, o in enumerate(self.optimizers):
+            torch.save(o.state_dict(), os.path.join(self.save_dir, '%s_optimizer_%d.pth' % (epoch, i)))
+
+    def load_optimizers(self, epoch):
+        for i, o in enumerate(self.optimizers):
+            o.load_state_dict(torch.load(os.path.join(self.save_dir, '%s_optimizer_%d.pth' % (epoch, i)), map_location='cpu'))
+
     def load_networks(self, epoch):
         for name, net in self._nets():
             path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))

@@ -82,6 +82,49 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
+    # ---- optimizer state in torch.optim.Adam's OWN checkpoint layout, so a file written here loads into torch.optim.Adam over the same
+    # parameter list (and the other way round).  The reference never saves optimizer state (base_model.py:190-208 stores the nets only:
+    # --continue-train restarts Adam's moments from zero); BaseModel.save_optimizers / load_optimizers add it.
+    def state_dict(self):
+        g = self.param_groups[0]
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.exp_avg[off:off + p.numel()].view(p.shape).detach().cpu().clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + p.numel()].view(p.shape).detach().cpu().clone()}
+        group = {k: v for k, v in g.items() if k != 'params'}
+        group.update(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        group['params'] = list(range(len(self.flat.params)))
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.flat.params):
+            raise ValueError('optimizer state does not match this parameter set (one group over %d parameters expected)' % len(self.flat.params))
+        if groups[0].get('weight_decay', 0) or groups[0].get('amsgrad', False) or groups[0].get('maximize', False):
+            raise ValueError('FusedAdam implements plain Adam: weight_decay / amsgrad / maximize state cannot be resumed')
+        g = self.param_groups[0]
+        for k in ('lr', 'betas', 'eps', 'initial_lr'):
+            if k in groups[0]:
+                g[k] = tuple(groups[0][k]) if k == 'betas' else groups[0][k]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+        steps = set()
+        for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'optimizer state of parameter {i}: shape {tuple(st["exp_avg"].shape)} != {tuple(p.shape)}')
+            self.exp_avg[off:off + p.numel()].view(p.shape).copy_(st['exp_avg'])
+            self.exp_avg_sq[off:off + p.numel()].view(p.shape).copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): one fused step counter cannot resume that')
+        self.step_count = steps.pop() if steps else 0
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None

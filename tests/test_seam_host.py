@@ -172,3 +172,48 @@ def test_update_learning_rate_and_visuals_follow_the_reference_contract(capsys):
     model.update_learning_rate()
     assert 'learning rate = ' in capsys.readouterr().out
     assert model.optimizers[0].param_groups[0]['lr'] == pytest.approx(lr0 * (1 - 1 / 3))
+
+
+def test_optimizer_state_resumes_training_and_loads_into_torch_adam(tmp_path):
+    """save_optimizers / load_optimizers (an extension: the reference stores no optimizer state, base_model.py:190-208).  (1) A run that is
+    saved after two steps, rebuilt from the files and stepped once more ends on the SAME weights as the uninterrupted run (bitwise: Adam's
+    moments and step count came back).  (2) The file is torch.optim.Adam's own layout: torch.optim.Adam over the same parameter list loads it
+    and holds the same moments."""
+    from test_host_model import make_opt
+    from golden_util import seeded_uniform
+    batch = {'A': seeded_uniform((1, 3, 64, 64), 1), 'B': [seeded_uniform((1, 3, 64, 64), 2), seeded_uniform((1, 3, 64, 64), 3)], 'A_paths': ['p']}
+
+    def build(seed, cont):
+        torch.manual_seed(seed)
+        o = make_opt(1, True, 'batch')
+        o.checkpoints_dir, o.name, o.continue_train = str(tmp_path), 'run', cont
+        m = CpuModel(o)
+        m.setup(o)
+        return m
+
+    a = build(5, False)
+    for _ in range(2):
+        a.set_input(batch)
+        a.optimize_parameters()
+    a.save_networks('latest')
+    a.save_optimizers('latest')
+    a.set_input(batch)
+    a.optimize_parameters()                                     # the uninterrupted third step
+    b = build(6, True)                                          # different init; continue_train loads the nets
+    b.load_optimizers('latest')
+    assert b.optimizer_G.step_count == 2 and b.optimizer_D.step_count == 2
+    b.set_input(batch)
+    b.optimize_parameters()
+    for n in a.model_names:
+        for (k, va), vb in zip(getattr(a, 'net' + n).state_dict().items(), getattr(b, 'net' + n).state_dict().values()):
+            assert torch.equal(va, vb), (n, k)
+    # torch.optim.Adam reads the same file
+    sd = torch.load(os.path.join(str(tmp_path), 'run', 'latest_optimizer_0.pth'))
+    params = [torch.nn.Parameter(p.detach().clone()) for p in b.optimizers[0].flat.params]
+    ta = torch.optim.Adam(params, lr=1.0)
+    ta.load_state_dict(sd)
+    assert ta.param_groups[0]['lr'] == pytest.approx(sd['param_groups'][0]['lr']) and tuple(ta.param_groups[0]['betas']) == (0.5, 0.999)
+    st = ta.state[params[3]]
+    assert float(st['step']) == 2.0 and torch.equal(st['exp_avg'], sd['state'][3]['exp_avg'])
+    with pytest.raises(ValueError):
+        b.optimizers[1].load_state_dict(sd)                     # the generator set's state does not fit the discriminator set
