@@ -65,6 +65,7 @@ SIGNATURES = {
     'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
     'dl_conv_bnstats_chunks': (_i, [C.POINTER(ConvDesc)]),
+    'dl_convt4_gather': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'dl_pp_ws_bytes': (C.c_size_t, [_i, _i]),
     'dl_pp_kde_first_minimum': (_i, [_vp, _i, _i, _vp, _vp]),
     'dl_pp_cells': (_i, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -127,8 +128,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 103:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 103 (stale build)')
+    if lib.dl_version() != 104:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 104 (stale build)')
     _lib = lib
     return lib
 

@@ -467,6 +467,48 @@ extern "C" int dl_shift_sum(const float *Tm, int N, int H, int W, int Tc, int Co
     DL_CHECK_LAUNCH("dl_shift_sum");
     return 0;
 }
+// Narrow-Cout transposed conv (the UNet's outermost ConvTranspose2d(2*ngf, 3, k=4, s=2, p=1) + Tanh, networks.py:573-576): every input
+// pixel feeds 4 x 4 output positions, so the gather GEMM (4 sub-pixel phases x 4 taps) stages each input pixel 16 times for 3 useful output
+// columns: 327 us at 8 x 256^2 x 128 -> 512^2.  Instead T[n,y,x,(ky*4+kx)*Cout+co] = sum_ci x[n,y,x,ci] * W[ci,co,ky,kx] is ONE plain GEMM over the
+// input (dl_conv_forward(raw_out) with a 1 x 1 plan: the input is staged once) and this kernel sums the 2 x 2 contributions of every output pixel:
+//   out[n,oy,ox,co] = act(bias[co] + sum_{ky,kx : (oy+1-ky), (ox+1-kx) even, in range} T[n,(oy+1-ky)/2,(ox+1-kx)/2,(ky*4+kx)*Cout+co])
+template <typename T>
+__global__ void __launch_bounds__(256) convt4_gather_kernel(const float *Tm, int N, int H, int W, int Tc, int Cout, const float *bias, int act,
+                                                            T *out, int o_ps, int oCp) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t npix = (size_t)N * Ho * Wo;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ((oy + 1) & 1) + 2 * a;                  // the two kernel rows with (oy + 1 - ky) even
+            const int y = (oy + 1 - ky) >> 1;
+            if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int kx = ((ox + 1) & 1) + 2 * b;
+                const int x = (ox + 1 - kx) >> 1;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const float *t = Tm + (((size_t)n * H + y) * W + x) * Tc + (ky * 4 + kx) * Cout;
+                for (int c = 0; c < Cout; ++c) acc[c] += t[c];
+            }
+        }
+        T *o = out + p * o_ps;
+        for (int c = 0; c < Cout; ++c) store1<T>(o + c, apply_act(act, acc[c] + (bias ? bias[c] : 0.f)));
+        for (int c = Cout; c < oCp; ++c) store1<T>(o + c, 0.f);
+    }
+}
+extern "C" int dl_convt4_gather(const float *Tm, int N, int H, int W, int Tc, int Cout, const float *bias, int act, int out_dtype, void *out,
+                                int o_ps, int oCp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!Tm || !out || N <= 0 || H <= 0 || W <= 0 || Cout < 1 || Cout > 4 || 16 * Cout > Tc || Cout > oCp) DL_FAIL("dl_convt4_gather: bad argument");
+    const size_t npix = (size_t)N * 4 * H * W;
+    if (out_dtype == DL_F32) hipLaunchKernelGGL(convt4_gather_kernel<float>, dim3(EW_BLOCKS(npix)), dim3(256), 0, stream, Tm, N, H, W, Tc, Cout, bias, act, (float *)out, o_ps, oCp);
+    else hipLaunchKernelGGL(convt4_gather_kernel<bf16_t>, dim3(EW_BLOCKS(npix)), dim3(256), 0, stream, Tm, N, H, W, Tc, Cout, bias, act, (bf16_t *)out, o_ps, oCp);
+    DL_CHECK_LAUNCH("dl_convt4_gather");
+    return 0;
+}
 // D[n,h,w,co*KW+kw] = dy[n,h,w-(kw-pad),co]  (zero outside; zero padding only).  One thread per pixel builds its whole
 // Dc-channel row in registers and writes it with 16-byte stores.
 template <typename T>

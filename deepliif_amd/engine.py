@@ -93,6 +93,8 @@ def new_act(n, h, w, c, prec: Precision, device, zero=False) -> Act:
 
 # A/B switch (DL_CONV_PREACT=0 disables): apply a conv's input activation in a separate pass so the conv can take the direct-to-LDS path
 _PREACT = os.environ.get('DL_CONV_PREACT', '1') != '0'
+# A/B switch (DL_CONVT4=0 disables): narrow-Cout ConvTranspose2d(4, 2, 1) at inference as one 1x1 GEMM + a 2x2 gather-sum (conv() below)
+_CONVT4 = os.environ.get('DL_CONVT4', '1') != '0'
 
 
 def empty_like_act(a: torch.Tensor) -> torch.Tensor:
@@ -148,6 +150,21 @@ class ConvLayer:
                 self.packed_dgrad = ops.PackedWeights(self.dgrad_plan, w.device, with_lo)
             be.pack_weights(self.packed_dgrad, w.detach())
             self.dgrad_key = key
+
+    def ensure_packed_taps(self, prec: Precision):
+        """Narrow-Cout ConvTranspose2d(k=4, s=2, p=1) at inference (conv() below): the weights as ONE 1x1 GEMM image with a row per
+        (ky, kx, co) -- W'[(ky*4+kx)*Cout + co][ci] = W[ci][co][ky][kx] -- so the input is staged once instead of once per (phase, tap)."""
+        w = self.weight
+        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device))
+        if getattr(self, 'taps_key', None) != key:
+            spec = self.spec
+            if getattr(self, 'packed_taps', None) is None or self.packed_taps.hi.device != w.device:
+                self.taps_spec = ConvSpec('conv', spec.cin, 16 * spec.cout, 1, 1, 0)
+                self.packed_taps = ops.PackedWeights(self.taps_spec.forward_plan(), w.device, prec.prec == L.PREC_BF16X3)
+            wt = w.detach().permute(2, 3, 1, 0).reshape(16 * spec.cout, spec.cin, 1, 1).contiguous()
+            ops.impl().pack_weights(self.packed_taps, wt)
+            self.taps_key = key
+        return self.packed_taps
 
 
 class PackBatch:
@@ -229,6 +246,20 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     if layer.narrow and in_act == L.ACT_NONE and ctx.prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
         # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
         be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
+        nch = 0
+    elif (_CONVT4 and spec.kind == 'convT' and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and spec.cout <= 4 and not (x_needs or w_needs)
+          and ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16 and getattr(be, 'convt4_gather', None) is not None):
+        # UnetGenerator's outermost up-convolution to 3 channels (networks.py:573-576), inference: one 1x1 GEMM over the input with a row per
+        # (ky, kx, co), then the 2x2 gather-sum + bias + tanh (dl_convt4_gather).  The 4-phase gather GEMM stages every input pixel 16 times for
+        # 3 useful columns: 327 us at 8 x 256^2 x 128, 5.9 % of the inference batch.
+        xin = x.t
+        if in_act != L.ACT_NONE:
+            xin = empty_like_act(x.t)
+            be.act_forward(in_act, x.t, xin)
+        T = torch.empty((n, hi, wi, cpad(16 * spec.cout)), dtype=torch.float32, device=x.t.device)
+        be.conv_forward(layer.ensure_packed_taps(ctx.prec), xin, T, hi, wi, None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, raw_out=True)
+        be.convt4_gather(T, spec.cout, layer.bias.detach() if layer.bias is not None else None, act, out)
+        del T, xin
         nch = 0
     elif layer.narrow:
         # T[n,h,w,(co,kw)] by the gather GEMM (vertical taps), then y = act(bias + sum_kw T[.., w+kw-pad, (co,kw)])

@@ -373,6 +373,14 @@ class HipBackend:
         L.check(self.lib.dl_shift_sum(_ptr(T), n, h, w, tc, cout, kw, pad, pad_mode, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out),
                                       out.shape[3], _stream()), 'dl_shift_sum')
 
+    def convt4_gather(self, T, cout, bias, act, out):
+        """second half of the narrow-Cout ConvTranspose2d(k=4, s=2, p=1): T = raw 1x1 GEMM [N,H,W,>=16*cout] fp32 -> out [N,2H,2W,Cp]"""
+        _need_cuda(T, out, bias)
+        n, h, w, tc = T.shape
+        assert T.dtype == torch.float32 and T.is_contiguous() and tuple(out.shape[:3]) == (n, 2 * h, 2 * w)
+        L.check(self.lib.dl_convt4_gather(_ptr(T), n, h, w, tc, cout, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out), out.shape[3], _stream()),
+                'dl_convt4_gather')
+
     def shift_stack(self, dy, cout, kw, pad, D):
         _need_cuda(dy, D)
         n, h, w, _ = dy.shape

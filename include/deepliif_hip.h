@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 103
+#define DL_VERSION 104
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -170,6 +170,11 @@ int dl_pack_weights_batch(const void *jobs_dev, const int32_t *block_tab_dev, in
  *   T[n,h,w,(co,kw)] = sum_{kh,ci} x[n,h+kh-pad,w,ci] * W[co,ci,kh,kw]      (dl_conv_forward, KH vertical taps, Cout*KW rows, raw_out)
  *   y[n,h,w,co]      = act(bias[co] + sum_kw T[n,h,w+kw-pad,co*KW+kw])      (dl_shift_sum)
  * and for the weight gradient  D[n,h,w,(co,kw)] = dy[n,h,w-(kw-pad),co]  (dl_shift_stack) feeds dl_conv_wgrad with KH x 1 taps. */
+/* Narrow-Cout ConvTranspose2d(k=4, s=2, p=1) (UnetGenerator's outermost up-convolution to 3 channels + Tanh, networks.py:573-576), second
+ * half: T[n,y,x,(ky*4+kx)*Cout+co] is the raw fp32 result of ONE 1x1 GEMM over the input (dl_conv_forward(raw_out) with rows = (ky,kx,co));
+ * out[n,oy,ox,co] = act(bias[co] + the 2x2 contributions with oy = 2y-1+ky, ox = 2x-1+kx).  Cout <= 4; out is N x 2H x 2W x oCp. */
+int dl_convt4_gather(const float *T, int N, int H, int W, int Tc, int Cout, const float *bias, int act, int out_dtype, void *out,
+                     int out_pstride, int out_Cp, void *stream);
 int dl_shift_sum(const float *T, int N, int H, int W, int Tc, int Cout, int KW, int pad, int pad_mode, const float *bias, int act,
                  int out_dtype, void *out, int out_pstride, int out_Cp, void *stream);
 int dl_shift_stack(int dtype, const void *dy, int dy_pstride, int N, int H, int W, int Cout, int KW, int pad, int pad_mode,

@@ -810,3 +810,39 @@ def test_norm_backward_reductions_fused_into_the_data_gradient(norm_kind, nact, 
     for key in res[True]:
         # identical inputs; the two routes differ in fp32 summation order of the reductions only (then one bf16 rounding of dy)
         assert rel(res[True][key], res[False][key]) < 4e-3, (key, rel(res[True][key], res[False][key]))
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 24, 40, 128, 3), (1, 7, 5, 16, 3), (3, 9, 33, 64, 1), (8, 256, 256, 128, 3)])
+def test_narrow_transposed_conv_as_one_gemm_plus_gather(n, h, w, cin, cout):
+    """UnetGenerator's outermost ConvTranspose2d(2*ngf, 3, 4, 2, 1) + Tanh behind an in-place ReLU (networks.py:573-576), inference route:
+    dl_conv_forward(raw_out) with one GEMM row per (ky, kx, co) + dl_convt4_gather, against torch's conv_transpose2d on the same bf16-rounded
+    operands, and against the 4-phase gather-GEMM route it replaces."""
+    if DRY:
+        pytest.skip('needs the HIP library')
+    from deepliif_amd import engine as E
+    prec = Precision.get('bf16')
+    be = hip()
+    spec = ConvSpec('convT', cin, cout, 4, 2, 1)
+    w0 = rnd((cin, cout, 4, 4), 21, prec, 0.05)
+    b0 = rnd((cout,), 22, Precision.get('fp32'), 0.1)
+    x0 = rnd((n, h, w, cin), 23, prec)
+    ref = torch.tanh(torch.nn.functional.conv_transpose2d(torch.relu(x0).permute(0, 3, 1, 2), w0, b0, stride=2, padding=1)).permute(0, 2, 3, 1)
+    outs = {}
+    for route in (True, False):
+        E._CONVT4 = route
+        layer = E.ConvLayer(spec, torch.nn.Parameter(w0.clone().to(DEV)), torch.nn.Parameter(b0.clone().to(DEV)))
+        calls = []
+        orig = be.convt4_gather
+        be.convt4_gather = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            y = E.conv(E.Ctx(prec, None, training=False), E.Act(x0.to(torch.bfloat16).to(DEV), cin, False), layer, act=L.ACT_TANH, in_act=L.ACT_RELU)
+        finally:
+            be.convt4_gather = orig
+        sync()
+        assert bool(calls) == route
+        assert tuple(y.t.shape) == (n, 2 * h, 2 * w, 8) and float(y.t[..., cout:].float().abs().max()) == 0.0
+        outs[route] = y.t[..., :cout].float().cpu()
+        assert rel(outs[route], ref) < 8e-3, (route, rel(outs[route], ref))
+    E._CONVT4 = os.environ.get('DL_CONVT4', '1') != '0'
+    ops._impl = None
+    assert rel(outs[True], outs[False]) < 8e-3
