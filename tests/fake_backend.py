@@ -266,6 +266,23 @@ class FakeBackend:
         out.zero_()
         out[..., :cout] = _act(act, acc).to(out.dtype)
 
+    def convt4_gather(self, T, cout, bias, act, out):
+        """dl_convt4_gather: out[n,oy,ox,co] = act(bias + sum over the 2x2 (ky,kx) with (oy+1-ky), (ox+1-kx) even of T[n,(oy+1-ky)/2,(ox+1-kx)/2,(ky*4+kx)*cout+co])"""
+        self._count('convt4_gather')
+        n, h, w, _ = T.shape
+        acc = torch.zeros(n, 2 * h, 2 * w, cout)
+        for ky in range(4):
+            for kx in range(4):
+                oy = 2 * torch.arange(h) - 1 + ky
+                ox = 2 * torch.arange(w) - 1 + kx
+                my, mx = (oy >= 0) & (oy < 2 * h), (ox >= 0) & (ox < 2 * w)
+                src = T[:, my][:, :, mx][..., (ky * 4 + kx) * cout:(ky * 4 + kx + 1) * cout].float()
+                acc[:, oy[my][:, None], ox[mx][None, :]] += src
+        if bias is not None:
+            acc += bias.float()
+        out.zero_()
+        out[..., :cout] = _act(act, acc).to(out.dtype)
+
     def reflect_fold(self, src, dst, pad):
         self._count('reflect_fold')
         n, h, w, cp = dst.shape

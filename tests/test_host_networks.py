@@ -153,3 +153,28 @@ def test_networks_with_dropout_train_and_eval():
     net.train()
     c, d = net(x), net(x)
     assert not torch.equal(c, d)          # two different dropout draws
+
+
+def test_narrow_transposed_conv_route_on_the_emulated_backend():
+    """The inference-only route of UnetGenerator's outermost up-convolution (engine.conv: one 1x1 GEMM with a row per (ky, kx, co) +
+    dl_convt4_gather) through the host code on the emulated backend, against torch's conv_transpose2d -- pins the derived weight image
+    W'[(ky*4+kx)*Cout+co][ci] = W[ci][co][ky][kx] and the 2x2 gather formula on CPU; the GPU kernels are checked in test_gpu_kernels.py."""
+    import fake_backend
+    from deepliif_amd import _lib as L
+    from deepliif_amd import ops
+    from deepliif_amd.geometry import ConvSpec
+    ops._impl = fake_backend.FakeBackend()
+    try:
+        g = torch.Generator().manual_seed(9)
+        n, h, w, cin, cout = 2, 5, 7, 16, 3
+        wt = (torch.randn(cin, cout, 4, 4, generator=g) * 0.1).to(torch.bfloat16).float()
+        bias = torch.randn(cout, generator=g) * 0.1
+        x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+        layer = E.ConvLayer(ConvSpec('convT', cin, cout, 4, 2, 1), torch.nn.Parameter(wt.clone()), torch.nn.Parameter(bias.clone()))
+        y = E.conv(E.Ctx(E.Precision.get('bf16'), None, training=False), E.Act(x, cin, False), layer, act=L.ACT_TANH, in_act=L.ACT_RELU)
+        assert ops._impl.calls.get('convt4_gather', 0) == 1
+        ref = torch.tanh(torch.nn.functional.conv_transpose2d(torch.relu(x.float()).permute(0, 3, 1, 2), wt, bias, stride=2, padding=1)).permute(0, 2, 3, 1)
+        assert tuple(y.t.shape) == (n, 2 * h, 2 * w, 8)
+        assert float((y.t[..., :cout].float() - ref).abs().max()) < 1e-2 and float(y.t[..., cout:].float().abs().max()) == 0.0
+    finally:
+        ops._impl = None
