@@ -1,9 +1,10 @@
-"""Post-processing row (f2): compute_final_results on the GPU (inputs resident in HBM) next to the CPU oracle on the same synthetic images.
+"""Post-processing row (f2): compute_final_results on the GPU (inputs resident in HBM) on synthetic images.
 
   python tools/post_probe.py            -> gpurun_out/post_probe.json
 Per size: whole-call time (two C-ABI calls + the host-side cell-list arithmetic + one device->host copy of the cell table), the GPU part alone
 (HIP events around dl_pp_cells and dl_pp_finish), algorithmic bytes = 9 B/pixel read (seg, marker, orig) + 6 B/pixel written (overlay,
-refined), and the oracle's time on the host (scipy.ndimage.label + numpy; the reference's own numba loops are not available here)."""
+refined).  The CPU side of the comparison (the pinned oracle: scipy.ndimage.label + numpy) is timed by the test suite, not here -- only
+tests/, smoke() and bench.py's cpu_baseline leg may execute oracle/ (tests/test_gpu_post.py::test_larger_images_against_the_oracle prints it with -s)."""
 import json, os, sys, time
 import numpy as np
 import torch
@@ -11,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
 from deepliif_amd import postprocessing as PP
 from golden_util import synth_cells
-from oracle import postprocess_oracle as PO
 
 out = []
 SIZES = ((512, 512, 300), (2048, 2048, 5000)) + (((8192, 8192, 60000),) if os.environ.get('POST_PROBE_BIG') else ())
@@ -41,11 +41,6 @@ for (h, w, ncell) in SIZES:
     t_cells_call = s.elapsed_time(e) * 1e-3
     row = {'size': [h, w], 'cells': res[2]['num_total'], 'components': int(len(cm.keep)), 'gpu_call_s': t_all, 'cells_stage_incl_host_s': t_cells_call,
            'algorithmic_MB': 15 * h * w / 1e6, 'algorithmic_GBs_whole_call': 15 * h * w / t_all / 1e9}
-    if h <= (2048 if os.environ.get('POST_PROBE_ORACLE_2048') else 512):
-        t0 = time.perf_counter()
-        o = PO.compute_final_results(orig, seg, marker, **kw)
-        row['oracle_cpu_s'] = time.perf_counter() - t0
-        row['identical_to_oracle'] = bool(np.array_equal(o[0], res[0].cpu().numpy()) and np.array_equal(o[1], res[1].cpu().numpy()) and o[2] == res[2])
     print(json.dumps(row), flush=True)
     out.append(row)
 os.makedirs('gpurun_out', exist_ok=True)
