@@ -94,8 +94,8 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline_child(norm, size):
-    """(child process) optimize_parameters() steps of the CPU oracle at batch 1, same model family, random init."""
+def cpu_baseline_child(norm, size, batch=1):
+    """(child process) optimize_parameters() steps of the CPU oracle at batch `batch` (default 1), same model family, random init."""
     from oracle import deepliif_oracle as O
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
@@ -106,8 +106,8 @@ def cpu_baseline_child(norm, size):
         nets[f'G{i}'] = O.random_state_dict('resnet_9blocks', 3, 3, 64, norm, 'zero', generator=g)
         nets[f'D{i}'] = O.random_state_dict('n_layers', 6, 3, 64, norm, 'zero', 4, generator=g)
     om = O.OracleDeepLIIF(cfg, nets)
-    A = torch.rand(1, 3, size, size, generator=g) * 2 - 1
-    B = [torch.rand(1, 3, size, size, generator=g) * 2 - 1 for _ in range(5)]
+    A = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+    B = [torch.rand(batch, 3, size, size, generator=g) * 2 - 1 for _ in range(5)]
     om.set_input({'A': A, 'B': B})
     # bounded sample of ~10-30 s of CPU work (1 warm-up + >= 3 timed steps): whole steps at batch 1, the warm-up step is
     # not counted; stops early only if the host is so slow that 3 steps would exceed ~45 s
@@ -117,7 +117,7 @@ def cpu_baseline_child(norm, size):
         t0 = time.time()
         om.optimize_parameters()
         times.append(time.time() - t0)
-    print(json.dumps({'seconds': sum(times) / len(times), 'steps': len(times), 'total_seconds': sum(times), 'cores': cores, 'size': size}), flush=True)
+    print(json.dumps({'seconds': sum(times) / len(times), 'steps': len(times), 'total_seconds': sum(times), 'cores': cores, 'size': size, 'batch': batch}), flush=True)
 
 
 def cpu_baseline(args):
@@ -126,9 +126,9 @@ def cpu_baseline(args):
     host cannot stall the benchmark; falls back to a 256x256 tile (reported in 512x512-tile equivalents) if 512x512 does not
     finish in time."""
     import subprocess
-    for size, limit in ((args.size, 240), (args.size // 2, 180)):
+    for size, limit in ((args.size, 240 * args.cpu_batch), (args.size // 2, 180 * args.cpu_batch)):
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--norm', args.norm, '--size', str(size)],
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--norm', args.norm, '--size', str(size), '--cpu-batch', str(args.cpu_batch)],
                                capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
             line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
             d = json.loads(line)
@@ -136,8 +136,8 @@ def cpu_baseline(args):
             last = f'{type(e).__name__}'
             continue
         scale = (size * size) / float(args.size * args.size)
-        return {'value': round(scale / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
-                'sample': f"1 warm-up + {d.get('steps', 1)} timed optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch 1, "
+        return {'value': round(scale * args.cpu_batch / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
+                'sample': f"1 warm-up + {d.get('steps', 1)} timed optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch {args.cpu_batch}, "
                           f"{size}x{size} tile, {d.get('total_seconds', d['seconds']):.1f} s of CPU work, {d['seconds']:.1f} s per step" + ('' if size == args.size else f' (scaled to {args.size}x{args.size}-tile units by pixel count)')}
     return {'value': None, 'unit': 'tiles/s', 'cores': usable_cores(), 'kind': 'port', 'sample': f'CPU oracle step did not finish within the time limit ({last})'}
 
@@ -160,10 +160,12 @@ def main():
     ap.add_argument('--region', type=int, default=20000, help='wsi workload: side of the synthetic square region in pixels')
     ap.add_argument('--no-strict', action='store_true', help='skip the strict-parity (fp32 policy) leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=1, help='batch size of the cpu_baseline leg: 1 = the reference default (cli.py:110) and a ~15 s sample; '
+                    '8 = the per-GPU batch of the GPU line (SURVEY 8d asks for both), ~2 minutes of CPU work')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        return cpu_baseline_child(args.norm, args.size)
+        return cpu_baseline_child(args.norm, args.size, args.cpu_batch)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under torchrun: become `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one process per
