@@ -574,30 +574,45 @@ def _resnet_units(net):
     return units
 
 
+def _nlayer_units(net):
+    """the same for an NLayerDiscriminator: conv + LeakyReLU, three conv -> norm -> LeakyReLU units, the 1-channel output conv"""
+    m, b = net.model, net._layers()
+    units = [('first', [m[0], m[1]], False, (b['first'], None), L.ACT_LRELU)]
+    idx = 2
+    for i, (c, nl) in enumerate(b['mid']):
+        units.append((f'mid{i}', [m[idx], m[idx + 1], m[idx + 2]], False, (c, nl), L.ACT_LRELU))
+        idx += 3
+    units.append(('last', [m[idx]], False, (b['last'], None), L.ACT_NONE))
+    return units
+
+
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])
 @pytest.mark.parametrize('norm', ['instance', 'batch'])
-def test_teacher_forced_layer_gradients(norm, precname):
+@pytest.mark.parametrize('arch', ['resnet_9blocks', 'n_layers'])
+def test_teacher_forced_layer_gradients(arch, norm, precname):
     """Whole-backward parity at a FIXED tolerance, without the conditioning of a 9-block reverse pass: a plain-torch fp32 teacher (the same
     module tree, equal to the pinned oracle on the output) runs forward + backward once and keeps every unit's input and the gradient
     arriving at its output; each conv -> norm -> activation (+ residual) unit of the engine then gets the TEACHER's input and the TEACHER's
     upstream gradient and must reproduce that unit's dx, d(residual) and parameter gradients: 1e-3 for the strict policy."""
     import copy
     import torch.nn.functional as F
-    nf, shape = 8, (2, 3, 64, 48)
-    sd = O.random_state_dict('resnet_9blocks', 3, 3, nf, norm, 'zero', 4, generator=torch.Generator().manual_seed(5))
-    net = build('resnet_9blocks', 3, nf, norm, 'zero')
+    is_d = arch == 'n_layers'
+    nf, cin, shape = 8, (6 if is_d else 3), ((2, 6, 64, 80) if is_d else (2, 3, 64, 48))
+    sd = O.random_state_dict(arch, cin, 3, nf, norm, 'zero', 4, generator=torch.Generator().manual_seed(5))
+    net = build(arch, cin, nf, norm, 'zero')
     net.load_state_dict(sd, strict=True)
     net.train()
     prec = E.Precision.get(precname)
-    units = _resnet_units(net)
+    make_units = _nlayer_units if is_d else _resnet_units
+    units = make_units(net)
     # ---- teacher: the same torch modules on CPU in fp32 (ReLU(True) is in-place in the tree: use functional copies)
     tnet = copy.deepcopy(net).cpu().float().train()
-    tunits = _resnet_units(tnet)
+    tunits = make_units(tnet)
 
     def run_unit(mods, x, res):
         h = x
         for mod in mods:
-            h = F.relu(h) if isinstance(mod, torch.nn.ReLU) else mod(h)
+            h = F.relu(h) if isinstance(mod, torch.nn.ReLU) else (F.leaky_relu(h, 0.2) if isinstance(mod, torch.nn.LeakyReLU) else mod(h))
         return h + res if res is not None else h
 
     x = seeded_uniform(shape, 6)
@@ -610,7 +625,8 @@ def test_teacher_forced_layer_gradients(norm, precname):
         h = run_unit(mods, xin, skip if has_res else None)
         h.retain_grad()
         keep.append((xin, skip if has_res else None, h))
-    yo = O.run_generator('resnet_9blocks', {k: v.clone() for k, v in sd.items()}, x, norm, 'zero')
+    sdo = {k: v.clone() for k, v in sd.items()}
+    yo = O.nlayer_discriminator(sdo, x, norm, 4) if is_d else O.run_generator(arch, sdo, x, norm, 'zero')
     assert rel(h, yo) < 1e-5                                   # the teacher IS the pinned oracle
     r = torch.randn(h.shape, generator=torch.Generator().manual_seed(7))
     (h * r).sum().backward()
@@ -641,8 +657,8 @@ def test_teacher_forced_layer_gradients(norm, precname):
         if res is not None:
             ra = E.to_engine(res.detach().to(DEV), prec)
             ra.needs_grad = True
-        if name == 'head':
-            ya = E.conv(ctx, xa, conv, act=L.ACT_TANH)
+        if nl is None:                      # conv with an epilogue activation only (generator head, discriminator first / last layer)
+            ya = E.conv(ctx, xa, conv, act=act)
         else:
             ya = E.norm_act(ctx, E.conv(ctx, xa, conv, stats=nl is not None), nl, act, residual=ra)
         e_y = rel(E.from_engine(ya), yout.detach())
@@ -659,8 +675,8 @@ def test_teacher_forced_layer_gradients(norm, precname):
             if os.environ.get('DL_TEST_VERBOSE'):
                 print(name, tuple(p.shape), 'max|ref| %.3e  max|err| %.3e  unit scale %.3e' % (float(rp.abs().max()), float((p.grad.cpu() - rp).abs().max()), scale))
         for k, v in errs.items():
-            kk = k if act == L.ACT_RELU else k + '_units_without_relu'
+            kk = k if act in (L.ACT_RELU, L.ACT_LRELU) else k + '_units_without_relu'
             worst[kk] = max(worst.get(kk, 0.0), v)
-            assert v <= (tol if act == L.ACT_RELU else tol_smooth), (name, k, v)
+            assert v <= (tol if act in (L.ACT_RELU, L.ACT_LRELU) else tol_smooth), (name, k, v)
     for k, v in worst.items():
-        ERRLOG[f'teacher_forced/resnet_9blocks-{norm}/{precname}/{k}'] = v
+        ERRLOG[f'teacher_forced/{arch}-{norm}/{precname}/{k}'] = v
