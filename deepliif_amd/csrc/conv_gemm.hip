@@ -1608,6 +1608,7 @@ __global__ void __launch_bounds__(256) conv_slab_reduce_kernel(const float *slab
 }
 
 #include "conv_c4.h"
+#include "conv_x3.h"
 
 // ------------------------------------------------------------------------------------------------ host dispatch
 template <typename TIn, typename TOut, int PREC, int BM, int BN, int BK, int WM, int WN>
@@ -1656,6 +1657,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (!d) return "(null)";
     if (c4_eligible(d)) return "conv_c4_patch_kernel";
     const int bm = glds_tile_bm(d);
+    if (bm == 0 && x3_glds_applies(d)) return x3_kernel_name(d);
     if (bm == 0) return (d->in_dtype == DL_BF16) ? "conv_gemm_kernel<bf16>" : "conv_gemm_kernel<f32>";
     if (d->Co <= 16) return "conv_gemm_glds_kernel<256,16,32>";
     if (d->Co <= 64) return "conv_gemm_glds_kernel<128,64,64>";
@@ -1768,7 +1770,7 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     if (c4_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
-    else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_tile<float, float, 3>(a, stream);
+    else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = x3_glds_applies(d) ? dispatch_tile_x3(a, stream) : dispatch_tile<float, float, 3>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_tile<float, float, 1>(a, stream);
     else DL_FAIL("dl_conv_forward: unsupported dtype/precision combination (%d, %d)", d->in_dtype, d->prec);
     if (rc) return rc;

@@ -723,6 +723,7 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 }
 
 #include "wgrad_c4.h"
+#include "wgrad_x3.h"
 
 extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -765,7 +766,20 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     // two phases later without forced waits; address arithmetic moved into the MFMA shadow).  The one-barrier kernel alone is 172 us,
     // within 8 % of the forward's 8-phase kernel (155-160 us), so there was little left to win here.
     static const char *w8 = getenv("DL_WGRAD_8PH");
-    if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') rc = launch_wgrad_8ph(a, stream);
+    // strict policy on the direct-to-LDS path (wgrad_x3.h); DL_NO_X3_GLDS=1: the round-1 register-staged kernel (A/B)
+    static const bool no_x3 = getenv("DL_NO_X3_GLDS") != nullptr;
+    const bool act_ok3 = (d->p_act == DL_ACT_NONE || d->p_act == DL_ACT_RELU || d->p_act == DL_ACT_LRELU) &&
+                         (d->q_act == DL_ACT_NONE || d->q_act == DL_ACT_RELU || d->q_act == DL_ACT_LRELU);
+    const bool fast3 = d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && act_ok3 && d->pad_mode == DL_PAD_ZERO && a.J >= 256 &&
+                       a.Ptot >= 32 * d->splitk && (d->p_pstride % 4) == 0 && (d->q_pstride % 4) == 0 && !no_x3;
+    // DL_WGRAD_X3 = "2": the staggered two-phase schedule (wgrad_4ph_x3_kernel), "3": the same without s_setprio.  OFF by default -- measured r03,
+    // same box, ResnetBlock shape, kernel + reduce: 627 us (604 without s_setprio) vs 577 us for the one-barrier kernel; PMC: the stagger
+    // raises the time waves spend parked at barriers / waitcnt (43 % vs 28 % of wave cycles) more than it overlaps (MFMA-busy 31.6 % vs 35.6 %).
+    static const char *w3 = getenv("DL_WGRAD_X3");
+    if (fast3 && (d->CAp % 256) == 0 && w3 && (w3[0] == '2' || w3[0] == '3')) rc = (w3[0] == '3') ? launch_wgrad_4ph_x3<1>(a, stream) : launch_wgrad_4ph_x3<0>(a, stream);
+    else if (fast3 && (d->CAp % 256) == 0) rc = launch_wgrad_glds_x3<256>(a, stream);
+    else if (fast3 && (d->CAp % 128) == 0) rc = launch_wgrad_glds_x3<128>(a, stream);
+    else if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') rc = launch_wgrad_8ph(a, stream);
     else if (fast && (d->CAp % 256) == 0) rc = launch_wgrad_glds<256, 2, 4>(a, stream);
     else if (fast && (d->CAp % 128) == 0) rc = launch_wgrad_glds<128, 2, 4>(a, stream);
     else if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);

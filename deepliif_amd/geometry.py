@@ -214,9 +214,12 @@ def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, 
 NUM_CUS = 256      # MI355X
 
 
-def wgrad_fast_path(cap: int, j: int, bf16: bool, no_act: bool, zero_pad: bool) -> bool:
-    """mirror of the dispatch predicate in wgrad.hip (direct-to-LDS 8-wave kernel)"""
-    return bf16 and no_act and zero_pad and j >= 256 and cap % 128 == 0
+def wgrad_fast_path(cap: int, j: int, bf16: bool, no_act: bool, zero_pad: bool, strict: bool = False, strict_act_ok: bool = True) -> bool:
+    """mirror of the dispatch predicates in wgrad.hip: the direct-to-LDS 8-wave kernels -- wgrad_glds_kernel (bf16 policy, no staged
+    activation) and wgrad_glds_x3_kernel (strict policy = fp32 storage + split-bf16 x3; relu / lrelu on an operand are applied while the
+    tile is split in LDS, csrc/wgrad_x3.h)"""
+    shape_ok = zero_pad and j >= 256 and cap % 128 == 0
+    return shape_ok and ((bf16 and no_act) or (strict and strict_act_ok))
 
 
 def choose_wgrad_splitk(cap: int, j: int, ptot: int, fast: bool = False, target_blocks: int = 1024, max_split: int = 256) -> int:

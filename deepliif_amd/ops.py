@@ -45,6 +45,8 @@ _SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
 # epilogue of a 1-workgroup-per-CU kernel (+37 us per fused ResnetBlock launch) and costs what the saved pass (49 us) was worth.
 _BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
 _NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
+_NO_X3_GLDS = os.environ.get('DL_NO_X3_GLDS') is not None           # A/B switch: the strict policy on the round-1 register-staged kernels (csrc reads the same variable)
+_X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
@@ -257,8 +259,9 @@ class HipBackend:
             d.KW, d.pad_w, d.stack_kw, d.CA = 1, 0, stack_kw, grad.shape[0] * stack_kw
         d.dtype, d.prec = dl_dtype(P), prec
         j = d.KH * d.KW * d.CBp
+        strict = d.dtype == L.DL_F32 and prec == L.PREC_BF16X3 and not _NO_X3_GLDS
         fast = wgrad_fast_path(d.CAp, j, d.dtype == L.DL_BF16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE,
-                               pad_mode == L.PAD_ZERO)
+                               pad_mode == L.PAD_ZERO, strict, p_act in _X3_ACTS and q_act in _X3_ACTS)
         d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
         if splitk is None and not _NO_WGRAD_C4 and self.wgrad_c4_applies(P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw):
             d.splitk = WGRAD_C4_PARTS          # one partial result per persistent workgroup (csrc/wgrad_c4.h)

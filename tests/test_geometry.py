@@ -104,3 +104,39 @@ def test_stride2_dgrad_even_and_odd_sizes(hw):
         dp = spec.dgrad_plan()
         dx = emu_gather_gemm(dp, to_nhwc(r, 16), emu_pack(dp, w), H, W_, (H + 1) // 2, (W_ + 1) // 2, 8)
         assert torch.allclose(from_nhwc(dx, 8), dx_ref, atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LDS layout of the strict-policy direct-to-LDS kernels (csrc/conv_x3.h): bank-conflict model of ds_read_b128
+# ---------------------------------------------------------------------------------------------------------------
+# ds_read_b128 is serviced in four 16-lane groups; bank of byte address a = (a / 4) % 64 (MI355X_MICROARCH.md, LDS table)
+_B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+_B128_GROUPS += [[l + 32 for l in g] for g in _B128_GROUPS]
+
+
+def _b128_worst_way(addr_of_lane):
+    worst = 0
+    for g in _B128_GROUPS:
+        slots = {}
+        for lane in g:
+            a = addr_of_lane(lane)
+            slots.setdefault((a // 16) % 16, set()).add(a)
+        worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+
+
+def _x3_swz(h):          # conv_x3.h: x3_swz
+    return (((h >> 2) & 1) << 2) | ((h & 1) << 1) | (((h >> 1) ^ (h >> 2)) & 1)
+
+
+def test_x3_swizzle_is_conflict_free():
+    """fp32 activation rows (128 B = 32 channels): lane (fr, fg) reads the 16-byte chunks 2*fg and 2*fg + 1 of row fr.  With the bf16 kernels'
+    swizzle c ^ ((row >> 1) & 7) those reads are 2-way conflicting; with c ^ x3_swz((row >> 1) & 7) they are conflict-free.  The weight rows
+    ([32 hi | 32 lo] bf16) read chunk fg and 4 + fg under the old swizzle, as the bf16 kernel does for kk = 0 / 1."""
+    assert sorted(_x3_swz(h) for h in range(8)) == list(range(8)), 'the swizzle must be a permutation (source-side / read-side involution)'
+    for e in range(2):
+        old = _b128_worst_way(lambda l: (l & 15) * 128 + (((2 * (l >> 4) + e) ^ (((l & 15) >> 1) & 7)) << 4))
+        new = _b128_worst_way(lambda l: (l & 15) * 128 + (((2 * (l >> 4) + e) ^ _x3_swz(((l & 15) >> 1) & 7)) << 4))
+        assert old == 2 and new == 1, (e, old, new)
+        w = _b128_worst_way(lambda l: (l & 15) * 128 + (((e * 4 + (l >> 4)) ^ (((l & 15) >> 1) & 7)) << 4))
+        assert w == 1, (e, w)

@@ -271,10 +271,12 @@ BIG_CASES = [
 ]
 
 
+@pytest.mark.parametrize('precname', ['bf16', 'fp32'])
 @pytest.mark.parametrize('case', BIG_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}n{c[6]}')
-def test_conv_big_tiles(case):
+def test_conv_big_tiles(case, precname):
+    """bf16: conv_gemm_8ph_kernel; fp32 (strict policy): conv_gemm_8ph_x3_kernel / conv_gemm_glds_x3_kernel (csrc/conv_x3.h)"""
     kind, cin, cout, k, s_, p, N, H, W_ = case
-    prec = Precision.get('bf16')
+    prec = Precision.get(precname)
     spec = ConvSpec(kind, cin, cout, k, s_, p, L.PAD_ZERO, 1 if kind == 'convT' else 0)
     wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
     w = rnd(wshape, 1, prec, 0.05)
@@ -339,26 +341,27 @@ def test_pack_weights_batch_matches_single_packs():
             assert torch.equal(batched.lo.view(torch.int16), single.lo.view(torch.int16))
 
 
-def test_wgrad_fast_path_ragged_pixels():
-    """direct-to-LDS weight gradient (bf16, 256 -> 256, 3x3) over a pixel count that is neither a multiple of the 64-pixel K step
-    nor of the split-K chunk, with tiles straddling images: 5 x 120 x 136 = 81 600 pixels.  Also with every env-selectable
-    block order (default XCD grouping is what the training step uses)."""
-    prec = Precision.get('bf16')
+@pytest.mark.parametrize('precname,ca,q_act', [('bf16', 256, L.ACT_NONE), ('fp32', 256, L.ACT_NONE), ('fp32', 128, L.ACT_LRELU), ('fp32', 256, L.ACT_RELU)])
+def test_wgrad_fast_path_ragged_pixels(precname, ca, q_act):
+    """direct-to-LDS weight gradient (wgrad_glds_kernel for the bf16 policy, wgrad_glds_x3_kernel for the strict one; ca -> 256, 3x3) over a
+    pixel count that is neither a multiple of the K step nor of the split-K chunk, with tiles straddling images: 5 x 120 x 136 = 81 600
+    pixels.  The strict kernel also applies the staged operand activation while it splits the tile in LDS."""
+    prec = Precision.get(precname)
     N, H, W_, C = 5, 120, 136, 256
     x = rnd((N, H, W_, C), 5, prec).to(prec.dtype)
-    dy = rnd((N, H, W_, C), 6, prec).to(prec.dtype)
+    dy = rnd((N, H, W_, ca), 6, prec).to(prec.dtype)
     fake, real = fake_backend.FakeBackend(), hip()
-    g_exp = torch.zeros(C, C, 3, 3)
-    fake.conv_wgrad(dy, x, g_exp, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False)
-    first = None
+    g_exp = torch.zeros(ca, C, 3, 3)
+    fake.conv_wgrad(dy, x, g_exp, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, q_act, prec.prec, False)
+    t = 1e-3 if precname == 'bf16' else 1e-4
     for sk in (None, 1, 7):
-        g = torch.empty(C, C, 3, 3, device=DEV)
-        real.conv_wgrad(dy.to(DEV), x.to(DEV), g, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, splitk=sk)
+        g = torch.empty(ca, C, 3, 3, device=DEV)
+        real.conv_wgrad(dy.to(DEV), x.to(DEV), g, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, q_act, prec.prec, False, splitk=sk)
         sync()
-        assert rel(g, g_exp) < 1e-3, ('splitk', sk)
+        assert rel(g, g_exp) < t, ('splitk', sk)
         if sk is None:
             g2 = torch.empty_like(g)
-            real.conv_wgrad(dy.to(DEV), x.to(DEV), g2, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, splitk=sk)
+            real.conv_wgrad(dy.to(DEV), x.to(DEV), g2, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, q_act, prec.prec, False, splitk=sk)
             sync()
             assert torch.equal(g, g2), 'run-to-run difference (fixed-order reduction expected)'
 
