@@ -94,7 +94,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline_child(norm, size, batch=1):
+def cpu_baseline_child(norm, size, batch=1, budget=45.0):
     """(child process) optimize_parameters() steps of the CPU oracle at batch `batch` (default 1), same model family, random init."""
     from oracle import deepliif_oracle as O
     cores = min(usable_cores(), 64)
@@ -113,31 +113,33 @@ def cpu_baseline_child(norm, size, batch=1):
     # not counted; stops early only if the host is so slow that 3 steps would exceed ~45 s
     om.optimize_parameters()
     times = []
-    while len(times) < 3 and (sum(times) < 45.0 or not times):
+    while len(times) < 3 and (sum(times) < budget or not times):
         t0 = time.time()
         om.optimize_parameters()
         times.append(time.time() - t0)
     print(json.dumps({'seconds': sum(times) / len(times), 'steps': len(times), 'total_seconds': sum(times), 'cores': cores, 'size': size, 'batch': batch}), flush=True)
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's PyTorch training step) timed on this box's host cores: a bounded sample of whole steps at batch 1
-    (the reference's default batch size, cli.py:110).  Runs in a child process with a time limit so that a slow / oversubscribed
-    host cannot stall the benchmark; falls back to a 256x256 tile (reported in 512x512-tile equivalents) if 512x512 does not
-    finish in time."""
+def cpu_baseline(args, batch=None, budget=45.0):
+    """The CPU oracle (a port of the reference's PyTorch training step) timed on this box's host cores: a bounded sample of whole steps at batch
+    `batch` (default args.cpu_batch = 1, the reference's default batch size, cli.py:110; SURVEY 8d also asks for the GPU line's per-GPU batch 8 ->
+    cpu_baseline_n8).  Runs in a child process with a time limit so that a slow / oversubscribed host cannot stall the benchmark; falls back
+    to a 256x256 tile (reported in 512x512-tile equivalents) if 512x512 does not finish in time."""
     import subprocess
-    for size, limit in ((args.size, 240 * args.cpu_batch), (args.size // 2, 180 * args.cpu_batch)):
+    batch = args.cpu_batch if batch is None else batch
+    last = 'not run'
+    for size, limit in ((args.size, 240 * batch), (args.size // 2, 180 * batch)):
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--norm', args.norm, '--size', str(size), '--cpu-batch', str(args.cpu_batch)],
-                               capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', '--norm', args.norm, '--size', str(size), '--cpu-batch', str(batch),
+                                '--cpu-budget', str(budget)], capture_output=True, text=True, timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
             line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
             d = json.loads(line)
         except Exception as e:            # timeout / crash: try the smaller sample, else report nothing
             last = f'{type(e).__name__}'
             continue
         scale = (size * size) / float(args.size * args.size)
-        return {'value': round(scale * args.cpu_batch / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
-                'sample': f"1 warm-up + {d.get('steps', 1)} timed optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch {args.cpu_batch}, "
+        return {'value': round(scale * batch / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
+                'sample': f"1 warm-up + {d.get('steps', 1)} timed optimize_parameters() step(s) of the fp32 CPU oracle (5 Resnet-9 G + 5 NLayer D, GAN+SmoothL1+Adam), batch {batch}, "
                           f"{size}x{size} tile, {d.get('total_seconds', d['seconds']):.1f} s of CPU work, {d['seconds']:.1f} s per step" + ('' if size == args.size else f' (scaled to {args.size}x{args.size}-tile units by pixel count)')}
     return {'value': None, 'unit': 'tiles/s', 'cores': usable_cores(), 'kind': 'port', 'sample': f'CPU oracle step did not finish within the time limit ({last})'}
 
@@ -158,24 +160,29 @@ def main():
                          '2 Resnet-9 + 2 UNet-512 (9-channel input) generators, 2 + 2 discriminators (6 / 12 channels); infer = configs[1]; '
                          'wsi = configs[4], tile-parallel whole-slide inference (synthetic uint8 region, 512 tiles, overlap 32)')
     ap.add_argument('--region', type=int, default=20000, help='wsi workload: side of the synthetic square region in pixels')
+    ap.add_argument('--no-timer-check', action='store_true', help='skip the second pass that times the same steps WITHOUT the per-launch events '
+                    '(roofline.timer_overhead)')
     ap.add_argument('--no-strict', action='store_true', help='skip the strict-parity (fp32 policy) leg')
+    ap.add_argument('--strict', action='store_true', help='time the strict-parity leg also when WORLD_SIZE > 1 (by default a multi-GPU run only carries the '
+                    'headline policy: the scaling curve should not pay for a second model and 8 more steps per rank)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1, help='batch size of the cpu_baseline leg: 1 = the reference default (cli.py:110) and a ~15 s sample; '
                     '8 = the per-GPU batch of the GPU line (SURVEY 8d asks for both), ~2 minutes of CPU work')
+    ap.add_argument('--no-cpu-baseline-n8', action='store_true', help='skip the second CPU leg at the per-GPU batch of the GPU line (batch 8: 1 warm-up + up to 3 '
+                    'steps inside a 100 s budget, about 2 minutes of CPU work)')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-budget', type=float, default=45.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        return cpu_baseline_child(args.norm, args.size, args.cpu_batch)
+        return cpu_baseline_child(args.norm, args.size, args.cpu_batch, args.cpu_budget)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under torchrun: become `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one process per
         # GPU over RCCL); rank 0 of that job prints the one JSON line
-        import socket
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-                                  '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+        # --standalone: torchrun's own c10d rendezvous picks (and keeps) a free port itself -- binding port 0 here, closing the socket and
+        # handing the number over would leave a window in which another process can take it
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+                                  f'--nproc-per-node={args.gpus}', os.path.abspath(__file__)] + sys.argv[1:])
 
     from deepliif_amd import distributed as D
     from deepliif_amd import models as M
@@ -290,7 +297,7 @@ def main():
 
     # ---- strict-parity leg, part 1 (before any optimizer step): distance of the headline policy from the strict policy on this batch
     strict = None
-    want_strict = (not args.no_strict) and args.precision != 'fp32' and args.workload in ('train', 'train18', 'ext')
+    want_strict = (not args.no_strict) and args.precision != 'fp32' and args.workload in ('train', 'train18', 'ext') and (world == 1 or args.strict)
     if want_strict:
         sstep, smodel, _, _, _ = build('fp32')
         for mdl in (model, smodel):
@@ -334,23 +341,40 @@ def main():
 
     tiles_total = args.steps * n * world
     value = tiles_total / dt
-
-    # ---- strict-parity leg, part 2: the same workload timed on the strict policy
-    if want_strict:
-        ssteps = max(5, min(args.steps, 8))
-        sdt = timed(sstep, 1, ssteps)
-        strict.update({'value': round(ssteps * n * world / sdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(sdt / ssteps * 1e3, 3), 'steps': ssteps, 'warmup': 1})
-        del smodel, sstep
+    # what do the event pairs around the dominant launches cost?  the same K steps once more, events off (same process, same state of the clocks)
+    dt_noev = None
+    if args.workload != 'wsi' and not dry and timer.pairs and not args.no_timer_check:
+        dt_noev = timed(step, 1, args.steps)
 
     kt = timer.mean_seconds()
+    n_pairs, dom_kernel = len(timer.pairs), timer.kernel
     flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * (4 * args.ngf) * (4 * args.ngf) * 9
+
+    # ---- strict-parity leg, part 2: the same workload timed on the strict policy, with its own roofline block (same layer shape, same
+    # ALGORITHMIC flops per launch -- the three bf16 MFMA passes per product are the policy's cost, not useful work)
+    if want_strict:
+        ssteps = max(5, min(args.steps, 8))
+        if hasattr(timer, '_orig'):
+            timer.pairs, timer.kernel = [], '?'
+        sdt = timed(sstep, 1, ssteps, timer if hasattr(timer, '_orig') else None)
+        strict.update({'value': round(ssteps * n * world / sdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(sdt / ssteps * 1e3, 3), 'steps': ssteps, 'warmup': 1,
+                       'model_tflops': round(ssteps * n * world / sdt * gf_per_tile / 1e3, 1)})
+        skt = timer.mean_seconds() if hasattr(timer, '_orig') else None
+        if skt:
+            sach = flops_per_launch / skt / 1e12
+            strict['roofline'] = {'bound': 'mfma', 'achieved': round(sach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(sach / PEAK_BF16_TFLOPS, 4),
+                                  'mfma_pipe_frac': round(3 * sach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                                  'kernel': f'{timer.kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv fwd + dgrad (fp32 storage, split-bf16 x3); timed by events around the host call',
+                                  'launches_timed': len(timer.pairs), 'avg_launch_us': round(skt * 1e6, 2),
+                                  'note': 'achieved = algorithmic conv flops per launch / launch time; mfma_pipe_frac counts the 3 MFMA passes the policy issues per product'}
+        del smodel, sstep
     roofline = None
     traffic, traffic_note = None, None
     try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/gpu_pmc.sh)
         with open(os.path.join(ROOT, 'profiles', PMC_FILE)) as f:
             pmc = json.load(f)
             # counters belong to ONE kernel at ONE shape: report them only when that is what this run dispatched
-            same = (n, s, args.precision, args.ngf) == (8, 512, 'bf16', 64) and timer.kernel != '?' and timer.kernel.split('<')[0] in pmc.get('kernel', '')
+            same = (n, s, args.precision, args.ngf) == (8, 512, 'bf16', 64) and dom_kernel != '?' and dom_kernel.split('<')[0] in pmc.get('kernel', '')
             traffic = pmc['traffic_bytes'] if same else None
             traffic_note = (f'NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same kernel and shape '
                             f'(profiles/{PMC_FILE}, collected with tools/gpu_pmc.sh on forward launches only)') if same else None
@@ -360,8 +384,13 @@ def main():
         ach = flops_per_launch / kt / 1e12
         roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
                     'traffic': traffic, 'traffic_note': traffic_note,
-                    'kernel': f'{timer.kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload not in ('infer', 'wsi') else 'fwd only') + '; timed by events around the host call',
-                    'launches_timed': len(timer.pairs), 'avg_launch_us': round(kt * 1e6, 2)}
+                    'kernel': f'{dom_kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload not in ('infer', 'wsi') else 'fwd only') + '; timed by events around the host call',
+                    'launches_timed': n_pairs, 'avg_launch_us': round(kt * 1e6, 2)}
+        if dt_noev is not None:
+            roofline['timer_overhead'] = {'ms_per_step_with_events': round(dt / args.steps * 1e3, 3), 'ms_per_step_without_events': round(dt_noev / args.steps * 1e3, 3),
+                                          'relative': round(dt / dt_noev - 1.0, 5),
+                                          'what': f'the {args.steps} timed steps carry {n_pairs} hipEvent pairs around the dominant launches; the same steps were timed once more '
+                                                  'without them (value / ms_per_step are the run WITH the events)'}
     out = {
         'metric': {'train': '512x512 tiles/s train-step (5G+5D)', 'train18': '512x512 tiles/s train-step (real DeepLIIF: 9 G + 9 D)', 'ext': '512x512 tiles/s train-step (DeepLIIFExt, 2 modalities: 4 G + 4 D)',
                    'infer': '512x512 tiles/s inference (4 Resnet-9 + 5 UNet-512)', 'wsi': '512x512 tiles/s whole-slide inference (tile-parallel, crop + 9 generators + stitch)'}[args.workload],
@@ -385,6 +414,9 @@ def main():
         out['data'] = 'DRY RUN on CPU through the test emulation backend (launch-path check only; numbers are meaningless)'
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train' and not dry:
         out['cpu_baseline'] = cpu_baseline(args)
+        if not args.no_cpu_baseline_n8 and args.batch != args.cpu_batch:
+            # "N=1 (reference default batch_size) and N=8": the same oracle at the GPU line's per-GPU batch, time-budgeted
+            out['cpu_baseline_n8'] = cpu_baseline(args, batch=args.batch, budget=100.0)
     else:
         out['cpu_baseline'] = None
         out['cpu_baseline_note'] = ('disabled by --no-cpu-baseline' if args.no_cpu_baseline else

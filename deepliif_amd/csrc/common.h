@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/deepliif_hip.h"
 
 typedef uint16_t bf16_t;   // raw bf16 bits
@@ -121,6 +122,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// A/B switches that Python reads too (os.environ.get(name) == '1'): ONE parse on both sides of the C ABI
+static inline bool dl_env_is_one(const char *name) { const char *v = getenv(name); return v && v[0] == '1' && v[1] == 0; }
 
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return ((1 << l) == v) ? l : -1; }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -3,6 +3,7 @@
 // deepliif/data/__init__.py:133-138 transform, deepliif/util/util.py:117-139 tensor2im).  Byte / integer work, HBM-bound:
 // one thread per pixel, 16-byte (bf16) or 2 x 16-byte (fp32) NHWC stores, no LDS.
 #include "common.h"
+#include <stdlib.h>
 
 // reflect-periodic source coordinate: an image narrower than a patch is widened by appending mirrored copies
 // (util/__init__.py:196-211) -> period 2*n: c, then 2n-1-c
@@ -118,6 +119,13 @@ __global__ void tile_paste_kernel(const T *__restrict__ tiles, int in_pstride, i
     }
 }
 
+// tiles / rectangles per launch (gridDim.y <= 65535); DL_TILE_GRID_Y=<n> overrides it so that the chunked path can be tested on small regions
+static int tile_grid_y() {
+    static const int v = [] { const char *e = getenv("DL_TILE_GRID_Y"); const int n = e ? atoi(e) : 0; return (n >= 1 && n <= 65535) ? n : 32768; }();
+    return v;
+}
+#define DL_TILE_GRID_Y (tile_grid_y())
+
 extern "C" int dl_tile_gather_u8(const void *const *imgs, const int64_t *row_strides, int n_src, int H0, int W0, const int32_t *origins,
                                  int n_tiles, int tile, int pad, uint32_t pad_rgb, const float *lut, int out_dtype, void *out,
                                  int out_pstride, int out_cp, void *stream) {
@@ -130,12 +138,19 @@ extern "C" int dl_tile_gather_u8(const void *const *imgs, const int64_t *row_str
         s.img[i] = (const uint8_t *)(i < n_src ? imgs[i] : imgs[0]);
         s.row_stride[i] = i < n_src ? row_strides[i] : row_strides[0];
     }
-    dim3 grid((tile * tile + 255) / 256, n_tiles);
-    if (out_dtype == DL_BF16)
-        hipLaunchKernelGGL(tile_gather_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, s, n_src, H0, W0, origins, tile, pad, pad_rgb, lut, (bf16_t *)out, out_pstride, out_cp);
-    else
-        hipLaunchKernelGGL(tile_gather_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s, n_src, H0, W0, origins, tile, pad, pad_rgb, lut, (float *)out, out_pstride, out_cp);
-    DL_CHECK_LAUNCH("dl_tile_gather_u8");
+    // gridDim.y is limited to 65535: a region with more tiles (about 115k x 115k pixels at tile 512 / overlap 32) is launched in chunks
+    for (int t0 = 0; t0 < n_tiles; t0 += DL_TILE_GRID_Y) {
+        const int nt = n_tiles - t0 < DL_TILE_GRID_Y ? n_tiles - t0 : DL_TILE_GRID_Y;
+        dim3 grid((tile * tile + 255) / 256, nt);
+        const size_t o0 = (size_t)t0 * tile * tile * out_pstride;
+        if (out_dtype == DL_BF16)
+            hipLaunchKernelGGL(tile_gather_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, s, n_src, H0, W0, origins + 2 * (size_t)t0, tile, pad, pad_rgb, lut,
+                               (bf16_t *)out + o0, out_pstride, out_cp);
+        else
+            hipLaunchKernelGGL(tile_gather_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, s, n_src, H0, W0, origins + 2 * (size_t)t0, tile, pad, pad_rgb, lut,
+                               (float *)out + o0, out_pstride, out_cp);
+        DL_CHECK_LAUNCH("dl_tile_gather_u8");
+    }
     return 0;
 }
 
@@ -147,9 +162,12 @@ extern "C" int dl_tile_gray_stats_u8(const void *img, int64_t row_stride, int H0
     if (e != hipSuccess) DL_FAIL("dl_tile_gray_stats_u8: memset failed: %s", hipGetErrorString(e));
     int bx = (tile * tile + 256 * 8 - 1) / (256 * 8);
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(tile_gray_stats_kernel, dim3(bx, n_tiles), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)img, (long long)row_stride, H0, W0, origins,
-                       tile, pad, pad_rgb, (unsigned long long *)stats);
-    DL_CHECK_LAUNCH("dl_tile_gray_stats_u8");
+    for (int t0 = 0; t0 < n_tiles; t0 += DL_TILE_GRID_Y) {
+        const int nt = n_tiles - t0 < DL_TILE_GRID_Y ? n_tiles - t0 : DL_TILE_GRID_Y;
+        hipLaunchKernelGGL(tile_gray_stats_kernel, dim3(bx, nt), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)img, (long long)row_stride, H0, W0,
+                           origins + 2 * (size_t)t0, tile, pad, pad_rgb, (unsigned long long *)stats + 3 * (size_t)t0);
+        DL_CHECK_LAUNCH("dl_tile_gray_stats_u8");
+    }
     return 0;
 }
 
@@ -157,11 +175,16 @@ extern "C" int dl_tile_paste_u8(int in_dtype, const void *tiles, int in_pstride,
                                 void *stream) {
     if (n_rects <= 0 || tile <= 0) DL_FAIL("dl_tile_paste_u8: empty problem (n_rects=%d tile=%d)", n_rects, tile);
     if (in_pstride < 8) DL_FAIL("dl_tile_paste_u8: engine tiles have at least 8 padded channels (pstride=%d)", in_pstride);
-    dim3 grid(64, n_rects);
-    if (in_dtype == DL_BF16)
-        hipLaunchKernelGGL(tile_paste_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)tiles, in_pstride, tile, rects, (uint8_t *)dst, (long long)dst_row_stride);
-    else
-        hipLaunchKernelGGL(tile_paste_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)tiles, in_pstride, tile, rects, (uint8_t *)dst, (long long)dst_row_stride);
-    DL_CHECK_LAUNCH("dl_tile_paste_u8");
+    for (int r0 = 0; r0 < n_rects; r0 += DL_TILE_GRID_Y) {          // the rectangles carry their own tile index: only the list is chunked
+        const int nr = n_rects - r0 < DL_TILE_GRID_Y ? n_rects - r0 : DL_TILE_GRID_Y;
+        dim3 grid(64, nr);
+        if (in_dtype == DL_BF16)
+            hipLaunchKernelGGL(tile_paste_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)tiles, in_pstride, tile, rects + 8 * (size_t)r0, (uint8_t *)dst,
+                               (long long)dst_row_stride);
+        else
+            hipLaunchKernelGGL(tile_paste_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)tiles, in_pstride, tile, rects + 8 * (size_t)r0, (uint8_t *)dst,
+                               (long long)dst_row_stride);
+        DL_CHECK_LAUNCH("dl_tile_paste_u8");
+    }
     return 0;
 }

@@ -22,8 +22,18 @@ from typing import Dict, List, Tuple
 import torch
 import torch.distributed as dist
 
-BUCKET_ELEMS = 64 * 1024 * 1024      # 256 MB fp32: upper bound for one all-reduce call
+BUCKET_ELEMS = 8 * 1024 * 1024       # 32 MB fp32: the largest single all-reduce call
+SPLIT_ELEMS = 16 * 1024 * 1024       # network slices above 64 MB (the 67 M-parameter UNet-512 generators: 268 MB) are exchanged progressively:
+                                     # a bucket goes on the wire as soon as <= 32 MB of the network's gradient tail is final (Tape.on_final),
+                                     # instead of the whole slice at the network's marker -- with one message per network the last UNet of
+                                     # the pass would be fully exposed; smaller networks (Resnet-9 45 MB, NLayerD 28 MB) stay ONE message each
 OVERLAP = os.environ.get('DL_DP_OVERLAP', '1') != '0'        # A/B switch: 0 = one blocking exchange after the whole backward (round 1)
+FORCE = os.environ.get('DL_DP_FORCE', '0') == '1'            # run the exchange path with ONE rank too (all-reduce over a 1-rank group = identity):
+                                                             # exercises RCCL's stream ordering against the ctypes launches on a single GPU
+
+
+def active() -> bool:
+    return world_size() > 1 or (FORCE and dist.is_available() and dist.is_initialized())
 
 
 def init_process_group_from_env(backend: str = None):
@@ -31,7 +41,9 @@ def init_process_group_from_env(backend: str = None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -51,8 +63,10 @@ def rank() -> int:
 class GradExchanger:
     """Sum-all-reduce of an optimizer's flat gradient across ranks; averaging is applied inside the optimizer step.
 
+    register_net(opt, params)  once: this contiguous run of the optimizer's parameters is one network
     begin(optimizer)           start of a backward pass whose gradients belong to `optimizer`
-    ready(params)              the gradients of this contiguous run of parameters are final: exchange them now (asynchronously)
+    param_final(p)             (Tape.on_final) one parameter's gradient is final: networks above 64 MB send their final tail in 32 MB buckets
+    ready(params)              the gradients of this contiguous run of parameters are final: exchange what has not gone out yet (asynchronously)
     finish(optimizer)          exchange whatever was not announced, wait for everything, set optimizer.dp_scale
     all_reduce(optimizer)      begin + finish without announcements (one blocking exchange)"""
 
@@ -62,12 +76,29 @@ class GradExchanger:
         self.current = None
         self._slices: Dict[int, Tuple[int, int]] = {}
         self._synced = set()
-        self.launch_log: List[Tuple[int, int]] = []          # (start, end) of every slice exchanged early in the last pass (tests / diagnostics)
+        self.launch_log: List[Tuple[int, int]] = []          # (start, end) of every range exchanged early in the last pass (tests / diagnostics)
+        self._big: Dict[int, Tuple[int, int]] = {}           # id(param) -> slice (start, end) of its network, networks above SPLIT_ELEMS only
+        self._param_range: Dict[int, Tuple[int, int]] = {}   # id(param) -> its own (start, end) in the flat buffer
+        self._progress: Dict[Tuple[int, int], dict] = {}     # per big slice and pass: final-but-unsent intervals, send watermark
+
+    def register_net(self, optimizer, params):
+        """tell the exchanger which contiguous run of `optimizer`'s flat parameters is one network (models call this once per network)"""
+        flat = getattr(optimizer, 'flat', None)
+        params = [p for p in params]
+        if flat is None or not params:
+            return
+        s, e = flat.slice_of(params)
+        self._slices[id(params[0])] = (s, e)
+        if e - s > SPLIT_ELEMS:
+            for p in params:
+                ps, pe = flat.slice_of([p])
+                self._big[id(p)] = (s, e)
+                self._param_range[id(p)] = (ps, pe)
 
     # -- one-time parameter synchronisation ---------------------------------------------------------------------
     def sync_parameters(self, optimizer, modules=()):
         """broadcast the flat parameters (and BatchNorm buffers of `modules`) from rank 0, once per optimizer"""
-        if world_size() == 1 or id(optimizer) in self._synced:
+        if not active() or id(optimizer) in self._synced:
             return
         flat = getattr(optimizer, 'flat', None)
         if flat is not None:
@@ -81,8 +112,28 @@ class GradExchanger:
 
     # -- per-pass protocol ---------------------------------------------------------------------------------------
     def begin(self, optimizer):
-        self.current = optimizer if (world_size() > 1 and OVERLAP and getattr(optimizer, 'flat', None) is not None) else None
+        self.current = optimizer if (active() and OVERLAP and getattr(optimizer, 'flat', None) is not None) else None
         self.handles, self.done, self.launch_log = [], [], []
+        self._progress = {}
+
+    def param_final(self, p):
+        """Tape.on_final: the gradient of `p` is complete for this pass.  Inside a network above SPLIT_ELEMS the flat order of the parameters
+        is the network's forward order (ResnetGenerator: a Sequential; UnetGenerator: down path outermost -> innermost, then the up path back
+        out), so reverse mode finalises a slice from its END: the final run [w, sent) behind the watermark is launched in buckets once it
+        reaches BUCKET_ELEMS.  A parameter that becomes final out of order just waits until the watermark reaches it (or for ready())."""
+        opt = self.current
+        if opt is None or id(p) not in self._big:
+            return
+        sl = self._big[id(p)]
+        st = self._progress.setdefault(sl, {'final': {}, 'w': sl[1], 'sent': sl[1]})
+        a, b = self._param_range[id(p)]
+        st['final'][b] = a
+        while st['w'] in st['final']:
+            st['w'] = st['final'].pop(st['w'])
+        if st['sent'] - st['w'] >= BUCKET_ELEMS:
+            self._launch(opt.flat.grad, st['w'], st['sent'])
+            self.launch_log.append((st['w'], st['sent']))
+            st['sent'] = st['w']
 
     def ready(self, params):
         opt = self.current
@@ -92,8 +143,13 @@ class GradExchanger:
         if key not in self._slices:
             self._slices[key] = opt.flat.slice_of(params)
         s, e = self._slices[key]
-        self._launch(opt.flat.grad, s, e)
-        self.launch_log.append((s, e))
+        st = self._progress.get((s, e))
+        if st is not None:
+            e = st['sent']                     # the tail of this slice already went out in buckets
+            st['w'] = st['sent'] = s
+        if e > s:
+            self._launch(opt.flat.grad, s, e)
+            self.launch_log.append((s, e))
 
     def _launch(self, g, s, e):
         for b in range(s, e, BUCKET_ELEMS):
@@ -105,7 +161,7 @@ class GradExchanger:
         flat = getattr(optimizer, 'flat', None)
         if flat is None:
             raise RuntimeError('every optimizer on this path owns a FlatParams set (optim.FusedAdam / optim.flat_optimizer)')
-        if ws == 1:
+        if not active():
             optimizer.dp_scale = 1.0
             self.current = None
             return

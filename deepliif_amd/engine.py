@@ -71,13 +71,35 @@ class Act:
 
 
 class Tape:
-    """Reverse-mode tape: forward ops append closures, backward() runs them last-to-first."""
+    """Reverse-mode tape: forward ops append closures, backward() runs them last-to-first.
+
+    Parameter bookkeeping for the data-parallel exchange (distributed.GradExchanger): every recorded op that will add to a parameter's
+    gradient announces it with use(); its backward closure calls done() after the gradient has been accumulated.  When the LAST
+    outstanding use of a parameter is done, its gradient is final for this pass and `on_final(param)` fires -- a network that runs
+    several times on one tape (a discriminator on real and fake pairs) therefore reports a weight only once, after both passes."""
 
     def __init__(self):
         self.nodes: List[Callable[[], None]] = []
+        self.uses = {}
+        self.on_final: Optional[Callable[[torch.nn.Parameter], None]] = None
 
     def record(self, fn: Callable[[], None]):
         self.nodes.append(fn)
+
+    def use(self, *params):
+        for p in params:
+            if p is not None and p.requires_grad:
+                self.uses[id(p)] = self.uses.get(id(p), 0) + 1
+
+    def done(self, *params):
+        for p in params:
+            if p is None or id(p) not in self.uses:
+                continue
+            self.uses[id(p)] -= 1
+            if self.uses[id(p)] == 0:
+                del self.uses[id(p)]
+                if self.on_final is not None:
+                    self.on_final(p)
 
     def backward(self):
         nodes, self.nodes = self.nodes, []
@@ -289,7 +311,17 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     if w_needs and act == L.ACT_NONE and layer.bias is not None and layer.bias.requires_grad:
         y.bias_grad = layer.bias.grad           # a following norm_act folds sum(dy) into its backward pass
 
+    if w_needs:
+        ctx.tape.use(layer.weight, layer.bias)
+
     def backward():
+        try:
+            backward_body()
+        finally:
+            if w_needs:
+                ctx.tape.done(layer.weight, layer.bias)      # (also when no gradient arrived: this use contributes nothing more)
+
+    def backward_body():
         g = y.grad
         y.grad = None
         if g is None:
@@ -395,7 +427,18 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
     if residual is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and y.t.dtype == torch.bfloat16 and y.needs_grad:
         z.bn_ctx = (y.t, stats, act)
 
+    track_affine = m is not None and m.weight.requires_grad
+    if track_affine:
+        ctx.tape.use(m.weight, m.bias)
+
     def backward():
+        try:
+            backward_body()
+        finally:
+            if track_affine:
+                ctx.tape.done(m.weight, m.bias)
+
+    def backward_body():
         g = z.grad
         z.grad = None
         gs, z.grad_stats = z.grad_stats, None

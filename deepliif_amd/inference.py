@@ -169,23 +169,61 @@ def _device_for(opt) -> torch.device:
     return torch.device('cuda', ids[0] if ids else 0)
 
 
+_BN_STAT_KEYS = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def load_generator_weights(net, model_dir, name, epoch='latest', eager_mode=False):
+    """Fill `net` from a reference model directory.  The reference knows two on-disk forms (deepliif/models/__init__.py:117-156, 216-219):
+      * eager_mode=True : `<epoch>_net_<name>.pth`, the state_dict save_networks() writes (base_model.py:190-212);
+      * eager_mode=False: `<name>.pt`, the TorchScript module `deepliif serialize` traces from it (cli.py:770-830) -- the DEFAULT inference
+        route and the form the published models are distributed in.
+    The engine does not execute TorchScript graphs (they are ATen programs); a `.pt` file is used as a WEIGHT CONTAINER: its
+    state_dict() carries the same keys as the `.pth` file, minus the BatchNorm running statistics, which the reference nulls before
+    tracing (disable_batchnorm_tracking_stats, util/__init__.py:743-755) and which the per-sample-statistics inference path never reads.
+    eager_mode=False falls back to the `.pth` file when no `.pt` exists (a training directory that was never serialized)."""
+    pth = os.path.join(model_dir, f'{epoch}_net_{name}.pth')
+    pt = os.path.join(model_dir, f'{name}.pt')
+    if not eager_mode and os.path.exists(pt):
+        sd = torch.jit.load(pt, map_location='cpu').state_dict()
+        src = pt
+    elif os.path.exists(pth):
+        sd = torch.load(pth, map_location='cpu')
+        src = pth
+    else:
+        raise FileNotFoundError(f'no weights for network {name!r} in {model_dir}: neither {os.path.basename(pth)}' +
+                                ('' if eager_mode else f' nor {os.path.basename(pt)}') + ' exists' +
+                                (f' ({os.path.basename(pt)} does: pass eager_mode=False to read it)' if eager_mode and os.path.exists(pt) else ''))
+    if hasattr(sd, '_metadata'):
+        del sd._metadata
+    res = net.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if k.rsplit('.', 1)[-1] not in _BN_STAT_KEYS]
+    if missing or res.unexpected_keys:
+        raise RuntimeError(f'{src}: state_dict does not match network {name!r}: missing {missing}, unexpected {list(res.unexpected_keys)}')
+    return src
+
+
+def _nets_cache_key(model_dir, phase, eager_mode, opt):
+    """the reference's lru_cache keys on (model_dir, eager_mode, opt, phase) (models/__init__.py:157); opt objects here are plain namespaces, so
+    the fields that change what gets built / loaded stand in for them"""
+    fields = tuple((k, repr(_get(opt, k, None))) for k in ('model', 'precision', 'epoch', 'norm', 'net_g', 'net_gs', 'ngf', 'padding', 'modalities_no', 'seg_gen',
+                                                           'input_no', 'gpu_ids', 'mod_id_seg', 'input_id'))
+    return (os.path.abspath(model_dir), phase, bool(eager_mode), fields)
+
+
 def init_nets(model_dir, eager_mode=False, opt=None, phase='test'):
     """deepliif/models/__init__.py:158-219.  Returns {name: net}; every net is callable on a [N,C,H,W] tensor.
-    TorchScript '<name>.pt' files are CUDA/ATen graphs and are not loaded here: the '<epoch>_net_<name>.pth' state_dicts
-    (the reference's own checkpoint format, base_model.py:190-212) are the interchange."""
-    key = (model_dir, phase)
-    if key in _NETS_CACHE and opt is None:
-        return _NETS_CACHE[key]
+    eager_mode=False (the reference's default) reads the serialized `<name>.pt` files, eager_mode=True the `<epoch>_net_<name>.pth`
+    checkpoints -- see load_generator_weights().  Nets are process-lifetime singletons per (directory, phase, eager_mode, relevant
+    option fields), like the reference's lru_cache."""
     if opt is None:
         opt = get_opt(model_dir, mode=phase)
+    key = _nets_cache_key(model_dir, phase, eager_mode, opt)
+    if key in _NETS_CACHE:
+        return _NETS_CACHE[key]
     nets = build_generators(opt, _device_for(opt), _get(opt, 'precision', None))
     epoch = _get(opt, 'epoch', 'latest')
     for n, net in nets.items():
-        path = os.path.join(model_dir, f'{epoch}_net_{n}.pth')
-        sd = torch.load(path, map_location='cpu')
-        if hasattr(sd, '_metadata'):
-            del sd._metadata
-        net.load_state_dict(sd)
+        load_generator_weights(net, model_dir, n, epoch, eager_mode)
     _NETS_CACHE[key] = nets
     return nets
 
@@ -217,6 +255,14 @@ def _seg_weight_map(opt, seg_weights):
     if seg_weights is None:
         return {f'G{S}{off + i}': 1 / (M + 1) for i in range(M + 1)}
     return {f'G{S}{off + i}': w for i, w in enumerate(seg_weights)}
+
+
+def _wrapper_flags(opt, seg_only, mod_only):
+    """run_wrapper forwards seg_only / mod_only to the generator DAG only for DeepLIIF / DeepLIIFKD; for DeepLIIFExt / SDG it calls
+    run_fn(tile, model_path, None, eager_mode, opt) (deepliif/models/__init__.py:446-452), so their tiled inference always produces GS_i"""
+    if _get(opt, 'model', 'DeepLIIF') in ('DeepLIIFExt', 'SDG'):
+        return False, False
+    return seg_only, mod_only
 
 
 def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None) -> 'OrderedDict[str, E.Act]':
@@ -355,6 +401,7 @@ def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod
         return {}, tiler.band
     empty = tiler.empty_mask()
     ids = np.array(tiler.tile_ids)
+    seg_only, mod_only = _wrapper_flags(opt, seg_only, mod_only)
     colors = empty_tile_colors(opt, seg_only, mod_only)
     if empty.any():
         for k, c in colors.items():
@@ -495,6 +542,7 @@ def _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mo
             return a[:plan.image_height, :plan.image_width]
         srcs = [ext(a) for a in srcs]
     rects, origins = plan.paste_rects(), plan.origins
+    seg_only, mod_only = _wrapper_flags(opt, seg_only, mod_only)
     colors = empty_tile_colors(opt, seg_only, mod_only)
     out: Dict[str, np.ndarray] = {}
 

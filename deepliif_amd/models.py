@@ -95,11 +95,30 @@ class BaseModel:
         params = [p for p in net.parameters()]
         tape.record(lambda: self.exchange.ready(params))
 
+    def _hook_tape(self, tape):
+        """a training tape reports every parameter whose gradient has become final to the gradient exchange (progressive buckets of the
+        networks above 64 MB, distributed.GradExchanger.param_final)"""
+        if tape is not None and self.is_train and getattr(self, 'exchange', None) is not None:
+            tape.on_final = self.exchange.param_final
+        return tape
+
+    def _register_nets_with_exchange(self):
+        for o in self.optimizers:
+            flat = getattr(o, 'flat', None)
+            if flat is None:
+                continue
+            owned = {id(p) for p in flat.params}
+            for _, net in self._nets():
+                params = list(net.parameters())
+                if params and id(params[0]) in owned:
+                    self.exchange.register_net(o, params)
+
     def _sync_replicas(self):
         """once, before the first step: broadcast parameters / BatchNorm buffers from rank 0 (what DistributedDataParallel does at
         construction, networks.py:134)"""
         if getattr(self, '_replicas_synced', False):
             return
+        self._register_nets_with_exchange()
         nets = [net for _, net in self._nets()]
         for o in self.optimizers:
             self.exchange.sync_parameters(o, nets)
@@ -323,7 +342,7 @@ class DeepLIIFModel(BaseModel):
         self._real_pairs = None
 
     def _ctx(self, tape, training=True):
-        return E.Ctx(self.precision, tape, training=training)
+        return E.Ctx(self.precision, self._hook_tape(tape), training=training)
 
     def forward(self, record: Optional[bool] = None):
         """DeepLIIF_model.py:175-203."""
@@ -567,7 +586,7 @@ class DeepLIIFExtModel(BaseModel):
     def forward(self, record=None):
         record = self.is_train if record is None else record
         tape = E.Tape() if record else None
-        ctx = E.Ctx(self.precision, tape, training=record)
+        ctx = E.Ctx(self.precision, self._hook_tape(tape), training=record)
         self._fake = []
         for net in self.netG:
             self._mark_net(tape, net)
@@ -592,7 +611,7 @@ class DeepLIIFExtModel(BaseModel):
 
     def backward_D(self):
         tape = E.Tape()
-        ctx = E.Ctx(self.precision, tape, training=True)
+        ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
         cg, cs, M = self.criterionGAN_mod, self.criterionGAN_seg, self.mod_gen_no
         for net in self._d_nets():
             self._mark_net(tape, net)
@@ -613,7 +632,7 @@ class DeepLIIFExtModel(BaseModel):
 
     def backward_G(self):
         tape = self._tape_G
-        ctx = E.Ctx(self.precision, tape, training=True)
+        ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
         cg, M = self.criterionGAN_mod, self.mod_gen_no
         rc = self._cat_real(E.Ctx(self.precision, None, training=True))
         for i in range(M):

@@ -82,9 +82,14 @@ class EngineNet(nn.Module):
         raise NotImplementedError
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """Inference seam: NCHW fp32 in, NCHW fp32 out (deepliif/models/__init__.py:285-291 calls net(tensor))."""
+        """Inference seam: NCHW fp32 in, NCHW fp32 out (deepliif/models/__init__.py:285-291 calls net(tensor)).
+        eval() (init_nets): BatchNorm on the statistics of each tile, which is what the reference's one-tile forwards with nulled running
+        statistics compute.  train(): what nn.Module.train() means for the reference's module tree -- TorchServe's handler
+        serves the nets in that mode (model-server/net_handler.py:10-12): statistics over the whole batch, running statistics updated
+        (momentum 0.1) where the module still tracks them, Dropout(0.5) active."""
         prec = E.Precision.get(self.precision)
-        ctx = E.Ctx(prec, None, training=False, per_sample_norm=self.batched_per_sample_norm)
+        train = self.training
+        ctx = E.Ctx(prec, None, training=train, per_sample_norm=self.batched_per_sample_norm and not train)
         return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
 
 

@@ -271,7 +271,7 @@ class HipBackend:
         L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
 
     def wgrad_c4_applies(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw=0) -> bool:
-        return wgrad_c4_ok(P.shape[3], grad.shape[0], Q.shape[3], grad.shape[1], k, step, pad, pad_mode, P.shape[1], P.shape[2], Q.shape[1], Q.shape[2],
+        return not _NO_WGRAD_C4 and wgrad_c4_ok(P.shape[3], grad.shape[0], Q.shape[3], grad.shape[1], k, step, pad, pad_mode, P.shape[1], P.shape[2], Q.shape[1], Q.shape[2],
                            P.dtype == torch.bfloat16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE, bool(stack_kw))
 
     # ---- normalisation

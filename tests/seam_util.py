@@ -40,3 +40,42 @@ def close_u8(got, exp, max_mismatch):
     frac = float((d != 0).mean())
     assert frac <= max_mismatch, frac
     return frac
+
+
+class _Holder(torch.nn.Module):
+    def forward(self, x):
+        return x
+
+
+def serialize_checkpoint_dir(mdir, out_dir, drop_running_stats=True):
+    """The on-disk form `deepliif serialize` (cli.py:770-830) leaves behind -- `<name>.pt` TorchScript modules + train_opt.txt, NO .pth files --
+    built WITHOUT the reference: every `<epoch>_net_<name>.pth` state_dict is wrapped in a module tree with the same parameter paths and
+    traced (identity forward).  What the engine relies on is exactly what this reproduces: torch.jit.load(f).state_dict() carries the
+    reference's keys, minus the BatchNorm running statistics that disable_batchnorm_tracking_stats nulls before tracing
+    (util/__init__.py:743-755).  (The reference's own traced files cannot be committed as fixtures: a TorchScript archive embeds the traced
+    module's source.)  tests/test_reference_seam.py checks the same loader against files the reference's tracer really wrote."""
+    os.makedirs(out_dir, exist_ok=True)
+    shutil.copy(os.path.join(mdir, 'train_opt.txt'), os.path.join(out_dir, 'train_opt.txt'))
+    for f in sorted(os.listdir(mdir)):
+        if not f.endswith('.pth'):
+            continue
+        name = f[len('latest_net_'):-len('.pth')]
+        if not name.startswith('G'):            # serialize traces what init_nets returns: the generators
+            continue
+        sd = torch.load(os.path.join(mdir, f), map_location='cpu')
+        root = _Holder()
+        for k, v in sd.items():
+            leaf = k.rsplit('.', 1)[-1]
+            if drop_running_stats and leaf in ('running_mean', 'running_var'):
+                continue
+            mod = root
+            for part in k.split('.')[:-1]:
+                if part not in mod._modules:
+                    mod.add_module(part, _Holder())
+                mod = mod._modules[part]
+            if leaf in ('running_mean', 'running_var', 'num_batches_tracked'):
+                mod.register_buffer(leaf, v.clone())
+            else:
+                mod.register_parameter(leaf, torch.nn.Parameter(v.clone(), requires_grad=False))
+        torch.jit.trace(root, torch.zeros(1)).save(os.path.join(out_dir, f'{name}.pt'))
+    return out_dir

@@ -17,12 +17,12 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--size', '64', '--batch', '1',
-                        '--ngf', '8', '--no-cpu-baseline'], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+                        '--ngf', '8', '--no-cpu-baseline', '--strict'], capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    # the gloo transport itself writes '[Gloo] Rank ...' lines to stdout from C++ (RCCL does not); everything else must be the ONE JSON line
-    # (two ranks write those concurrently, so a '[Gloo] Rank' prefix and its '... is connected to 1 peer ranks ...' tail can land on different lines)
-    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith('[Gloo]') and 'peer ranks' not in l]
-    assert len(lines) == 1, lines
+    # the gloo transport itself writes '[Gloo] Rank ...' fragments to stdout from C++, from both ranks at once (RCCL does not): look for the contract
+    # line by its first key instead of trying to recognise everything that is NOT it
+    lines = [l[l.index('{"metric"'):] for l in r.stdout.splitlines() if '{"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline', 'strict_parity'):

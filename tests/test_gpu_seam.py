@@ -8,7 +8,7 @@ import torch
 from PIL import Image
 
 from golden_util import synth_image
-from seam_util import Z, build_checkpoint_dir, close_u8
+from seam_util import Z, build_checkpoint_dir, close_u8, serialize_checkpoint_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -118,3 +118,75 @@ def test_infer_modalities_adds_postprocessed_images_and_scoring(tmp_path):
     assert all('Seg' in k for k in only_seg)
     mods, none = I.infer_modalities(img2, 64, mdir, eager_mode=True, opt=opt, mod_only=True)
     assert none is None and 'SegOverlaid' not in mods
+
+
+def test_serialized_model_directory_default_route_on_the_gpu(tmp_path):
+    """the reference's DEFAULT inference route (eager_mode=False, models/__init__.py:216-219) on a directory that holds only `<name>.pt` TorchScript
+    files + train_opt.txt: used as weight containers, same uint8 bytes as the checkpoint directory they were serialized from"""
+    import os
+    from deepliif_amd import inference as I
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    sdir = serialize_checkpoint_dir(mdir, str(tmp_path / 'serialized'))
+    assert not [f for f in os.listdir(sdir) if f.endswith('.pth')]
+    img, img2 = _images()
+    r_pt = I.inference(img2, 64, 4, sdir, opt=_opt(sdir, 'fp32'))
+    r_pth = I.inference(img2, 64, 4, mdir, eager_mode=True, opt=_opt(mdir, 'fp32'))
+    assert list(r_pt) == Z['dl_m2/inf_keys'].tolist()
+    for k, v in r_pt.items():
+        close_u8(v, Z[f'dl_m2/inf/{k}'], 0.005)
+        assert np.array_equal(np.asarray(v), np.asarray(r_pth[k])), k
+
+
+@pytest.mark.parametrize('kind', ['resnet', 'unet'])
+def test_torchserve_handler_contract(kind):
+    """model-server/resnet.py:4-14, unet.py:4-13: the served classes construct the generators with EXACTLY these keyword arguments (no-argument
+    subclasses), TorchServe loads a state_dict into them, and net_handler.py:7-16 puts the module in train() mode and feeds it
+    torch.load(BytesIO(body)).to(device).  In that mode the reference's module tree has Dropout(0.5) active and BatchNorm on batch statistics with
+    running-statistic updates; with use_dropout=False the train()-mode output of one tile equals the eval()-mode output (statistics of that tile)."""
+    from io import BytesIO
+    from deepliif_amd.networks import ResnetGenerator, UnetGenerator, get_norm_layer
+    from oracle import deepliif_oracle as O
+
+    class Resnet(ResnetGenerator):
+        def __init__(self, use_dropout=True):
+            super(Resnet, self).__init__(input_nc=3, output_nc=3, ngf=64, norm_layer=get_norm_layer(norm_type='batch'), use_dropout=use_dropout, n_blocks=9,
+                                         padding_type='zero')
+
+    class Unet(UnetGenerator):
+        def __init__(self, use_dropout=True):
+            super(Unet, self).__init__(input_nc=3, output_nc=3, num_downs=9, ngf=64, norm_layer=get_norm_layer(norm_type='batch'), use_dropout=use_dropout)
+
+    cls, arch, size = (Resnet, 'resnet_9blocks', 128) if kind == 'resnet' else (Unet, 'unet_512', 512)
+    sd = O.random_state_dict(arch, 3, 3, 64, 'batch', 'zero', 4, generator=torch.Generator().manual_seed(11))
+    body = BytesIO()
+    torch.save(torch.rand(1, 3, size, size, generator=torch.Generator().manual_seed(12)) * 2 - 1, body)
+
+    def serve(net):                                      # NetHandler.preprocess + BaseHandler.inference
+        net.train()
+        with torch.no_grad():
+            return net(torch.load(BytesIO(body.getvalue())).to('cuda'))
+
+    net = cls().set_precision('fp32')
+    net.load_state_dict(sd, strict=True)
+    net.to('cuda')
+    bn = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    rm0 = [m.running_mean.clone() for m in bn]
+    y1, y2 = serve(net), serve(net)
+    assert y1.shape == (1, 3, size, size) and y1.device.type == 'cuda' and bool(torch.isfinite(y1).all()) and float(y1.abs().max()) <= 1.0
+    assert not torch.equal(y1, y2), 'Dropout(0.5) must be active in train() mode (use_dropout=True)'
+    assert all(int(m.num_batches_tracked) == 2 for m in bn)
+    moved = sum(float((m.running_mean - r).abs().max()) > 0 for m, r in zip(bn, rm0))
+    assert moved >= len(bn) - 1, 'BatchNorm running statistics are updated in train() mode (%d of %d moved)' % (moved, len(bn))   # a 1x1 map has mean == input: may not move
+    # without dropout: train()-mode serving of ONE tile == eval()-mode inference of that tile (both normalise with the tile's own statistics),
+    # and both equal the CPU oracle's forward of the same state_dict
+    net2 = cls(use_dropout=False).set_precision('fp32')
+    net2.load_state_dict(sd, strict=True)
+    net2.to('cuda')
+    yt = serve(net2)
+    net2.eval()
+    with torch.no_grad():
+        ye = net2(torch.load(BytesIO(body.getvalue())).to('cuda'))
+    assert torch.equal(yt, ye)
+    exp = O.run_generator(arch, sd, torch.load(BytesIO(body.getvalue())), 'batch', 'zero')
+    err = float((yt.cpu() - exp).abs().max() / exp.abs().max())
+    assert err < 1e-3, err

@@ -68,3 +68,46 @@ def test_reference_options_object_drives_the_drop_in(tmp_path, ref_options):
     finally:
         M._MODEL_CLASSES['DeepLIIF'] = M.DeepLIIFModel
         fake_backend.uninstall()
+
+
+def test_files_traced_by_the_reference_load_through_the_default_route(tmp_path, ref_options):
+    """`deepliif serialize` (cli.py:796-811) on a checkpoint directory: the reference's own init_nets(eager) nets, disable_batchnorm_tracking_stats,
+    torch.jit.trace, save -- done here with the reference's code -- then the drop-in's init_nets(dir) (eager_mode=False, the reference's default,
+    models/__init__.py:216-219) reads those `<name>.pt` files and reproduces the reference's run_dask bytes for the directory."""
+    import numpy as np
+    from PIL import Image
+    import fake_backend
+    from deepliif.models import init_nets as ref_init_nets
+    from deepliif.util import disable_batchnorm_tracking_stats
+    from deepliif_amd import inference as I
+    from golden_util import synth_image
+    from seam_util import Z, build_checkpoint_dir, close_u8
+    Options, _ = ref_options
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    ropt = Options(path_file=os.path.join(mdir, 'train_opt.txt'), mode='test')
+    ropt.ngf, ropt.gpu_ids, ropt.epoch = 8, [], 'latest'
+    sdir = os.path.join(str(tmp_path), 'serialized')
+    os.makedirs(sdir)
+    import shutil
+    shutil.copy(os.path.join(mdir, 'train_opt.txt'), os.path.join(sdir, 'train_opt.txt'))
+    sample = torch.zeros(1, 3, 64, 64)
+    for name, net in ref_init_nets(mdir, eager_mode=True, opt=ropt, phase='test').items():
+        net = disable_batchnorm_tracking_stats(net.eval()).cpu()
+        torch.jit.trace(net, sample).save(os.path.join(sdir, f'{name}.pt'))
+    assert sorted(os.listdir(sdir)) == ['G1.pt', 'G2.pt', 'GS0.pt', 'GS1.pt', 'GS2.pt', 'train_opt.txt']
+    fake_backend.install()
+    old = I._device_for
+    I._device_for = lambda opt: torch.device('cpu')
+    I._NETS_CACHE.clear()
+    try:
+        opt = I.get_opt(sdir)
+        opt.ngf, opt.precision = 8, 'fp32'
+        tile = Image.fromarray(synth_image(150, 100, 31)).crop((0, 0, 64, 64))
+        res = I.run_dask(tile, model_path=sdir, opt=opt)
+        assert list(res) == Z['dl_m2/run_dask_keys'].tolist()
+        for k, v in res.items():
+            close_u8(v, Z[f'dl_m2/run_dask/{k}'], 0.01)
+    finally:
+        I._device_for = old
+        I._NETS_CACHE.clear()
+        fake_backend.uninstall()

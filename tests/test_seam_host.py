@@ -15,7 +15,7 @@ from deepliif_amd import inference as I
 from deepliif_amd import models as M
 from deepliif_amd import networks as N
 from golden_util import synth_image
-from seam_util import Z, build_checkpoint_dir, close_u8
+from seam_util import Z, build_checkpoint_dir, close_u8, serialize_checkpoint_dir
 
 
 @pytest.fixture(autouse=True)
@@ -91,6 +91,52 @@ def test_ext_and_sdg_inference_from_a_checkpoint_dir(tmp_path, tag):
     assert list(r) == Z[f'{tag}/inf_keys'].tolist()
     for k, v in r.items():
         close_u8(v, Z[f'{tag}/inf/{k}'], 0.01)
+
+
+def test_serialized_model_directory_is_the_default_inference_route(tmp_path):
+    """init_nets(model_dir) with the reference's default eager_mode=False reads `<name>.pt` (deepliif/models/__init__.py:216-219): a directory
+    holding ONLY the TorchScript files + train_opt.txt (what `deepliif serialize` writes and what is distributed) gives the same bytes as the
+    `.pth` directory it was made from; eager_mode=True on it fails like the reference (no checkpoint to load), naming the file that exists"""
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    sdir = serialize_checkpoint_dir(mdir, str(tmp_path / 'serialized'))
+    assert sorted(os.listdir(sdir)) == ['G1.pt', 'G2.pt', 'GS0.pt', 'GS1.pt', 'GS2.pt', 'train_opt.txt']
+    opt = _test_opt(sdir)
+    img, _ = _images()
+    tile = img.crop((0, 0, 64, 64))
+    res = I.run_dask(tile, model_path=sdir, opt=opt)                       # eager_mode defaults to False, as in the reference
+    assert list(res) == Z['dl_m2/run_dask_keys'].tolist()
+    for k, v in res.items():
+        close_u8(v, Z[f'dl_m2/run_dask/{k}'], 0.01)
+    ref = I.run_dask(tile, model_path=mdir, eager_mode=True, opt=_test_opt(mdir))
+    for k in res:
+        assert np.array_equal(np.asarray(res[k]), np.asarray(ref[k])), k         # same weights -> same bytes
+    with pytest.raises(FileNotFoundError, match='G1.pt does'):
+        I.init_nets(sdir, eager_mode=True, opt=opt)
+    # eager_mode=False on a directory that was never serialized falls back to the checkpoints
+    nets = I.init_nets(mdir, eager_mode=False, opt=_test_opt(mdir))
+    assert list(nets) == ['G1', 'G2', 'GS0', 'GS1', 'GS2']
+
+
+def test_init_nets_cache_distinguishes_options(tmp_path):
+    """the cache key must include what the reference's lru_cache keys on (opt, eager_mode): a later call with other options must not
+    get nets built for the first one"""
+    mdir = build_checkpoint_dir(tmp_path, 'dl_m2')
+    a = I.init_nets(mdir, eager_mode=True, opt=_test_opt(mdir, 'fp32'))
+    b = I.init_nets(mdir, eager_mode=True, opt=_test_opt(mdir, 'bf16'))
+    assert a is not b and next(iter(a.values())).precision == 'fp32' and next(iter(b.values())).precision == 'bf16'
+    assert I.init_nets(mdir, eager_mode=True, opt=_test_opt(mdir, 'fp32')) is a
+
+
+def test_ext_tiled_inference_ignores_mod_only_like_run_wrapper(tmp_path):
+    """run_wrapper calls run_fn(tile, model_path, None, eager_mode, opt) for DeepLIIFExt / SDG (models/__init__.py:446-452) -- seg_only /
+    mod_only never reach the generator DAG, so inference(mod_only=True) still returns Seg_i"""
+    mdir = build_checkpoint_dir(tmp_path, 'ext_m2')
+    opt = _test_opt(mdir)
+    _, img2 = _images()
+    r = I.inference(img2, 64, 4, mdir, eager_mode=True, opt=opt, batch_size=4, mod_only=True)
+    assert list(r) == Z['ext_m2/inf_keys'].tolist()
+    for k, v in r.items():
+        close_u8(v, Z[f'ext_m2/inf/{k}'], 0.01)
 
 
 def test_transform_and_tensor_to_pil_bytes():
