@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libdeepliif_hip.so')
 
 DL_F32, DL_BF16 = 0, 1
 PREC_BF16, PREC_BF16X3 = 1, 3
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1 = 0, 1, 2, 3
@@ -85,6 +85,8 @@ SIGNATURES = {
     'dl_act_backward': (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_dropout': (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _f, C.c_uint64, _vp]),
     'dl_axpby': (_i, [_i, _f, _vp, _i, _f, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_gate_forward': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    'dl_gate_backward': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_copy_channels': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i64, _i, _i, _vp]),
     'dl_channel_sum': (_i, [_i, _vp, _i, _i64, _i, _i, _vp, _i, _vp, _vp]),
     'dl_nchw_to_nhwc': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -128,8 +130,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 104:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 104 (stale build)')
+    if lib.dl_version() != 105:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 105 (stale build)')
     _lib = lib
     return lib
 

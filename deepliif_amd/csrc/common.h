@@ -96,6 +96,7 @@ __device__ __forceinline__ float apply_act(int act, float v) {
         case DL_ACT_RELU: return v > 0.f ? v : 0.f;
         case DL_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
         case DL_ACT_TANH: return tanhf(v);
+        case DL_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
         default: return v;
     }
 }
@@ -105,6 +106,7 @@ __device__ __forceinline__ float act_grad_from_output(int act, float y) {
         case DL_ACT_RELU: return y > 0.f ? 1.f : 0.f;
         case DL_ACT_LRELU: return y > 0.f ? 1.f : 0.2f;
         case DL_ACT_TANH: return 1.f - y * y;
+        case DL_ACT_SIGMOID: return y * (1.f - y);
         default: return 1.f;
     }
 }

@@ -56,6 +56,73 @@ extern "C" int dl_act_backward(int act, int dtype, const void *dy, int dy_ps, co
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- attention gate (att_unet.py:108-115)
+template <typename T>
+__global__ void __launch_bounds__(256) gate_fwd_kernel(const T *x, int x_ps, const T *psi, int psi_ps, T *out, int o_ps, size_t npix, int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cvec;
+        const int c0 = (int)(i % cvec) * 8;
+        float v[8];
+        Vec8<T>::load(x + p * x_ps + c0, v);
+        const float a = load1<T>(psi + p * psi_ps);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= a;
+        Vec8<T>::store(out + p * o_ps + c0, v);
+    }
+}
+// one thread per (pixel, 8-channel chunk); the cvec = Cp / 8 <= 64 chunks of a pixel sit in adjacent lanes of ONE wave (cvec is a power of
+// two and the grid stride is a multiple of 64), so dpsi = sum_c g * x is a butterfly over those lanes
+template <typename T>
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const T *g, int g_ps, const T *x, int x_ps, const T *psi, int psi_ps, T *dx, int dx_ps, T *dpsi,
+                                                       int dpsi_ps, size_t npix, int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = npix * cvec;
+    const size_t rounded = (total + 63) / 64 * 64;               // whole waves stay converged for the shuffles
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < rounded; i += (size_t)gridDim.x * blockDim.x) {
+        const bool live = i < total;
+        const size_t p = live ? i / cvec : 0;
+        const int c0 = (int)(i % cvec) * 8;
+        float gv[8], xv[8];
+        float part = 0.f;
+        if (live) {
+            Vec8<T>::load(g + p * g_ps + c0, gv);
+            Vec8<T>::load(x + p * x_ps + c0, xv);
+            const float a = load1<T>(psi + p * psi_ps);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { part += gv[k] * xv[k]; gv[k] *= a; }
+            if (dx) Vec8<T>::store(dx + p * dx_ps + c0, gv);
+        }
+        for (int o = cvec >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (live && c0 == 0) {
+            float d[8] = {part, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            Vec8<T>::store(dpsi + p * dpsi_ps, d);
+        }
+    }
+}
+extern "C" int dl_gate_forward(int dtype, const void *x, int x_ps, const void *psi, int psi_ps, void *out, int o_ps, int64_t npix, int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !psi || !out || Cp % 8 || x_ps % 8 || psi_ps % 8 || o_ps % 8 || npix <= 0) DL_FAIL("dl_gate_forward: bad argument");
+    const size_t total = (size_t)npix * (Cp / 8);
+    if (dtype == DL_F32) hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)x, x_ps, (const float *)psi, psi_ps, (float *)out, o_ps, (size_t)npix, Cp);
+    else hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)x, x_ps, (const bf16_t *)psi, psi_ps, (bf16_t *)out, o_ps, (size_t)npix, Cp);
+    DL_CHECK_LAUNCH("dl_gate_forward");
+    return 0;
+}
+extern "C" int dl_gate_backward(int dtype, const void *g, int g_ps, const void *x, int x_ps, const void *psi, int psi_ps, void *dx, int dx_ps, void *dpsi,
+                                int dpsi_ps, int64_t npix, int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!g || !x || !psi || !dpsi || Cp % 8 || g_ps % 8 || x_ps % 8 || psi_ps % 8 || dpsi_ps % 8 || (dx && dx_ps % 8) || npix <= 0) DL_FAIL("dl_gate_backward: bad argument");
+    const int cvec = Cp / 8;
+    if (cvec > 64 || (cvec & (cvec - 1))) DL_FAIL("dl_gate_backward: Cp=%d must be a power of two <= 512 (one wave reduces the channels of a pixel)", Cp);
+    const size_t total = (size_t)npix * cvec;
+    if (dtype == DL_F32) hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)g, g_ps, (const float *)x, x_ps, (const float *)psi, psi_ps, (float *)dx, dx_ps, (float *)dpsi, dpsi_ps, (size_t)npix, Cp);
+    else hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)g, g_ps, (const bf16_t *)x, x_ps, (const bf16_t *)psi, psi_ps, (bf16_t *)dx, dx_ps, (bf16_t *)dpsi, dpsi_ps, (size_t)npix, Cp);
+    DL_CHECK_LAUNCH("dl_gate_backward");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- out = alpha*a + beta*b
 template <typename T>
 __global__ void __launch_bounds__(256) axpby_kernel(float alpha, const T *a, int a_ps, float beta, const T *b, int b_ps, T *out, int o_ps,

@@ -526,6 +526,53 @@ def concat_channels(ctx: Ctx, parts: List[Act]) -> Act:
     return z
 
 
+def act_op(ctx: Ctx, x: Act, act: int) -> Act:
+    """a stand-alone activation layer (nn.Sigmoid of the attention gate, att_unet.py:100-104): y = act(x)"""
+    be = ops.impl()
+    out = empty_like_act(x.t)
+    be.act_forward(act, x.t, out)
+    needs = ctx.tape is not None and x.needs_grad
+    y = Act(out, x.C, needs)
+    if needs:
+        def backward():
+            g = y.grad
+            y.grad = None
+            if g is None:
+                return
+            dx = empty_like_act(g)
+            be.act_backward(act, g, y.t, dx)
+            x.add_grad(dx)
+        ctx.tape.record(backward)
+    return y
+
+
+def gate(ctx: Ctx, x: Act, psi: Act, out: Optional[torch.Tensor] = None) -> Act:
+    """Attention_block.forward's last line (att_unet.py:113-115): x * psi, psi a ONE-channel map broadcast over the channels of x.
+    `out` may be the first half of a concat buffer (torch.cat((x_gated, d), dim=1) is then zero-copy, like the UNet skips)."""
+    be = ops.impl()
+    assert psi.C == 1 and psi.t.shape[:3] == x.t.shape[:3]
+    if out is None:
+        out = empty_like_act(x.t)
+    be.gate_forward(x.t, psi.t, out)
+    needs = ctx.tape is not None and (x.needs_grad or psi.needs_grad)
+    z = Act(out, x.C, needs)
+    if needs:
+        def backward():
+            g = z.grad
+            z.grad = None
+            if g is None:
+                return
+            dx = empty_like_act(x.t) if x.needs_grad else None
+            dpsi = empty_like_act(psi.t)
+            be.gate_backward(g, x.t, psi.t, dx, dpsi)
+            if dx is not None:
+                x.add_grad(dx)
+            if psi.needs_grad:
+                psi.add_grad(dpsi)
+        ctx.tape.record(backward)
+    return z
+
+
 def weighted_sum(ctx: Ctx, parts: List[Act], weights: List[float]) -> Act:
     """stack([w_i * x_i]).sum(0)  (DeepLIIF_model.py:203, 258-262)."""
     be = ops.impl()

@@ -352,6 +352,140 @@ class _JoinedAct(E.Act):
 
 
 # -------------------------------------------------------------------------------------------------------------
+# Attention U-Net (`--net-gs unet_512_attention`, networks.py:189-190 -> att_unet.py:117-199)
+# -------------------------------------------------------------------------------------------------------------
+class conv_block(nn.Module):
+    """Parameter container, att_unet.py:32-55: Conv2d(k4 s2 p1, bias) [+ BatchNorm2d] + LeakyReLU(0.2) / ReLU (innermost)."""
+
+    def __init__(self, ch_in, ch_out, innermost=False, outermost=False):
+        super().__init__()
+        conv = nn.Conv2d(ch_in, ch_out, kernel_size=4, stride=2, padding=1, bias=True)
+        if outermost:
+            self.conv = nn.Sequential(conv, nn.LeakyReLU(0.2, True))
+        elif innermost:
+            self.conv = nn.Sequential(conv, nn.ReLU(inplace=True))
+        else:
+            self.conv = nn.Sequential(conv, nn.BatchNorm2d(ch_out), nn.LeakyReLU(0.2, True))
+        self.ch_in, self.ch_out, self.innermost, self.outermost = ch_in, ch_out, innermost, outermost
+
+
+class up_conv(nn.Module):
+    """att_unet.py:57-85: ConvTranspose2d(k4 s2 p1) + BatchNorm2d + ReLU; the outermost one has a bias and ends in Tanh; every one but the
+    innermost reads the concatenation [gated skip | up] (ch_in * 2 channels)."""
+
+    def __init__(self, ch_in, ch_out, innermost=False, outermost=False):
+        super().__init__()
+        if outermost:
+            self.up = nn.Sequential(nn.ConvTranspose2d(ch_in * 2, ch_out, kernel_size=4, stride=2, padding=1), nn.Tanh())
+        else:
+            self.up = nn.Sequential(nn.ConvTranspose2d(ch_in if innermost else ch_in * 2, ch_out, kernel_size=4, stride=2, padding=1, bias=False),
+                                    nn.BatchNorm2d(ch_out), nn.ReLU(True))
+        self.ch_in, self.ch_out, self.innermost, self.outermost = ch_in, ch_out, innermost, outermost
+
+
+class Attention_block(nn.Module):
+    """att_unet.py:88-115: psi = Sigmoid(BN(Conv1x1(relu(BN(Conv1x1(g)) + BN(Conv1x1(x)))))) with ONE channel; returns x * psi."""
+
+    def __init__(self, F_g, F_l, F_int):
+        super().__init__()
+        self.W_g = nn.Sequential(nn.Conv2d(F_g, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(F_int))
+        self.W_x = nn.Sequential(nn.Conv2d(F_l, F_int, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(F_int))
+        self.psi = nn.Sequential(nn.Conv2d(F_int, 1, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(inplace=True)
+        self.F_g, self.F_l, self.F_int = F_g, F_l, F_int
+
+
+class AttU_Net(EngineNet):
+    """att_unet.py:117-199, same module tree and state_dict keys (Conv1..Conv8, Up8, Att8, ..., Up2, Att2, Up1; widths are fixed at
+    64 ... 512, BatchNorm2d is hard-wired: define_G passes neither ngf nor the norm layer).  Eight stride-2 levels: the input side must be a
+    multiple of 256.  On the engine: the 4x4 stride-2 convs and transposed convs are the UNet's gather GEMMs (bias / LeakyReLU / ReLU / Tanh in
+    the epilogue or behind the fused norm kernel), the attention blocks' 1x1 convs are plain GEMMs over the pixels, relu(g1 + x1) is the
+    residual form of the norm kernel + an input activation of the psi conv, x * psi is dl_gate_forward / _backward, and
+    torch.cat((x_gated, d), 1) is zero-copy: the gate and the up path's norm write the two halves of one buffer."""
+
+    def __init__(self, img_ch=3, output_ch=1):
+        super().__init__()
+        self.Conv1 = conv_block(img_ch, 64, outermost=True)
+        self.Conv2 = conv_block(64, 128)
+        self.Conv3 = conv_block(128, 256)
+        self.Conv4 = conv_block(256, 512)
+        self.Conv5 = conv_block(512, 512)
+        self.Conv6 = conv_block(512, 512)
+        self.Conv7 = conv_block(512, 512)
+        self.Conv8 = conv_block(512, 512, innermost=True)
+        self.Up8 = up_conv(512, 512, innermost=True)
+        self.Att8 = Attention_block(512, 512, 512)
+        self.Up7 = up_conv(512, 512)
+        self.Att7 = Attention_block(512, 512, 512)
+        self.Up6 = up_conv(512, 512)
+        self.Att6 = Attention_block(512, 512, 512)
+        self.Up5 = up_conv(512, 512)
+        self.Att5 = Attention_block(512, 512, 512)
+        self.Up4 = up_conv(512, 256)
+        self.Att4 = Attention_block(256, 256, 128)
+        self.Up3 = up_conv(256, 128)
+        self.Att3 = Attention_block(128, 128, 64)
+        self.Up2 = up_conv(128, 64)
+        self.Att2 = Attention_block(64, 64, 32)
+        self.Up1 = up_conv(64, output_ch, outermost=True)
+        self.norm_kind = 'batch'
+
+    def _bind(self):
+        def conv_of(seq, spec):
+            return E.ConvLayer(spec, seq[0].weight, seq[0].bias)
+
+        def bn_of(seq, c, idx=1):
+            return E.NormLayer('batch', c, seq[idx]) if isinstance(seq[idx], nn.BatchNorm2d) else None
+        downs = []
+        for k in range(1, 9):
+            blk = getattr(self, f'Conv{k}')
+            downs.append((conv_of(blk.conv, ConvSpec('conv', blk.ch_in, blk.ch_out, 4, 2, 1)), bn_of(blk.conv, blk.ch_out), blk))
+        ups, atts = {}, {}
+        for k in range(8, 0, -1):
+            blk = getattr(self, f'Up{k}')
+            cin = blk.up[0].weight.shape[0]
+            ups[k] = (conv_of(blk.up, ConvSpec('convT', cin, blk.ch_out, 4, 2, 1)), bn_of(blk.up, blk.ch_out), blk)
+            if k >= 2:
+                a = getattr(self, f'Att{k}')
+                atts[k] = dict(wg=(conv_of(a.W_g, ConvSpec('conv', a.F_g, a.F_int, 1, 1, 0)), bn_of(a.W_g, a.F_int)),
+                               wx=(conv_of(a.W_x, ConvSpec('conv', a.F_l, a.F_int, 1, 1, 0)), bn_of(a.W_x, a.F_int)),
+                               psi=(conv_of(a.psi, ConvSpec('conv', a.F_int, 1, 1, 1, 0)), bn_of(a.psi, 1)))
+        return dict(downs=downs, ups=ups, atts=atts)
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        """att_unet.py:153-199."""
+        b = self._layers()
+        assert x.t.shape[1] % 256 == 0 and x.t.shape[2] % 256 == 0, 'AttU_Net halves the image eight times: H and W must be multiples of 256'
+        xs = []
+        h = x
+        for conv, bn, blk in b['downs']:
+            if bn is None:
+                h = E.conv(ctx, h, conv, act=L.ACT_RELU if blk.innermost else L.ACT_LRELU)
+            else:
+                h = E.norm_act(ctx, E.conv(ctx, h, conv, stats=True), bn, L.ACT_LRELU)
+            xs.append(h)                                    # xs[k - 1] = x_k
+        n = x.t.shape[0]
+        src = xs[7]                                         # x8
+        for k in range(8, 1, -1):
+            conv, bn, _ = b['ups'][k]
+            skip = xs[k - 2]                                # x_{k-1}: what Att_k gates
+            c = conv.spec.cout
+            assert skip.C == c and E.cpad(c) == c
+            hh, ww = skip.t.shape[1], skip.t.shape[2]
+            cat = torch.empty((n, hh, ww, 2 * c), dtype=ctx.prec.dtype, device=x.t.device)
+            d = E.norm_act(ctx, E.conv(ctx, src, conv, stats=True), bn, L.ACT_RELU, out=cat[..., c:])
+            a = b['atts'][k]
+            g1 = E.norm_act(ctx, E.conv(ctx, d, a['wg'][0], stats=True), a['wg'][1], L.ACT_NONE)
+            s = E.norm_act(ctx, E.conv(ctx, skip, a['wx'][0], stats=True), a['wx'][1], L.ACT_NONE, residual=g1)          # g1 + x1
+            p = E.norm_act(ctx, E.conv(ctx, s, a['psi'][0], in_act=L.ACT_RELU, stats=True), a['psi'][1], L.ACT_NONE)     # psi conv over relu(g1 + x1)
+            p = E.act_op(ctx, p, L.ACT_SIGMOID)
+            xg = E.gate(ctx, skip, p, out=cat[..., :c])
+            src = _JoinedAct(cat, 2 * c, xg, d, ctx)
+        conv, _, _ = b['ups'][1]
+        return E.conv(ctx, src, conv, act=L.ACT_TANH)
+
+
+# -------------------------------------------------------------------------------------------------------------
 # NLayerDiscriminator
 # -------------------------------------------------------------------------------------------------------------
 class NLayerDiscriminator(EngineNet):
@@ -444,6 +578,8 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
     elif netG in ('unet_32', 'unet_64', 'unet_128', 'unet_256', 'unet_512'):
         downs = {'unet_32': 5, 'unet_64': 6, 'unet_128': 7, 'unet_256': 8, 'unet_512': 9}[netG]
         net = UnetGenerator(input_nc, output_nc, downs, ngf, norm_layer=norm_layer, use_dropout=use_dropout)
+    elif netG == 'unet_512_attention':
+        net = AttU_Net(img_ch=input_nc, output_ch=output_nc)       # networks.py:189-190: ngf / norm / dropout are not forwarded
     else:
         raise NotImplementedError('Generator model name [%s] is not on the MI355X hot path' % netG)
     return init_net(net, init_type, init_gain, gpu_ids)

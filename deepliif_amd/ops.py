@@ -332,6 +332,20 @@ class HipBackend:
         L.check(self.lib.dl_axpby(dl_dtype(a), float(alpha), _ptr(a), pstride(a), float(beta), _ptr(b), pstride(b) if b is not None else 8,
                                   _ptr(out), pstride(out), npix, a.shape[3], _stream()), 'dl_axpby')
 
+    def gate_forward(self, x, psi, out):
+        """out = x * psi[..., :1] (attention gate, att_unet.py:108-115)"""
+        _need_cuda(x, psi, out)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        L.check(self.lib.dl_gate_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(out), pstride(out), npix, x.shape[3], _stream()),
+                'dl_gate_forward')
+
+    def gate_backward(self, g, x, psi, dx, dpsi):
+        """dx = g * psi[..., :1] (dx may be None); dpsi[..., 0] = sum_c g * x, dpsi[..., 1:] = 0"""
+        _need_cuda(g, x, psi, dx, dpsi)
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        L.check(self.lib.dl_gate_backward(dl_dtype(x), _ptr(g), pstride(g), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(dx),
+                                          pstride(dx) if dx is not None else 8, _ptr(dpsi), pstride(dpsi), npix, x.shape[3], _stream()), 'dl_gate_backward')
+
     def copy_channels(self, src, s_c0, dst, d_c0, nch, accumulate=False):
         _need_cuda(src, dst)
         npix = src.shape[0] * src.shape[1] * src.shape[2]

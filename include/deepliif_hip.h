@@ -28,11 +28,12 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 104
+#define DL_VERSION 105
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
-enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3 };   /* LRELU slope 0.2 (networks.py:578,639) */
+enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3,       /* LRELU slope 0.2 (networks.py:578,639) */
+       DL_ACT_SIGMOID = 4 };   /* nn.Sigmoid of the attention gate (att_unet.py:100-104): elementwise entry points only (dl_act_forward / _backward) */
 enum { DL_PAD_ZERO = 0, DL_PAD_REFLECT = 1 };
 enum { DL_NORM_INSTANCE = 0, DL_NORM_BATCH = 1 };
 enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L1 = 3 };
@@ -240,6 +241,14 @@ int dl_act_forward(int act, int dtype, const void *x, int x_pstride, void *y, in
 /* dx = dy * act'(.) evaluated from the activation OUTPUT y (relu/lrelu: sign, tanh: 1-y^2) */
 int dl_act_backward(int act, int dtype, const void *dy, int dy_pstride, const void *y, int y_pstride,
                     void *dx, int dx_pstride, int64_t npix, int Cp, void *stream);
+/* Attention gate of the attention U-Net (att_unet.py:84-115, `unet_512_attention`, networks.py:189-190): Attention_block.forward returns
+ * x * psi with psi = Sigmoid(BatchNorm2d(Conv2d(F_int, 1, 1)(relu(W_g(g) + W_x(x))))) -- ONE channel broadcast over the C channels of x.
+ *   forward : out[p][c] = x[p][c] * psi[p][0]                                 (psi: NHWC with >= 8 padded channels, channel 0 real)
+ *   backward: dx[p][c] = g[p][c] * psi[p][0];  dpsi[p][0] = sum_c g[p][c] * x[p][c],  dpsi[p][1..7] = 0    (dx may be NULL) */
+int dl_gate_forward(int dtype, const void *x, int x_pstride, const void *psi, int psi_pstride, void *out, int out_pstride, int64_t npix, int Cp,
+                    void *stream);
+int dl_gate_backward(int dtype, const void *g, int g_pstride, const void *x, int x_pstride, const void *psi, int psi_pstride, void *dx,
+                     int dx_pstride, void *dpsi, int dpsi_pstride, int64_t npix, int Cp, void *stream);
 /* nn.Dropout(p) in training mode (networks.py:493-494, 604-605): y = x * keep / (1-p), keep = hash(seed, element) >= p.
  * Calling it again with the same seed on the gradient reproduces the same mask (backward); y may alias x. */
 int dl_dropout(int dtype, const void *x, int x_pstride, void *y, int y_pstride, int64_t npix, int Cp, float p, uint64_t seed, void *stream);

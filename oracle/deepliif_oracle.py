@@ -189,6 +189,45 @@ def unet_generator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str = 'ba
     return torch.tanh(y)
 
 
+ATT_DOWN = [(None, 64), (64, 128), (128, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512)]      # Conv1..Conv8 (ch_in of Conv1 = img_ch)
+ATT_UP = {8: (512, 512), 7: (512, 512), 6: (512, 512), 5: (512, 512), 4: (512, 256), 3: (256, 128), 2: (128, 64)}     # Up_k: ch_in (x2 when concatenated), ch_out
+ATT_GATE = {8: (512, 512), 7: (512, 512), 6: (512, 512), 5: (512, 512), 4: (256, 128), 3: (128, 64), 2: (64, 32)}     # Att_k: F_g = F_l, F_int
+
+
+def att_unet_generator(sd: Dict[str, torch.Tensor], x: torch.Tensor, update_running: bool = False) -> torch.Tensor:
+    """AttU_Net.forward, deepliif/models/att_unet.py:153-199 (`--net-gs unet_512_attention`, networks.py:189-190).
+
+    conv_block (:32-55): Conv2d(k4 s2 p1, bias) [+ BatchNorm2d] + LeakyReLU(0.2); Conv1 has no norm, Conv8 no norm and ReLU.
+    up_conv (:57-85): ConvTranspose2d(k4 s2 p1, no bias) + BatchNorm2d + ReLU; Up1 has a bias and ends in Tanh.
+    Attention_block (:88-115): psi = sigmoid(BN(conv1x1(relu(BN(conv1x1(g)) + BN(conv1x1(x)))))), one channel; returns x * psi.
+    BatchNorm2d is hard-wired (define_G forwards neither norm nor ngf) and evaluated on batch statistics like every norm of the path."""
+    def bn(key, t):
+        return _norm_from_sd(sd, key, t, 'batch', update_running)
+
+    xs = []
+    h = x
+    for k in range(1, 9):
+        pre = f'Conv{k}.conv'
+        h = F.conv2d(h, sd[f'{pre}.0.weight'], sd[f'{pre}.0.bias'], stride=2, padding=1)
+        if k == 1:
+            h = F.leaky_relu(h, 0.2)
+        elif k == 8:
+            h = torch.relu(h)
+        else:
+            h = F.leaky_relu(bn(f'{pre}.1', h), 0.2)
+        xs.append(h)
+    src = xs[7]
+    for k in range(8, 1, -1):
+        d = torch.relu(bn(f'Up{k}.up.1', F.conv_transpose2d(src, sd[f'Up{k}.up.0.weight'], None, stride=2, padding=1)))
+        skip = xs[k - 2]
+        a = f'Att{k}'
+        g1 = bn(f'{a}.W_g.1', F.conv2d(d, sd[f'{a}.W_g.0.weight'], sd[f'{a}.W_g.0.bias']))
+        x1 = bn(f'{a}.W_x.1', F.conv2d(skip, sd[f'{a}.W_x.0.weight'], sd[f'{a}.W_x.0.bias']))
+        psi = torch.sigmoid(bn(f'{a}.psi.1', F.conv2d(torch.relu(g1 + x1), sd[f'{a}.psi.0.weight'], sd[f'{a}.psi.0.bias'])))
+        src = torch.cat((skip * psi, d), dim=1)
+    return torch.tanh(F.conv_transpose2d(src, sd['Up1.up.0.weight'], sd['Up1.up.0.bias'], stride=2, padding=1))
+
+
 def nlayer_discriminator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str = 'batch', n_layers: int = 4,
                          update_running: bool = False) -> torch.Tensor:
     """NLayerDiscriminator.forward, networks.py:618-664: conv(k4,s2,p1,bias)+lrelu; (n_layers-1) x [conv k4 s2 + norm
@@ -211,6 +250,8 @@ def run_generator(arch: str, sd, x, norm='batch', padding_type='zero', update_ru
     table = {'unet_32': 5, 'unet_64': 6, 'unet_128': 7, 'unet_256': 8, 'unet_512': 9}
     if arch in table:
         return unet_generator(sd, x, norm, table[arch], update_running)
+    if arch == 'unet_512_attention':
+        return att_unet_generator(sd, x, update_running)
     raise NotImplementedError(arch)
 
 
@@ -312,6 +353,21 @@ def layer_table(arch: str, input_nc: int, output_nc: int = 3, nf: int = 64, norm
             idx += 3
         idx += 1
         out.append(('conv', f'model.{idx}', output_nc, nf, 7, True, False))
+        return out
+    if arch == 'unet_512_attention':
+        # att_unet.py:120-151: registration order Conv1..Conv8, Up8, Att8, Up7, Att7, ..., Up2, Att2, Up1; widths fixed; BatchNorm2d always
+        for k, (cin, cout) in enumerate(ATT_DOWN, start=1):
+            out.append(('conv', f'Conv{k}.conv.0', cout, input_nc if cin is None else cin, 4, True, False))
+            if 1 < k < 8:
+                out.append(('norm', f'Conv{k}.conv.1', cout))
+        for k in range(8, 1, -1):
+            cin, cout = ATT_UP[k]
+            out.append(('conv', f'Up{k}.up.0', cout, cin if k == 8 else 2 * cin, 4, False, True)); out.append(('norm', f'Up{k}.up.1', cout))
+            f, fi = ATT_GATE[k]
+            out.append(('conv', f'Att{k}.W_g.0', fi, f, 1, True, False)); out.append(('norm', f'Att{k}.W_g.1', fi))
+            out.append(('conv', f'Att{k}.W_x.0', fi, f, 1, True, False)); out.append(('norm', f'Att{k}.W_x.1', fi))
+            out.append(('conv', f'Att{k}.psi.0', 1, fi, 1, True, False)); out.append(('norm', f'Att{k}.psi.1', 1))
+        out.append(('conv', 'Up1.up.0', output_nc, 128, 4, True, True))
         return out
     if arch.startswith('unet_'):
         num_downs = {'unet_32': 5, 'unet_64': 6, 'unet_128': 7, 'unet_256': 8, 'unet_512': 9}[arch]

@@ -17,6 +17,8 @@ def _act(act, v):
         return torch.where(v > 0, v, 0.2 * v)
     if act == L.ACT_TANH:
         return torch.tanh(v)
+    if act == L.ACT_SIGMOID:
+        return torch.sigmoid(v)
     return v
 
 
@@ -27,6 +29,8 @@ def _act_grad_from_output(act, y):
         return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
     if act == L.ACT_TANH:
         return 1 - y * y
+    if act == L.ACT_SIGMOID:
+        return y * (1 - y)
     return torch.ones_like(y)
 
 
@@ -192,6 +196,18 @@ class FakeBackend:
     def act_backward(self, act, dy, y, dx):
         self._count('act_bwd')
         dx.copy_((dy.float() * _act_grad_from_output(act, y.float())).to(dx.dtype))
+
+    def gate_forward(self, x, psi, out):
+        self._count('gate')
+        out.copy_((x.float() * psi.float()[..., :1]).to(out.dtype))
+
+    def gate_backward(self, g, x, psi, dx, dpsi):
+        self._count('gate_bwd')
+        if dx is not None:
+            dx.copy_((g.float() * psi.float()[..., :1]).to(dx.dtype))
+        d = torch.zeros(dpsi.shape, dtype=torch.float32)
+        d[..., 0] = (g.float() * x.float()).sum(-1)
+        dpsi.copy_(d.to(dpsi.dtype))
 
     def dropout(self, x, y, p, seed):
         self._count('dropout')

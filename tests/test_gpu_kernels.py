@@ -849,3 +849,41 @@ def test_narrow_transposed_conv_as_one_gemm_plus_gather(n, h, w, cin, cout):
     E._CONVT4 = os.environ.get('DL_CONVT4', '1') != '0'
     ops._impl = None
     assert rel(outs[True], outs[False]) < 8e-3
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 9, 7, 64), (1, 16, 16, 512), (3, 5, 4, 8)])
+def test_attention_gate_and_sigmoid(shape, precname):
+    """dl_gate_forward / dl_gate_backward (x * psi, one-channel psi broadcast over the channels; att_unet.py:113-115) and the sigmoid entry of
+    dl_act_forward / dl_act_backward against the formula emulation"""
+    prec = Precision.get(precname)
+    x = rnd(shape, 1, prec).to(prec.dtype)
+    g = rnd(shape, 2, prec).to(prec.dtype)
+    psi = torch.zeros(shape[:3] + (8,))
+    psi[..., 0] = torch.sigmoid(rnd(shape[:3], 3, prec))
+    psi = (psi.to(prec.dtype).float() if prec.dtype == torch.bfloat16 else psi).to(prec.dtype)
+    fake, real = fake_backend.FakeBackend(), hip()
+    out_f, out_r = torch.empty(shape, dtype=prec.dtype), torch.empty(shape, dtype=prec.dtype, device=DEV)
+    fake.gate_forward(x, psi, out_f)
+    real.gate_forward(x.to(DEV), psi.to(DEV), out_r)
+    sync()
+    assert rel(out_r, out_f) < (1e-6 if precname == 'fp32' else 1e-2)
+    dx_f, dpsi_f = torch.empty(shape, dtype=prec.dtype), torch.empty(psi.shape, dtype=prec.dtype)
+    dx_r, dpsi_r = torch.empty(shape, dtype=prec.dtype, device=DEV), torch.full(psi.shape, 7.0, dtype=prec.dtype, device=DEV)
+    fake.gate_backward(g, x, psi, dx_f, dpsi_f)
+    real.gate_backward(g.to(DEV), x.to(DEV), psi.to(DEV), dx_r, dpsi_r)
+    sync()
+    assert rel(dx_r, dx_f) < (1e-6 if precname == 'fp32' else 1e-2)
+    assert rel(dpsi_r, dpsi_f) < (1e-5 if precname == 'fp32' else 1e-2) and float(dpsi_r[..., 1:].abs().max()) == 0.0
+    real.gate_backward(g.to(DEV), x.to(DEV), psi.to(DEV), None, dpsi_r)           # dx is optional
+    sync()
+    assert rel(dpsi_r, dpsi_f) < (1e-5 if precname == 'fp32' else 1e-2)
+    y_f, y_r = torch.empty(shape, dtype=prec.dtype), torch.empty(shape, dtype=prec.dtype, device=DEV)
+    fake.act_forward(L.ACT_SIGMOID, x, y_f)
+    real.act_forward(L.ACT_SIGMOID, x.to(DEV), y_r)
+    sync()
+    assert rel(y_r, y_f) < (2e-6 if precname == 'fp32' else 1e-2)
+    fake.act_backward(L.ACT_SIGMOID, g, y_f, dx_f)
+    real.act_backward(L.ACT_SIGMOID, g.to(DEV), y_f.to(DEV), dx_r)
+    sync()
+    assert rel(dx_r, dx_f) < (2e-6 if precname == 'fp32' else 1e-2)

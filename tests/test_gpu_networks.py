@@ -587,6 +587,110 @@ def _nlayer_units(net):
     return units
 
 
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('tag', ['in3_n1', 'in9_n2'])
+def test_attention_unet_against_reference_fixture(tag, precname):
+    """`--net-gs unet_512_attention` (AttU_Net, att_unet.py:117-199) on the GPU against the reference-generated fixture: outputs (training-mode
+    and inference-mode forward) at 1e-3 for the strict policy, BatchNorm running statistics, and the gradients at the bound the fixture
+    can carry (att_util.GRAD_TOL: the reference's own fp32 backward is 1e-2 ... 4e-2 from an fp64 evaluation at random initialisation)."""
+    import att_util
+    cin, sd, x, r = att_util.case(tag)
+    net = N.define_G(cin, 3, 64, 'unet_512_attention', 'batch', False, 'normal', 0.02, [0])
+    net.load_state_dict(sd, strict=True)
+    net.set_precision(precname).train()
+    prec = E.Precision.get(precname)
+    tape = E.Tape()
+    ctx = E.Ctx(prec, tape, training=True)
+    xa = E.to_engine(x.to(DEV), prec)
+    xa.needs_grad = True
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    ya = net.run(ctx, xa)
+    y = E.from_engine(ya)
+    ya.grad = E.to_engine(r.to(DEV), prec).t
+    tape.backward()
+    dx = E.from_engine(E.Act(xa.grad, xa.C))
+    running = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k}
+    net.eval()
+    net.batched_per_sample_norm = False          # the fixture's inference forward is ONE reference forward over the whole batch
+    with torch.no_grad():
+        y_eval = net(x.to(DEV))
+    if precname == 'fp32':
+        errs = att_util.check_against_fixture(tag, y.cpu(), dx.cpu(), {k: p.grad.cpu() for k, p in net.named_parameters()}, {k: v.cpu() for k, v in running.items()},
+                                              y_eval.cpu(), 1e-3)
+    else:
+        errs = {'y': att_util.rel(y.cpu()[:, :, ::8, ::8], att_util.Z[f'{tag}/y_strided']), 'y_eval': att_util.rel(y_eval.cpu()[:, :, ::8, ::8], att_util.Z[f'{tag}/y_eval_strided'])}
+        assert errs['y'] < 8e-2 and errs['y_eval'] < 8e-2, errs
+    for k, v in errs.items():
+        ERRLOG[f'att_unet/{tag}/{precname}/{k}'] = v
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('level,shape', [(2, (2, 16, 24)), (4, (2, 8, 8)), (8, (3, 2, 2))], ids=lambda v: str(v).replace(' ', ''))
+def test_teacher_forced_attention_block_gradients(level, shape, precname):
+    """One Attention_block (att_unet.py:88-115) at a fixed tolerance: the fp32 torch teacher's g, x and upstream gradient go in, the engine's
+    three 1x1 conv + BatchNorm units, relu(g1 + x1) (residual form of the norm kernel + input activation of the psi conv), the sigmoid and the
+    gate x * psi must give the block output, dg, dx and every parameter gradient: 1e-3 for the strict policy."""
+    import torch.nn.functional as F
+    f, fi = O.ATT_GATE[level]
+    n, hh, ww = shape
+    net = N.define_G(3, 3, 64, 'unet_512_attention', 'batch', False, 'normal', 0.02, [0])
+    net.set_precision(precname).train()
+    blk = getattr(net, f'Att{level}')
+    gen = torch.Generator().manual_seed(31 + level)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / m.weight.shape[1]) ** 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1 + 0.1 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    tsd = {k: v.detach().cpu().clone() for k, v in blk.state_dict().items()}
+    g = seeded_uniform((n, f, hh, ww), 41)
+    x = seeded_uniform((n, f, hh, ww), 42)
+    up = torch.randn((n, f, hh, ww), generator=torch.Generator().manual_seed(43))
+    names = [k for k in tsd if tsd[k].is_floating_point() and 'running' not in k]
+
+    def teacher(gg, xx, params):
+        def bn(pre, t):
+            m, v = t.mean((0, 2, 3), keepdim=True), t.var((0, 2, 3), unbiased=False, keepdim=True)
+            return (t - m) / torch.sqrt(v + 1e-5) * params[pre + '.weight'].view(1, -1, 1, 1) + params[pre + '.bias'].view(1, -1, 1, 1)
+        g1 = bn('W_g.1', F.conv2d(gg, params['W_g.0.weight'], params['W_g.0.bias']))
+        x1 = bn('W_x.1', F.conv2d(xx, params['W_x.0.weight'], params['W_x.0.bias']))
+        psi = torch.sigmoid(bn('psi.1', F.conv2d(torch.relu(g1 + x1), params['psi.0.weight'], params['psi.0.bias'])))
+        return xx * psi
+
+    tp = {k: tsd[k].clone().requires_grad_(True) for k in names}
+    gr, xr = g.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    out_t = teacher(gr, xr, tp)
+    ref = torch.autograd.grad(out_t, [gr, xr] + [tp[k] for k in names], up)
+    prec = E.Precision.get(precname)
+    a = net._layers()['atts'][level]
+    params = dict(blk.named_parameters())
+    for p in params.values():
+        p.grad = torch.zeros_like(p)
+    tape = E.Tape()
+    ctx = E.Ctx(prec, tape, training=True)
+    ga, xa = E.to_engine(g.to(DEV), prec), E.to_engine(x.to(DEV), prec)
+    ga.needs_grad = xa.needs_grad = True
+    g1 = E.norm_act(ctx, E.conv(ctx, ga, a['wg'][0], stats=True), a['wg'][1], L.ACT_NONE)
+    s_ = E.norm_act(ctx, E.conv(ctx, xa, a['wx'][0], stats=True), a['wx'][1], L.ACT_NONE, residual=g1)
+    p_ = E.act_op(ctx, E.norm_act(ctx, E.conv(ctx, s_, a['psi'][0], in_act=L.ACT_RELU, stats=True), a['psi'][1], L.ACT_NONE), L.ACT_SIGMOID)
+    oa = E.gate(ctx, xa, p_)
+    errs = {'y': rel(E.from_engine(oa), out_t.detach())}
+    oa.grad = E.to_engine(up.to(DEV), prec).t
+    tape.backward()
+    errs['dg'] = l2(E.from_engine(E.Act(ga.grad, ga.C)), ref[0])
+    errs['dx'] = l2(E.from_engine(E.Act(xa.grad, xa.C)), ref[1])
+    scale = max(float(t.abs().max()) for t in ref[2:])
+    errs['dparams'] = max(float((params[k].grad.cpu() - rp).abs().max()) / scale for k, rp in zip(names, ref[2:]))
+    tol = {'fp32': 1e-3, 'bf16': 1.5e-1}[precname]        # bf16: the ReLU mask of relu(g1 + x1) flips where |g1 + x1| is below the bf16 step (see the Resnet test)
+    for k, v in errs.items():
+        ERRLOG[f'teacher_forced/attention{level}/{precname}/{k}'] = v
+        assert v <= tol, (k, v)
+
+
 def _unet_chain(net):
     chain, blk = [], net.model
     while blk is not None:

@@ -178,3 +178,37 @@ def test_narrow_transposed_conv_route_on_the_emulated_backend():
         assert float((y.t[..., :cout].float() - ref).abs().max()) < 1e-2 and float(y.t[..., cout:].float().abs().max()) == 0.0
     finally:
         ops._impl = None
+
+
+@pytest.mark.parametrize('tag', ['in9_n2'])
+def test_attention_unet_on_the_emulated_backend(tag):
+    """`unet_512_attention` (att_unet.py:117-199): module tree / state_dict keys of the reference, the layer program, the zero-copy
+    [gated skip | up] concatenation, the gate and sigmoid backward, BatchNorm running-statistic updates -- against the reference-generated fixture
+    (tests/golden/att_unet.npz).  Gradient tolerance: see att_util.GRAD_TOL."""
+    import att_util
+    cin, sd, x, r = att_util.case(tag)
+    net = N.define_G(cin, 3, 64, 'unet_512_attention', 'batch', False, 'normal', 0.02, [])
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net.set_precision('fp32').train()
+    prec = E.Precision.get('fp32')
+    tape = E.Tape()
+    ctx = E.Ctx(prec, tape, training=True)
+    xa = E.to_engine(x, prec)
+    xa.needs_grad = True
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    ya = net.run(ctx, xa)
+    y = E.from_engine(ya)
+    ya.grad = E.to_engine(r, prec).t
+    tape.backward()
+    dx = E.from_engine(E.Act(xa.grad, xa.C))
+    running = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k}
+    net.eval()
+    for m in net.modules():                      # the reference's inference toggle (util/__init__.py:743-755)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.track_running_stats = False
+    net.batched_per_sample_norm = False          # the fixture's eval forward is ONE reference forward over the batch of 2 (statistics over the batch)
+    with torch.no_grad():
+        y_eval = net(x)
+    att_util.check_against_fixture(tag, y, dx, {k: p.grad for k, p in net.named_parameters()}, running, y_eval, 2e-4)

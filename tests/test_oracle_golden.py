@@ -269,3 +269,22 @@ def test_step_with_vgg_term_follows_reference():
         assert np.allclose(om.vgg_losses, VGG[f'step{s}/vgg'], rtol=tol)
         for i in range(2):
             assert rel_err(om.fake_B[i].detach()[:, :, ::2, ::2], VGG[f'step{s}/fake_B_{i + 1}']) < (RTOL if s == 0 else 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# attention U-Net (unet_512_attention, att_unet.py): oracle restatement vs the reference-generated fixture
+# ---------------------------------------------------------------------------------------------------------------------------
+import att_util  # noqa: E402
+
+
+@pytest.mark.parametrize('tag', att_util.TAGS)
+def test_attention_unet_forward_backward(tag):
+    cin, sd, x, r = att_util.case(tag)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+    xo = x.clone().requires_grad_(True)
+    y = O.att_unet_generator(sd, xo, update_running=True)
+    (y * r).sum().backward()
+    with torch.no_grad():
+        y_eval = O.att_unet_generator({k: v.detach() for k, v in sd.items()}, x)
+    running = {k: v for k, v in sd.items() if 'running_' in k}
+    att_util.check_against_fixture(tag, y.detach(), xo.grad, {k: p.grad for k, p in params.items()}, running, y_eval, RTOL)
