@@ -178,3 +178,36 @@ def test_inference_seam_returns_reference_names():
     # tile size != network resolution: PIL resampling on the host either side of the batched generators
     res32 = I.inference(img, 32, 2, None, opt=opt, nets=nets, mod_only=True)
     assert list(res32) == ['mod1', 'mod2'] and res32['mod1'].size == (150, 100)
+
+
+def test_slide_region_loop_on_the_gpu():
+    """deepliif_amd.wsi.infer_slide (reference: infer_results_for_wsi, models/__init__.py:663-727) with the real kernels and the GPU
+    post-processing: a 300 x 210 "slide" in regions of 128 (3 x 2 regions).  The schedule for 1, 2 and 4 ranks (whole regions per rank, ranks
+    run one after the other here) must give the canvases and the cell counts of the reference's sequential loop of stand-alone infer_modalities() calls."""
+    from PIL import Image
+    from deepliif_amd import inference as I
+    from deepliif_amd import wsi as W
+    torch.manual_seed(4)
+    opt = _opt(1)
+    opt.net_gs, opt.scale_size, opt.modalities_names, opt.background_colors = 'unet_64', 64, ['IHC', 'Marker'], [(201, 211, 208)]
+    nets = I.build_generators(opt, torch.device('cuda', 0), 'fp32')
+    slide = synth_image(300, 210, 23)
+    slide[:50] = 250
+    h, w = slide.shape[:2]
+    ref_canv, ref_total = {}, None
+    for (x, y, rw, rh) in W.region_grid(w, h, 128):
+        images, scoring = I.infer_modalities(Image.fromarray(slide[y:y + rh, x:x + rw]), 64, None, opt=opt, nets=nets)
+        ref_total = W.add_scoring(ref_total, scoring)
+        W.paste_into(ref_canv, (x, y, rw, rh), images, w, h)
+    ref_total = W.finish_scoring(ref_total)
+    assert {'Marker', 'Seg', 'SegOverlaid', 'SegRefined'} <= set(ref_canv) or {'mod1-Marker', 'Seg', 'SegOverlaid', 'SegRefined'} <= set(ref_canv)
+    for world in (1, 2, 4):
+        canv, total = {}, None
+        for rank in range(world):
+            plan, part = W.infer_slide(lambda x, y, rw, rh: slide[y:y + rh, x:x + rw], w, h, 64, None, nets=nets, opt=opt, region_size=128, rank=rank, world=world,
+                                       on_region=lambda xywh, images, scoring: W.paste_into(canv, xywh, images, w, h))
+            assert plan.mode == 'regions' and len(plan.regions) == 6
+            total = W.add_scoring(total, part)
+        assert W.finish_scoring(total) == ref_total
+        for k in ref_canv:
+            assert np.array_equal(canv[k], ref_canv[k]), (world, k)
