@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ('phase_tap_begin', i32 * (MAX_PHASES + 1)), ('phase_kbase', i32 * MAX_PHASES),
                 ('tap_dh', C.c_int8 * MAX_TAPS), ('tap_dw', C.c_int8 * MAX_TAPS),
                 ('pad_mode', i32), ('w_kstride', i32), ('w_rows', i32), ('act', i32),
-                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32), ('ci_real', i32)]
+                ('in_dtype', i32), ('out_dtype', i32), ('prec', i32), ('splitk', i32), ('in_act', i32), ('bias_n', i32), ('raw_out', i32), ('ci_real', i32), ('in_split', i32)]
 
 
 
@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
                 ('Hq', i32), ('Wq', i32), ('CBp', i32), ('q_pstride', i32),
                 ('KH', i32), ('KW', i32), ('step', i32), ('pad', i32), ('pad_mode', i32),
                 ('CA', i32), ('CB', i32), ('dtype', i32), ('prec', i32), ('splitk', i32), ('accumulate', i32),
-                ('q_act', i32), ('p_act', i32), ('pad_w', i32), ('stack_kw', i32)]
+                ('q_act', i32), ('p_act', i32), ('pad_w', i32), ('stack_kw', i32), ('p_split', i32), ('q_split', i32)]
 
 
 class PackDesc(C.Structure):
@@ -79,8 +79,8 @@ SIGNATURES = {
     'dl_pack_batch_blocks': (_i, [_vp, _i, _vp]),
     'dl_pack_weights_batch': (_i, [_vp, _vp, _i, _vp]),
     'dl_norm_ws_floats': (C.c_size_t, [C.POINTER(NormDesc)]),
-    'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'dl_norm_forward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'dl_norm_backward': (_i, [C.POINTER(NormDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'dl_act_forward': (_i, [_i, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_act_backward': (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     'dl_dropout': (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _f, C.c_uint64, _vp]),
@@ -130,8 +130,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 105:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 105 (stale build)')
+    if lib.dl_version() != 106:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 106 (stale build)')
     _lib = lib
     return lib
 

@@ -84,6 +84,21 @@ template <> struct Vec8<bf16_t> {
         *reinterpret_cast<u32x4_t *>(p) = a;
     }
 };
+// SPLIT COPY of 8 fp32 values (strict policy, see conv_x3.h / wgrad_x3.h): the same 32 bytes an fp32 group of 8 channels occupies, holding
+// [8 x bf16 hi | 8 x bf16 lo] with hi = bf16(x), lo = bf16(x - hi) -- exactly what the strict kernels would compute from the fp32 values while
+// staging; a producer that writes it once saves every consumer (forward conv, data gradient, weight gradient: 9 taps each) the conversion.
+__device__ __forceinline__ void store_split8(float *p, const float (&v)[8]) {
+    u32x4_t hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t h = pack2_bf16(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+    *reinterpret_cast<u32x4_t *>(p) = hi;
+    *reinterpret_cast<u32x4_t *>(p + 4) = lo;
+}
+
 template <typename T> __device__ __forceinline__ float load1(const T *p);
 template <> __device__ __forceinline__ float load1<float>(const float *p) { return *p; }
 template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }

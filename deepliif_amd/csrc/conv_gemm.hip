@@ -27,6 +27,7 @@ struct ConvArgs {
     int phase_tap_begin[DL_MAX_PHASES + 1];
     int phase_kbase[DL_MAX_PHASES];
     int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
+    int in_split;           // strict kernels: the input is the producer-written split copy ([8 hi | 8 lo] per 8 channels): no in-kernel split
     int epi_old;            // DL_OLD_EPILOGUE=1: per-fragment stores instead of the LDS-transposed whole-row stores (A/B switch)
     int tiles_m, tiles_n, Mtot;
     int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
@@ -1745,6 +1746,9 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
     for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
     a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
+    a.in_split = d->in_split;
+    if (d->in_split && !(d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && d->in_act == DL_ACT_NONE && x3_glds_applies(d)))
+        DL_FAIL("dl_conv_forward: in_split needs the strict policy (fp32 + BF16X3) on the direct-to-LDS kernels and no input activation");
     static const bool epi_old = getenv("DL_OLD_EPILOGUE") != nullptr;
     a.epi_old = epi_old ? 1 : 0;
     a.Mtot = d->N * d->Hq * d->Wq;

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_x3_kernel(const ConvArgs a)
     // pixel -- channels 8g..8g+7 in fp32 -- becomes [8 hi | 8 lo] bf16, i.e. exactly the two 16-byte fragments a consumer lane needs, so the
     // fragment reads below need no VALU at all and every element is split once per workgroup instead of once per consuming wave (4x).
     auto convert_x = [&](auto BUF, auto H) __attribute__((always_inline)) {
-        if (ABL >= 2 || !CVT) return;
+        if (ABL >= 2 || !CVT || a.in_split) return;          // in_split: the producer wrote [8 hi | 8 lo] per channel group -- what this would leave in LDS
         constexpr int buf = decltype(BUF)::value, h = decltype(H)::value;
         char *base = smem_raw + (buf * 4 + S_X + h) * HALFB + wave * (16 * ROWB);
         f32x4_t v[2];
@@ -670,11 +670,19 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_x3_kernel(const C
             wh[i] = *reinterpret_cast<const bf16x8_t *>(Ws + i * 16 * ROWB + foffw[0]);
             wl[i] = *reinterpret_cast<const bf16x8_t *>(Ws + i * 16 * ROWB + foffw[1]);
         }
+        if (a.in_split) {            // producer-written split copy: chunk 2*fg holds the 8 hi values, chunk 2*fg + 1 the 8 lo values of this lane's K slice
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const f32x4_t r0 = *reinterpret_cast<const f32x4_t *>(Xs + j * 16 * ROWB + foffx[0]);
-            const f32x4_t r1 = *reinterpret_cast<const f32x4_t *>(Xs + j * 16 * ROWB + foffx[1]);
-            x3_split8<IN_ACT>(r0, r1, xh[j], xl[j]);
+            for (int j = 0; j < FM; ++j) {
+                xh[j] = *reinterpret_cast<const bf16x8_t *>(Xs + j * 16 * ROWB + foffx[0]);
+                xl[j] = *reinterpret_cast<const bf16x8_t *>(Xs + j * 16 * ROWB + foffx[1]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const f32x4_t r0 = *reinterpret_cast<const f32x4_t *>(Xs + j * 16 * ROWB + foffx[0]);
+                const f32x4_t r1 = *reinterpret_cast<const f32x4_t *>(Xs + j * 16 * ROWB + foffx[1]);
+                x3_split8<IN_ACT>(r0, r1, xh[j], xl[j]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < FN; ++i)
@@ -754,6 +762,7 @@ static int dispatch_tile_x3(const ConvArgs &a, hipStream_t stream) {
         if (abl && abl[0] == '2') return launch_conv_8ph_x3<DL_ACT_NONE, 2>(a, stream);
         if (abl && abl[0] == '3') return launch_conv_8ph_x3<DL_ACT_NONE, 3>(a, stream);
         if (abl && abl[0] == '4') return launch_conv_8ph_x3<DL_ACT_NONE, 4>(a, stream);
+        if (a.in_split) return launch_conv_8ph_x3<DL_ACT_NONE, 0>(a, stream);      // (the timing variants below re-split their input)
         static const char *var = getenv("DL_X3_VAR");
         if (var && var[0] == '1') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 1>(a, stream);
         if (var && var[0] == '2') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 2>(a, stream);

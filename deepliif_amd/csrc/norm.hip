@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) norm_fwd_finalize_kernel(const float *sum
 // registers) and walks down the pixels; grid = (pixel blocks, N)
 template <typename T, int ACT>
 __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, const float *scale, const float *shift, const T *res, int r_ps,
-                                                         T *z, int z_ps, NormGeom g) {
+                                                         T *z, int z_ps, NormGeom g, float *split, int split_ps) {
     constexpr int act = ACT;
     const int cvec = g.Cp / 8;
     const int n = blockIdx.y;
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
                     for (int k = 0; k < 8; ++k) v[u][k] += r[u][k];
                 }
                 Vec8<T>::store(z + ((size_t)n * g.HW + p + u * pstep) * z_ps + c0, v[u]);
+                if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, v[u]);
             }
         }
         for (; p < g.HW; p += pstep) {
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
             Vec8<T>::store(z + pix * z_ps + c0, v);
+            if (split) store_split8(split + pix * split_ps + c0, v);
         }
     }
 }
@@ -284,7 +286,7 @@ template <typename T, int ACT>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz_ps, const T *y, int y_ps, const float *gamma,
                                                              const float *mean, const float *rstd, const float *scale, const float *shift,
                                                              const float *c1, const float *c2, T *dy, int dy_ps, NormGeom g,
-                                                             float *bpart) {
+                                                             float *bpart, float *split, int split_ps) {
     constexpr int act = ACT;
     __shared__ float bred[256 * 9];
     const int cvec = g.Cp / 8;
@@ -335,6 +337,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                     bs[k] += o[k];
                 }
                 Vec8<T>::store(dy + ((size_t)n * g.HW + p + u * pstep) * dy_ps + c0, o);
+                if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, o);
             }
         }
         for (; p < g.HW; p += pstep) {
@@ -354,6 +357,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                 bs[k] += o[k];
             }
             Vec8<T>::store(dy + pix * dy_ps + c0, o);
+            if (split) store_split8(split + pix * split_ps + c0, o);
         }
         }
         if (bpart) {       // per-block channel sums of dy: the gradient of the conv bias in front of this norm
@@ -435,9 +439,10 @@ static int check_desc(const dl_norm_desc *d, const char *who) {
 
 extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, const float *beta,
                                float *running_mean, float *running_var, float *mean, float *rstd, float *scale, float *shift,
-                               const void *residual, void *z, float *ws, void *stream_) {
+                               const void *residual, void *z, float *ws, void *z_split, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_forward")) return -1;
+    if (z_split && d->dtype != DL_F32) DL_FAIL("dl_norm_forward: the split copy belongs to the fp32 (strict) policy");
     if (!y || !z || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_forward: null argument");
     const NormGeom g = make_geom_fwd(d);
     const int pblocks = g.N * g.nchunks;
@@ -464,9 +469,9 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
     }
     const dim3 blocks = apply_grid(g);
 #define DL_LAUNCH_APPLY_F32(A) hipLaunchKernelGGL((norm_apply_kernel<float, A>), blocks, dim3(256), 0, stream, (const float *)y, d->y_pstride, \
-                                                  scale, shift, (const float *)residual, d->r_pstride, (float *)z, d->z_pstride, g)
+                                                  scale, shift, (const float *)residual, d->r_pstride, (float *)z, d->z_pstride, g, (float *)z_split, d->Cp)
 #define DL_LAUNCH_APPLY_BF16(A) hipLaunchKernelGGL((norm_apply_kernel<bf16_t, A>), blocks, dim3(256), 0, stream, (const bf16_t *)y, d->y_pstride, \
-                                                   scale, shift, (const bf16_t *)residual, d->r_pstride, (bf16_t *)z, d->z_pstride, g)
+                                                   scale, shift, (const bf16_t *)residual, d->r_pstride, (bf16_t *)z, d->z_pstride, g, (float *)nullptr, 0)
     if (d->dtype == DL_F32) { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_APPLY_F32) }
     else { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_APPLY_BF16) }
     DL_CHECK_LAUNCH("dl_norm_forward(apply)");
@@ -475,9 +480,11 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
 
 extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const void *y, const float *gamma,
                                 const float *mean, const float *rstd, const float *scale, const float *shift,
-                                void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *stream_) {
+                                void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *dy_split,
+                                void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_backward")) return -1;
+    if (dy_split && d->dtype != DL_F32) DL_FAIL("dl_norm_backward: the split copy belongs to the fp32 (strict) policy");
     if (!dz || !y || !dy || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
     // ext_nchunks > 0: the producer of dz (dl_conv_forward_bnstats) already left the [N][ext_nchunks][2][Cp] partials at the start of ws
     const bool ext = d->ext_nchunks > 0;
@@ -510,9 +517,11 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
     float *bpart = dy_chansum ? c2 + (size_t)g.N * g.Cp : nullptr;
     const dim3 blocks = apply_grid(g);
 #define DL_LAUNCH_BAPPLY_F32(A) hipLaunchKernelGGL((norm_bwd_apply_kernel<float, A>), blocks, dim3(256), 0, stream, (const float *)dz, dz_ps, \
-                                                   (const float *)y, d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (float *)dy, dy_ps, g, bpart)
+                                                   (const float *)y, d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (float *)dy, dy_ps, g, bpart, \
+                                                   (float *)dy_split, d->Cp)
 #define DL_LAUNCH_BAPPLY_BF16(A) hipLaunchKernelGGL((norm_bwd_apply_kernel<bf16_t, A>), blocks, dim3(256), 0, stream, (const bf16_t *)dz, dz_ps, \
-                                                    (const bf16_t *)y, d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, bpart)
+                                                    (const bf16_t *)y, d->y_pstride, gamma, mean, rstd, scale, shift, c1, c2, (bf16_t *)dy, dy_ps, g, bpart, \
+                                                    (float *)nullptr, 0)
     if (d->dtype == DL_F32) { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BAPPLY_F32) }
     else { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BAPPLY_BF16) }
     DL_CHECK_LAUNCH("dl_norm_backward(apply)");

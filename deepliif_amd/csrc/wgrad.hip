@@ -27,6 +27,7 @@ struct WgradArgs {
     int dn, dh, dw;     // 32 pixels in mixed radix (Hp*Wp, Wp, 1)
     int p_act, q_act;
     int xcd_group;      // 1: tiles of one pixel range share an XCD (see the kernels)
+    int p_split, q_split;   // strict kernels (wgrad_x3.h): the operand is the producer-written split copy
 };
 
 __device__ __forceinline__ int reflect_idx_w(int i, int n) {
@@ -754,6 +755,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     const int hw = d->Hp * d->Wp;
     a.dn = 32 / hw; a.dh = (32 % hw) / d->Wp; a.dw = (32 % hw) % d->Wp;
     a.p_act = d->p_act; a.q_act = d->q_act;
+    a.p_split = d->p_split; a.q_split = d->q_split;
     static const char *xg_env = getenv("DL_WGRAD_XCDGROUP");          // A/B switch: "0" keeps the plain 2-D block order
     a.xcd_group = (xg_env && xg_env[0] == '0') ? 0 : 1;
 
@@ -776,7 +778,9 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     // same box, ResnetBlock shape, kernel + reduce: 627 us (604 without s_setprio) vs 577 us for the one-barrier kernel; PMC: the stagger
     // raises the time waves spend parked at barriers / waitcnt (43 % vs 28 % of wave cycles) more than it overlaps (MFMA-busy 31.6 % vs 35.6 %).
     static const char *w3 = getenv("DL_WGRAD_X3");
-    if (fast3 && (d->CAp % 256) == 0 && w3 && (w3[0] == '2' || w3[0] == '3')) rc = (w3[0] == '3') ? launch_wgrad_4ph_x3<1>(a, stream) : launch_wgrad_4ph_x3<0>(a, stream);
+    if ((d->p_split || d->q_split) && !(fast3 && (d->CAp % 128) == 0 && (!d->p_split || d->p_act == DL_ACT_NONE) && (!d->q_split || d->q_act == DL_ACT_NONE)))
+        DL_FAIL("dl_conv_wgrad: split-copy operands need the strict direct-to-LDS kernel (fp32 + BF16X3, zero padding, CAp %% 128 == 0, J >= 256) and no staged activation on them");
+    if (fast3 && (d->CAp % 256) == 0 && w3 && (w3[0] == '2' || w3[0] == '3') && !d->p_split && !d->q_split) rc = (w3[0] == '3') ? launch_wgrad_4ph_x3<1>(a, stream) : launch_wgrad_4ph_x3<0>(a, stream);
     else if (fast3 && (d->CAp % 256) == 0) rc = launch_wgrad_glds_x3<256>(a, stream);
     else if (fast3 && (d->CAp % 128) == 0) rc = launch_wgrad_glds_x3<128>(a, stream);
     else if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') rc = launch_wgrad_8ph(a, stream);

@@ -84,20 +84,41 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
     const float *zero = reinterpret_cast<const float *>(g_wzero_page);
 
     // ---- P: instruction i of this wave fills tile rows (wave*A_INS + i)*A_RPI + lane / A_LPR; this lane owns channels 4*(lane % A_LPR) .. +3
+    // A SPLIT-COPY operand (a.p_split / a.q_split: the producer already wrote [8 hi | 8 lo] per group of 8 channels, same addressing as the
+    // fp32 tensor) is fetched straight into the plane layout the in-LDS conversion would have produced: LDS position q of the hi (lo) plane
+    // of pixel row r holds the hi (lo) half of channel group g = 2 * ((q >> 1) ^ wswz(r)) + (q & 1), i.e. source floats 8g (+4 for lo); the
+    // permutation depends on the row through wswz, so it is one offset per DMA instruction.
     const int a_rsub = lane / A_LPR, a_c = lane % A_LPR;
     const float *p_src[A_INS];
 #pragma unroll
     for (int i = 0; i < A_INS; ++i) {
         const int row = (wave * A_INS + i) * A_RPI + a_rsub;
-        p_src[i] = P + (size_t)(p_begin + row) * a.p_pstride + ta * BA + a_c * 4;
+        int col = a_c * 4;
+        if (a.p_split) {
+            const int plane = a_c / (A_LPR / 2), q = a_c % (A_LPR / 2);
+            col = 8 * (2 * ((q >> 1) ^ wswz(row)) + (q & 1)) + 4 * plane;
+        }
+        p_src[i] = P + (size_t)(p_begin + row) * a.p_pstride + ta * BA + col;
     }
-    // ---- Q: instruction i fills tile row wave*J_INS + i; this lane owns columns j0 .. j0+3 = one (tap, 4 channels) for every row
-    const int j0 = tj * BJ + lane * 4;
-    const int q_tap = j0 >> a.log2CB;
-    const int q_cb = j0 & (a.CBp - 1);
-    const bool q_tap_ok = q_tap < a.KH * a.KW;
-    const int q_kh = q_tap_ok ? q_tap / a.KW : 0;
-    const int q_kw = q_tap_ok ? q_tap - q_kh * a.KW : 0;
+    // ---- Q: instruction i fills tile row wave*J_INS + i; this lane owns 4 columns (fp32) or one hi / lo half of 8 columns (split copy) of
+    // ONE tap for that row
+    int q_cb[J_INS], q_kh[J_INS], q_kw[J_INS];
+    bool q_tap_ok[J_INS];
+#pragma unroll
+    for (int i = 0; i < J_INS; ++i) {
+        int jc = lane * 4, extra = 0;
+        if (a.q_split) {
+            const int plane = lane >> 5, q = lane & 31;
+            jc = 8 * (2 * ((q >> 1) ^ wswz(wave * J_INS + i)) + (q & 1));
+            extra = 4 * plane;
+        }
+        const int j0 = tj * BJ + jc;
+        const int tap = j0 >> a.log2CB;
+        q_cb[i] = (j0 & (a.CBp - 1)) + extra;
+        q_tap_ok[i] = tap < a.KH * a.KW;
+        q_kh[i] = q_tap_ok[i] ? tap / a.KW : 0;
+        q_kw[i] = q_tap_ok[i] ? tap - q_kh[i] * a.KW : 0;
+    }
     int q_n[J_INS], q_h[J_INS], q_w[J_INS];
     const int HWp = a.Hp * a.Wp;
 #pragma unroll
@@ -122,9 +143,9 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < J_INS; ++i) {
             const int row = wave * J_INS + i;
-            const int h = q_h[i] * a.step - a.pad + q_kh, w = q_w[i] * a.step - a.pad_w + q_kw;
-            const bool ok = q_tap_ok && (pbase + row < p_end) && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
-            const float *src = ok ? Q + ((size_t)(q_n[i] * a.Hq + h) * a.Wq + w) * a.q_pstride + q_cb : zero;
+            const int h = q_h[i] * a.step - a.pad + q_kh[i], w = q_w[i] * a.step - a.pad_w + q_kw[i];
+            const bool ok = q_tap_ok[i] && (pbase + row < p_end) && ((unsigned)h < (unsigned)a.Hq) && ((unsigned)w < (unsigned)a.Wq);
+            const float *src = ok ? Q + ((size_t)(q_n[i] * a.Hq + h) * a.Wq + w) * a.q_pstride + q_cb[i] : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(base + TAB + row * ROWJ), 16, 0, 0);
             // advance this row's pixel by 32 (mixed radix add, single carries)
@@ -142,10 +163,15 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
     auto convert_tile = [&](int buf) {
         char *base = smem_raw + buf * BUFB;
         f32x4_t ra[A_INS], rq[J_INS];
+        if (!a.p_split) {
 #pragma unroll
-        for (int i = 0; i < A_INS; ++i) ra[i] = *reinterpret_cast<const f32x4_t *>(base + (wave * A_INS + i) * 1024 + lane * 16);
+            for (int i = 0; i < A_INS; ++i) ra[i] = *reinterpret_cast<const f32x4_t *>(base + (wave * A_INS + i) * 1024 + lane * 16);
+        }
+        if (!a.q_split) {
 #pragma unroll
-        for (int i = 0; i < J_INS; ++i) rq[i] = *reinterpret_cast<const f32x4_t *>(base + TAB + (wave * J_INS + i) * ROWJ + lane * 16);
+            for (int i = 0; i < J_INS; ++i) rq[i] = *reinterpret_cast<const f32x4_t *>(base + TAB + (wave * J_INS + i) * ROWJ + lane * 16);
+        }
+        if (!a.p_split) {
 #pragma unroll
         for (int i = 0; i < A_INS; ++i) {
             const int row = (wave * A_INS + i) * A_RPI + a_rsub;
@@ -155,6 +181,8 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
             *reinterpret_cast<u32x2_t *>(dst) = hi;
             *reinterpret_cast<u32x2_t *>(dst + ROWA / 2) = lo;
         }
+        }
+        if (!a.q_split) {
 #pragma unroll
         for (int i = 0; i < J_INS; ++i) {
             const int row = wave * J_INS + i;
@@ -163,6 +191,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
             char *dst = base + TAB + row * ROWJ + (((lane >> 2) ^ wswz(row)) << 5) + (lane & 3) * 8;
             *reinterpret_cast<u32x2_t *>(dst) = hi;
             *reinterpret_cast<u32x2_t *>(dst + ROWJ / 2) = lo;
+        }
         }
     };
 

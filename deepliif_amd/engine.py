@@ -40,7 +40,7 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only', 'split', 'grad_split')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -53,6 +53,10 @@ class Act:
         self.norm_only = False                            # conv output handed straight to ONE norm_act and to nothing else (conv(stats=True))
         self.bn_ctx = None                                # norm_act output z = act(norm(y)): (y tensor, statistics, act) for a consumer conv's backward
         self.grad_stats = None                            # (chunks, workspace token): the ONLY contribution to .grad also left the norm-backward reductions
+        # strict policy: SPLIT COPIES ([8 bf16 hi | 8 bf16 lo] per group of 8 channels, same shape / bytes as the fp32 tensor) written by the
+        # norm kernel that produced the tensor, so that the convolutions consuming it skip their in-kernel hi / lo split (csrc/conv_x3.h)
+        self.split: Optional[torch.Tensor] = None         # of .t
+        self.grad_split: Optional[torch.Tensor] = None    # of .grad, valid only while .grad is that ONE contribution
 
     @property
     def shape(self):
@@ -68,6 +72,7 @@ class Act:
         else:
             ops.impl().axpby(1.0, self.grad, 1.0, g, self.grad)
             self.grad_stats = None          # reductions fused into the first contribution's producer no longer describe the sum
+            self.grad_split = None          # ... nor does its split copy
 
 
 class Tape:
@@ -299,8 +304,10 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             xin = empty_like_act(x.t)
             be.act_forward(in_act, x.t, xin)
             fwd_in_act = L.ACT_NONE
-        nch = be.conv_forward(layer.packed_fwd, xin, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act, fwd_in_act,
-                              ctx.prec.prec, want_stats=stats and act == L.ACT_NONE)
+        x_split = x.split is not None and fwd_in_act == L.ACT_NONE and xin is x.t and getattr(be, 'supports_split', False) and \
+            be.conv_takes_split(x.t, ctx.prec.prec, fwd_in_act, spec.pad_mode)
+        nch = be.conv_forward(layer.packed_fwd, x.split if x_split else xin, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act,
+                              fwd_in_act, ctx.prec.prec, want_stats=stats and act == L.ACT_NONE, **({'in_split': True} if x_split else {}))
         del xin
     y = Act(out, spec.cout, x_needs or w_needs)
     y.norm_only = bool(stats)       # the caller's promise (see the docstring); norm_act's bias-gradient fusion relies on it
@@ -323,13 +330,15 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
 
     def backward_body():
         g = y.grad
-        y.grad = None
+        gs = y.grad_split if (y.norm_only and getattr(be, 'supports_split', False)) else None       # split copy of g (norm_act's backward wrote it)
+        y.grad, y.grad_split = None, None
         if g is None:
             return
         if act != L.ACT_NONE:                       # epilogue activation: derivative from the saved output
             gp = empty_like_act(g)
             be.act_backward(act, g, y.t, gp)
-            g = gp
+            g, gs = gp, None
+        xs = x.split if (x.split is not None and in_act == L.ACT_NONE and getattr(be, 'supports_split', False)) else None
         if w_needs:
             if layer.narrow and spec.pad_mode == L.PAD_ZERO and getattr(be, 'wgrad_c4_applies', None) is not None and \
                     be.wgrad_c4_applies(g, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec):
@@ -342,9 +351,13 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 be.conv_wgrad(D, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec, True, stack_kw=spec.k)
                 del D
             elif spec.kind == 'conv':
-                be.conv_wgrad(g, x.t, layer.weight.grad, spec.k, spec.stride, spec.pad, spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True)
+                sp = (gs is not None or xs is not None) and be.wgrad_takes_split(g, x.t, layer.weight.grad, spec.k, spec.pad_mode, ctx.prec.prec)
+                be.conv_wgrad(gs if (sp and gs is not None) else g, xs if (sp and xs is not None) else x.t, layer.weight.grad, spec.k, spec.stride, spec.pad,
+                              spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True, **({'p_split': gs is not None, 'q_split': xs is not None} if sp else {}))
             else:
-                be.conv_wgrad(x.t, g, layer.weight.grad, spec.k, spec.stride, spec.pad, L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True)
+                sp = (gs is not None or xs is not None) and be.wgrad_takes_split(x.t, g, layer.weight.grad, spec.k, L.PAD_ZERO, ctx.prec.prec)
+                be.conv_wgrad(xs if (sp and xs is not None) else x.t, gs if (sp and gs is not None) else g, layer.weight.grad, spec.k, spec.stride, spec.pad,
+                              L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True, **({'p_split': xs is not None, 'q_split': gs is not None} if sp else {}))
             if layer.bias is not None and layer.bias.requires_grad and not y.bias_done:
                 be.channel_sum(g, spec.cout, layer.bias.grad, True)
         if x_needs and spec.kind == 'conv' and spec.pad_mode == L.PAD_REFLECT:
@@ -370,7 +383,9 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             # data gradient also produces that norm's backward reductions (one pass over y' and dx saved); valid only while dx stays
             # the sole contribution (Act.add_grad drops it otherwise)
             fuse = x.bn_ctx if (x.grad is None and in_act == L.ACT_NONE) else None
-            nch = be.conv_forward(layer.packed_dgrad, g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, bn=fuse)
+            g_split = gs is not None and be.conv_takes_split(g, ctx.prec.prec, L.ACT_NONE, L.PAD_ZERO)
+            nch = be.conv_forward(layer.packed_dgrad, gs if g_split else g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, bn=fuse,
+                                  **({'in_split': True} if g_split else {}))
             if in_act != L.ACT_NONE:                # relu / lrelu keep the sign: mask from the un-activated input
                 be.act_backward(in_act, dx, x.t, dx)
             x.add_grad(dx)
@@ -385,6 +400,7 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
              out: Optional[torch.Tensor] = None) -> Act:
     """z = act(norm(y)) (+ residual).  norm None = identity norm (norm='none')."""
     be = ops.impl()
+    own_out = out is None
     if out is None:
         out = empty_like_act(y.t)
     needs = ctx.tape is not None and (y.needs_grad or (residual is not None and residual.needs_grad))
@@ -419,9 +435,15 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
         rm, rv, momentum = m.running_mean, m.running_var, (m.momentum if m.momentum is not None else 0.1)
         m.num_batches_tracked += 1
     ext = y.stats[0] if (y.stats is not None and y.stats[1] == be.norm_ws_token()) else 0
+    # strict policy, stand-alone output: the kernel also writes the split copy its consumers (conv forward / weight gradient) read instead
+    # of splitting the fp32 values themselves for every tap (one extra 4-byte store per element here; csrc/conv_x3.h)
+    zs = None
+    if own_out and ctx.prec.prec == L.PREC_BF16X3 and out.dtype == torch.float32 and getattr(be, 'supports_split', False):
+        zs = torch.empty(out.shape, dtype=torch.float32, device=out.device)
     stats = be.norm_forward(y.t, out, norm.C, scope, act, gamma, beta, rm, rv, momentum, residual.t if residual is not None else None,
-                            ext_nchunks=ext)
+                            ext_nchunks=ext, **({'z_split': zs} if zs is not None else {}))
     z = Act(out, y.C, needs)
+    z.split = zs
     if not needs:
         return z
     if residual is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and y.t.dtype == torch.bfloat16 and y.needs_grad:
@@ -453,12 +475,18 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
             # dy is y's ONLY gradient contribution: promised by the producer (conv(stats=True) -> norm_only), not inferred from the moment's
             # y.grad (a consumer recorded EARLIER on the tape would contribute later and its share of the bias gradient would be lost)
             fuse_bias = y.bias_grad is not None and y.norm_only and y.grad is None and not y.bias_done
+            # dy is the ONLY gradient the conv output y ever receives (norm_only): its producer's data / weight gradient kernels can read a split copy
+            dys = None
+            if y.norm_only and y.needs_grad and y.grad is None and ctx.prec.prec == L.PREC_BF16X3 and dy.dtype == torch.float32 and \
+                    getattr(be, 'supports_split', False):
+                dys = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
             be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None,
-                             y.bias_grad if fuse_bias else None, ext_nchunks=ext_b)
+                             y.bias_grad if fuse_bias else None, ext_nchunks=ext_b, **({'dy_split': dys} if dys is not None else {}))
             if fuse_bias:
                 y.bias_done = True
             if y.needs_grad:
                 y.add_grad(dy)
+                y.grad_split = dys
 
     ctx.tape.record(backward)
     return z

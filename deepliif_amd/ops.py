@@ -176,7 +176,7 @@ class HipBackend:
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
                      act: int, in_act: int, prec: int, splitk: Optional[int] = None, raw_out: bool = False, want_stats: bool = False,
-                     bn=None):
+                     bn=None, in_split: bool = False):
         """raw_out: `out` is an fp32 [N,Ho,Wo,Co] tensor that receives the raw accumulators (narrow-Cout path).
         want_stats: ask the kernel to also leave the per-(image, channel) partial sums of `out` at the start of the shared
         normalisation workspace; returns the chunk count to hand to norm_forward(ext_nchunks=...) -- 0 when the dispatch for
@@ -203,6 +203,7 @@ class HipBackend:
             splitk = choose_splitk(plan, n, hq, wq, cop)
         d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, pstride(out), hq, wq, dl_dtype(x), prec, act, in_act,
                            0 if bias is None else bias.numel(), splitk)
+        d.in_split = 1 if in_split else 0           # x is the producer-written split copy of the fp32 activations (norm_forward(z_split=...))
         assert dl_dtype(out) == d.in_dtype
         if auto_split and splitk > 1 and plan.cc_real <= 4:
             # the 4-channel patch kernel (csrc/conv_c4.h) has no split-K form and needs none (its K is 7 steps): prefer it when it applies
@@ -242,7 +243,8 @@ class HipBackend:
 
     # ---- weight gradient
     def conv_wgrad(self, P: torch.Tensor, Q: torch.Tensor, grad: torch.Tensor, k: int, step: int, pad: int, pad_mode: int,
-                   p_act: int, q_act: int, prec: int, accumulate: bool, splitk: Optional[int] = None, stack_kw: int = 0):
+                   p_act: int, q_act: int, prec: int, accumulate: bool, splitk: Optional[int] = None, stack_kw: int = 0, p_split: bool = False,
+                   q_split: bool = False):
         """stack_kw > 0: P is a dl_shift_stack image (channel = a*stack_kw + kw); vertical taps only (KH = k, KW = 1)"""
         _need_cuda(P, Q, grad)
         assert grad.dtype == torch.float32 and grad.is_contiguous()
@@ -267,8 +269,22 @@ class HipBackend:
             d.splitk = WGRAD_C4_PARTS          # one partial result per persistent workgroup (csrc/wgrad_c4.h)
         d.accumulate = 1 if accumulate else 0
         d.p_act, d.q_act = p_act, q_act
+        d.p_split, d.q_split = (1 if p_split else 0), (1 if q_split else 0)
         slab = WS.get('wgrad_slab', d.splitk * d.CAp * j, P.device)
         L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
+
+    supports_split = os.environ.get('DL_NO_SPLIT_COPY') is None          # A/B switch: DL_NO_SPLIT_COPY=1 keeps every hi / lo split inside the conv kernels
+
+    def conv_takes_split(self, x, prec, in_act, pad_mode) -> bool:
+        """can dl_conv_forward read the split copy of x (strict policy on the direct-to-LDS kernels, csrc/conv_x3.h: x3_glds_applies)?"""
+        return (self.supports_split and not _NO_X3_GLDS and x.dtype == torch.float32 and prec == L.PREC_BF16X3 and in_act == L.ACT_NONE)
+
+    def wgrad_takes_split(self, P, Q, grad, k, pad_mode, prec, stack_kw=0) -> bool:
+        """mirror of the fast3 predicate in wgrad.hip: strict direct-to-LDS weight gradient"""
+        if not self.supports_split or _NO_X3_GLDS or stack_kw or P.dtype != torch.float32 or prec != L.PREC_BF16X3 or pad_mode != L.PAD_ZERO:
+            return False
+        cap, j, ptot = P.shape[3], k * k * Q.shape[3], P.shape[0] * P.shape[1] * P.shape[2]
+        return cap % 128 == 0 and j >= 256 and ptot >= 32 * choose_wgrad_splitk(cap, j, ptot, True)
 
     def wgrad_c4_applies(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw=0) -> bool:
         return not _NO_WGRAD_C4 and wgrad_c4_ok(P.shape[3], grad.shape[0], Q.shape[3], grad.shape[1], k, step, pad, pad_mode, P.shape[1], P.shape[2], Q.shape[1], Q.shape[2],
@@ -284,9 +300,11 @@ class HipBackend:
         d.eps, d.momentum = 1e-5, momentum
         return d
 
-    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0):
-        """ext_nchunks > 0: the convolution that produced y already left its partial sums in the 'norm_ws' workspace"""
-        _need_cuda(y, z, gamma, beta, residual)
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0, z_split=None):
+        """ext_nchunks > 0: the convolution that produced y already left its partial sums in the 'norm_ws' workspace.
+        z_split (fp32 policy): dense buffer shaped like z that receives the split copy of z ([8 bf16 hi | 8 bf16 lo] per 8 channels)"""
+        _need_cuda(y, z, gamma, beta, residual, z_split)
+        assert z_split is None or (z_split.is_contiguous() and z_split.dtype == torch.float32 and z_split.shape == z.shape)
         d = self._norm_desc(y, C_real, scope, act, momentum, pstride(z), pstride(residual) if residual is not None else 8)
         d.ext_nchunks = ext_nchunks
         if not ext_nchunks:
@@ -295,18 +313,21 @@ class HipBackend:
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                          _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(z),
-                                         _ptr(ws), _stream()), 'dl_norm_forward')
+                                         _ptr(ws), _ptr(z_split), _stream()), 'dl_norm_forward')
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0):
-        """ext_nchunks > 0: the conv that produced dz already left the reductions in the 'norm_ws' workspace (conv_forward(bn=...))"""
-        _need_cuda(dz, y, dy, dy_chansum)
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0, dy_split=None):
+        """ext_nchunks > 0: the conv that produced dz already left the reductions in the 'norm_ws' workspace (conv_forward(bn=...)).
+        dy_split: see norm_forward(z_split)"""
+        _need_cuda(dz, y, dy, dy_chansum, dy_split)
+        assert dy_split is None or (dy_split.is_contiguous() and dy_split.dtype == torch.float32 and dy_split.shape == dy.shape)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
         d.ext_nchunks = ext_nchunks
         WS.bump_norm_token()
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
-                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _stream()), 'dl_norm_backward')
+                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _ptr(dy_split), _stream()),
+                'dl_norm_backward')
 
     # ---- elementwise
     def act_forward(self, act, x, y):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 105
+#define DL_VERSION 106
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -81,6 +81,9 @@ typedef struct dl_conv_desc {
                                        (first half of the narrow-Cout path, see dl_shift_sum)                            */
     int32_t ci_real;                /* real (unpadded) contracted channels; 0 = unknown.  <= 4 with Ci == 8 lets a stride-1 7x7 layer take the
                                        4-channel patch kernel (csrc/conv_c4.h: ResnetGenerator stem forward, head data gradient)               */
+    int32_t in_split;               /* 1 (strict policy only: DL_F32 + DL_PREC_BF16X3, in_act == DL_ACT_NONE): `in` is the SPLIT COPY of the fp32
+                                       activations -- same addressing, every group of 8 channels holds [8 bf16 hi | 8 bf16 lo] (written by
+                                       dl_norm_forward / dl_norm_backward, z_split / dy_split) -- so the kernels skip their own hi / lo split   */
 } dl_conv_desc;
 
 int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
@@ -132,6 +135,7 @@ typedef struct dl_wgrad_desc {
     int32_t pad_w;                       /* horizontal padding; -1 = same as `pad` */
     int32_t stack_kw;                    /* >0: P's channel a' = a*stack_kw + kw (dl_shift_stack image), KW must be 1; the result goes to
                                             grad[a][b][kh][kw] with stack_kw kernel columns */
+    int32_t p_split, q_split;            /* 1: P / Q is the split copy of the fp32 tensor (see dl_conv_desc.in_split); strict policy, no staged activation */
 } dl_wgrad_desc;
 
 int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
@@ -223,7 +227,11 @@ size_t dl_norm_ws_floats(const dl_norm_desc *d);     /* scratch needed by forwar
 int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, const float *beta,
                     float *running_mean, float *running_var,
                     float *mean, float *rstd, float *scale, float *shift,
-                    const void *residual, void *z, float *ws, void *stream);
+                    const void *residual, void *z, float *ws, void *z_split, void *stream);
+/* z_split / dy_split (may be NULL; DL_F32 only): a dense [N][H][W][Cp] buffer of the SAME byte size as the fp32 tensor that receives the split
+ * copy of z / dy -- per group of 8 channels 16 bytes of bf16 hi = bf16(v) followed by 16 bytes of bf16 lo = bf16(v - hi) -- for the strict-policy
+ * convolutions that consume the tensor next (dl_conv_desc.in_split, dl_wgrad_desc.p_split / q_split): the hi / lo split a conv kernel would redo
+ * for every tap and in every consuming wave is done once, by the producer, at the cost of one more 4-byte-per-element store. */
 
 /* dy = d/dy of [ z = act(norm(y)) (+res) ] given dz; dgamma/dbeta (+)= ...; the residual branch receives dz itself.
  * Strides: y uses d->y_pstride, dz uses d->z_pstride, dy uses d->r_pstride.
@@ -231,7 +239,7 @@ int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, co
  * produced y (Conv2d(bias=True) in front of InstanceNorm2d, networks.py:381-384), fused into the same pass. */
 int dl_norm_backward(const dl_norm_desc *d, const void *dz, const void *y, const float *gamma,
                      const float *mean, const float *rstd, const float *scale, const float *shift,
-                     void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *stream);
+                     void *dy, float *dgamma, float *dbeta, int accumulate_affine, float *dy_chansum, float *ws, void *dy_split, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise (networks.py nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh, torch.cat, the seg weighted sum

@@ -87,7 +87,9 @@ class FakeBackend:
     def norm_ws_token(self):
         return 0
 
-    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False, want_stats=False, bn=None):
+    supports_split = False          # the emulation works on fp32 tensors: split copies (engine.norm_act) are a GPU-side storage detail
+
+    def conv_forward(self, packed, x, out, hq, wq, bias, act, in_act, prec, splitk=None, raw_out=False, want_stats=False, bn=None, in_split=False):
         self._count('conv')
         plan = packed.plan
         xv = _act(in_act, x.float())
@@ -105,7 +107,7 @@ class FakeBackend:
             acc[..., :bias.numel()] += bias.float()
         out.copy_(_act(act, acc).to(out.dtype))
 
-    def conv_wgrad(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, accumulate, splitk=None, stack_kw=0):
+    def conv_wgrad(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, accumulate, splitk=None, stack_kw=0, p_split=False, q_split=False):
         self._count('wgrad')
         Pv, Qv = _act(p_act, P.float()), _act(q_act, Q.float())
         CA, CB = grad.shape[0], grad.shape[1]
@@ -130,7 +132,7 @@ class FakeBackend:
         else:
             grad.copy_(g)
 
-    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0):
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0, z_split=None):
         assert ext_nchunks == 0
         self._count('norm_fwd')
         yv = y.float()
@@ -160,7 +162,7 @@ class FakeBackend:
             stats[i] = t.reshape(-1, Cp).expand(N, Cp)
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0):
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0, dy_split=None):
         assert ext_nchunks == 0, 'the emulation never reports fused norm-backward reductions'
         self._count('norm_bwd')
         yv, g = y.float(), dz.float()

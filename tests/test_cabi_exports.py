@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/deepliif_hip.h but not exported by libdeepliif_hip.so'
         assert n in L.SIGNATURES, f'{n} has no ctypes signature in deepliif_amd/_lib.py'
-    assert lib.dl_version() == 105
+    assert lib.dl_version() == 106
     assert isinstance(lib.dl_last_error(), bytes)
 
 
@@ -76,5 +76,5 @@ def test_empty_problems_are_rejected_before_any_launch():
     assert lib.dl_conv_wgrad(C.byref(w), dummy, dummy, dummy, dummy, None) != 0 and b'empty problem' in lib.dl_last_error()
     n = L.NormDesc()
     n.N, n.H, n.W, n.Cp, n.C = 0, 8, 8, 8, 8
-    assert lib.dl_norm_forward(C.byref(n), dummy, None, None, None, None, dummy, dummy, dummy, dummy, None, dummy, dummy, None) != 0
+    assert lib.dl_norm_forward(C.byref(n), dummy, None, None, None, None, dummy, dummy, dummy, dummy, None, dummy, dummy, None, None) != 0
     assert b'empty problem' in lib.dl_last_error()

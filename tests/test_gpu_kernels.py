@@ -887,3 +887,65 @@ def test_attention_gate_and_sigmoid(shape, precname):
     real.act_backward(L.ACT_SIGMOID, g.to(DEV), y_f.to(DEV), dx_r)
     sync()
     assert rel(dx_r, dx_f) < (2e-6 if precname == 'fp32' else 1e-2)
+
+
+def _split_copy(t):
+    """host-side model of store_split8 (csrc/common.h): per group of 8 channels [8 bf16 hi | 8 bf16 lo] in the bytes of the fp32 group"""
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    g = torch.stack([hi.reshape(*t.shape[:3], -1, 8), lo.reshape(*t.shape[:3], -1, 8)], dim=4)       # [N,H,W,groups,2,8] bf16
+    return g.contiguous().view(torch.int16).reshape(*t.shape[:3], -1).view(torch.float32).reshape(t.shape)
+
+
+@pytest.mark.parametrize('case', [('conv', 256, 256, 3, 1, 1, 8, 64, 128), ('conv', 128, 256, 3, 2, 1, 4, 64, 64), ('convT', 256, 128, 3, 2, 1, 2, 32, 32),
+                                  ('conv', 64, 128, 4, 2, 1, 2, 48, 40), ('conv', 512, 512, 4, 1, 1, 2, 9, 9)], ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}')
+def test_split_copy_inputs_are_bit_identical_to_the_in_kernel_split(case):
+    """strict policy: the norm kernels can write a SPLIT COPY of their fp32 output (hi = bf16(v), lo = bf16(v - hi) per group of 8 channels) and the
+    direct-to-LDS strict kernels read it instead of splitting the fp32 values while staging (dl_conv_desc.in_split, dl_wgrad_desc.p_split /
+    q_split).  Same split formula on both routes -> forward, data gradient and weight gradient must be BIT-IDENTICAL; and the copy the norm
+    kernels write must be exactly the host model of the layout."""
+    kind, cin, cout, k, s_, p, N, H, W_ = case
+    prec = Precision.get('fp32')
+    spec = ConvSpec(kind, cin, cout, k, s_, p, L.PAD_ZERO, 1 if (kind == 'convT' and k == 3) else 0)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd(wshape, 1, prec, 0.05).to(DEV)
+    x = rnd((N, H, W_, cin), 3, prec).to(DEV)
+    ho, wo = spec.out_hw(H, W_)
+    dy = rnd((N, ho, wo, cout), 4, prec).to(DEV)
+    real = hip()
+    # the norm kernels' split outputs
+    zs = torch.empty_like(x)
+    z = torch.empty_like(x)
+    st = real.norm_forward(x, z, cin, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, -1.0, None, z_split=zs)
+    sync()
+    assert torch.equal(zs.view(torch.int32), _split_copy(z).view(torch.int32)), 'dl_norm_forward(z_split)'
+    dys = torch.empty_like(x)
+    dyo = torch.empty_like(x)
+    real.norm_backward(rnd((N, H, W_, cin), 5, prec).to(DEV), x, dyo, st, cin, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, dy_split=dys)
+    sync()
+    assert torch.equal(dys.view(torch.int32), _split_copy(dyo).view(torch.int32)), 'dl_norm_backward(dy_split)'
+    xs, dys = _split_copy(x), _split_copy(dy)
+    for plan_kind, src, srcs in (('fwd', x, xs), ('dgrad', dy, dys)):
+        plan = spec.forward_plan() if plan_kind == 'fwd' else spec.dgrad_plan()
+        packed = ops.PackedWeights(plan, DEV, True)
+        real.pack_weights(packed, w)
+        if plan_kind == 'fwd':
+            oshape, (hq, wq) = (N, ho, wo, cpad(cout)), ((ho, wo) if kind == 'conv' else (H, W_))
+        else:
+            oshape = (N, H, W_, cpad(cin))
+            hq, wq = ((H + 1) // 2, (W_ + 1) // 2) if (kind == 'conv' and s_ == 2) else (H, W_)
+        a, b = torch.empty(oshape, device=DEV), torch.empty(oshape, device=DEV)
+        real.conv_forward(packed, src, a, hq, wq, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+        real.conv_forward(packed, srcs, b, hq, wq, None, L.ACT_NONE, L.ACT_NONE, prec.prec, in_split=True)
+        sync()
+        assert 'x3' in real.last_conv_kernel, real.last_conv_kernel
+        assert torch.equal(a, b), plan_kind
+    gshape = wshape
+    P, Ps, Q, Qs = (dy, dys, x, xs) if kind == 'conv' else (x, xs, dy, dys)
+    g0 = torch.empty(gshape, device=DEV)
+    real.conv_wgrad(P, Q, g0, k, s_, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False)
+    for ps, qs in ((True, True), (True, False), (False, True)):
+        g1 = torch.empty(gshape, device=DEV)
+        real.conv_wgrad(Ps if ps else P, Qs if qs else Q, g1, k, s_, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, p_split=ps, q_split=qs)
+        sync()
+        assert torch.equal(g0, g1), ('wgrad', ps, qs)

@@ -691,6 +691,29 @@ def test_teacher_forced_attention_block_gradients(level, shape, precname):
         assert v <= tol, (k, v)
 
 
+def test_strict_step_with_and_without_split_copies_is_bit_identical(monkeypatch):
+    """DL_NO_SPLIT_COPY A/B on the whole training step (strict policy): with the split copies the norm kernels write and the convolutions read,
+    two optimize_parameters() steps give bit-identical weights and losses to the step that splits inside every conv kernel."""
+    def run(split):
+        monkeypatch.setattr(ops.HipBackend, 'supports_split', split)
+        torch.manual_seed(3)
+        opt = make_opt(2, True, 'batch', 'unet_64', 32, 'fp32')
+        model = M.create_model(opt)
+        model.setup(opt)
+        A = seeded_uniform((2, 3, 128, 128), 22)
+        B = [seeded_uniform((2, 3, 128, 128), 23 + i) for i in range(3)]
+        losses = []
+        for _ in range(2):
+            model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+            model.optimize_parameters()
+            losses.append(dict(model.get_current_losses()))
+        torch.cuda.synchronize()
+        return torch.cat([o.flat.data.clone() for o in model.optimizers]), losses
+    w1, l1 = run(True)
+    w0, l0 = run(False)
+    assert l1 == l0 and torch.equal(w1, w0)
+
+
 def _unet_chain(net):
     chain, blk = [], net.model
     while blk is not None:
