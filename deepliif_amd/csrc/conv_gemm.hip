@@ -1676,7 +1676,8 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
     if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
-    const int bm = glds_tile_bm(d);
+    static const bool no_x3_stats = getenv("DL_NO_X3_STATS") != nullptr;       // A/B: strict policy with the stand-alone statistics pass
+    const int bm = (x3_glds_applies(d) && !no_x3_stats) ? x3_tile_bm(d) : glds_tile_bm(d);
     const int hw = d->Hq * d->Wq;
     if (bm == 0 || hw % bm) return 0;
     return (hw / bm) * d->n_phase;

@@ -68,13 +68,22 @@ __device__ __forceinline__ void x3_split4(f32x4_t v, u32x2_t &hi, u32x2_t &lo) {
 
 // fp32 store epilogue of the strict kernels (accumulator layout of mfma_f32_16x16x32: lane = (pixel fr, channels 4*fg .. 4*fg + 3)):
 // one 16-byte store per fragment -- the four lanes fg = 0..3 of a pixel write 64 contiguous bytes -- or raw fp32 slabs for split-K / raw_out
+// + the optional fused per-(image, channel) statistics of the stored values for the normalisation that follows (dl_conv_stats_chunks protocol, as the
+// bf16 kernels: one chunk per tile and phase; the host guarantees that a tile lies in ONE image): sums over the lane's pixels, four DPP adds
+// over the 16 lanes of a row, the WM wave rows through LDS (dead after the K loop)
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void x3_epilogue(const ConvArgs &a, f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], int tm, int tn, int phase, int ks,
-                                            int wm, int wn, int lane) {
+                                            int wm, int wn, int lane, int tid, char *smem_raw) {
     constexpr int PM = BM / WM, PN = BN / WN, FM = PM / 16, FN = PN / 16;
     const int fr = lane & 15, fg = lane >> 4;
     const int HWq = a.Hq * a.Wq;
     const int oh = a.phase_oh[phase], ow = a.phase_ow[phase];
+    const bool want_stats = a.stats_part != nullptr;
+    float st1[FN][4], st2[FN][4];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[i][r] = st2[i][r] = 0.f;
     float bias[FN][4];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
@@ -107,6 +116,40 @@ __device__ __forceinline__ void x3_epilogue(const ConvArgs &a, f32x4_t (&acc)[BN
                 }
                 float *dst = reinterpret_cast<float *>(a.out) + opix * a.out_pstride + co;
                 *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (want_stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { st1[i][r] += v[r]; st2[i][r] += v[r] * v[r]; }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();                                           // every wave is out of the K loop: the tile buffers are dead
+        float *red = reinterpret_cast<float *>(smem_raw);          // [WM][2][BN]
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(st1[i][r]), s2 = row16_sum(st2[i][r]);
+                if (fr == 0) {
+                    const int c = wn * PN + i * 16 + fg * 4 + r;
+                    red[(wm * 2 + 0) * BN + c] = s1;
+                    red[(wm * 2 + 1) * BN + c] = s2;
+                }
+            }
+        __syncthreads();
+        const int m0 = tm * BM;
+        const int n = m0 / HWq;
+        const int chunk = ((m0 - n * HWq) / BM) * a.n_phase + phase;
+        for (int c = tid; c < BN; c += WM * WN * 64) {
+            const int co = tn * BN + c;
+            if (co < a.Co) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
+                float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + co;
+                o[0] = s1;
+                o[a.Co] = s2;
             }
         }
     }
@@ -480,7 +523,7 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_x3_kernel(const ConvArgs a)
 #undef DL_X3_TL
 #undef DL_X3_CH
 
-    x3_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane);
+    x3_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane, tid, smem_raw);
 }
 
 template <int IN_ACT, int ABL, int VAR = 0>
@@ -699,7 +742,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_x3_kernel(const C
         __syncthreads();
     }
 
-    x3_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane);
+    x3_epilogue<BM, BN, WM, WN>(a, acc, tm, tn, phase, ks, wm, wn, lane, tid, smem_raw);
 }
 
 template <int BM, int BN, int WM, int WN, bool UTAP, int IN_ACT>
@@ -746,6 +789,12 @@ static bool x3_glds_applies(const dl_conv_desc *d) {
 static bool x3_big_tile(int in_act, int pad_mode, int Ci, int mtot, int Co, int n_phase, int splitk) {
     static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
     return !no_big && in_act == DL_ACT_NONE && pad_mode == DL_PAD_ZERO && Ci >= 32 && big_tile_fills_gpu(mtot, Co, n_phase, splitk);
+}
+
+// tile height (pixels) of the strict direct-to-LDS dispatch (for dl_conv_stats_chunks)
+static int x3_tile_bm(const dl_conv_desc *d) {
+    if (x3_big_tile(d->in_act, d->pad_mode, d->Ci, d->N * d->Hq * d->Wq, d->Co, d->n_phase, d->splitk)) return 256;
+    return d->Co <= 16 ? 256 : 128;
 }
 
 static const char *x3_kernel_name(const dl_conv_desc *d) {

@@ -423,13 +423,16 @@ STATS_CASES = [
 ]
 
 
+@pytest.mark.parametrize('precname', ['bf16', 'fp32'])
 @pytest.mark.parametrize('scope', [L.NORM_INSTANCE, L.NORM_BATCH])
 @pytest.mark.parametrize('case', STATS_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}n{c[6]}')
-def test_conv_fused_norm_statistics(case, scope):
+def test_conv_fused_norm_statistics(case, scope, precname):
     """dl_conv_forward(stats_part) + dl_norm_forward(ext_nchunks) must give the statistics / output of the stand-alone pass over
-    the same stored y (the sums are taken over the bf16-rounded values in both)."""
+    the same stored y (the sums are taken over the stored -- bf16-rounded or fp32 -- values in both).  fp32 = the strict policy's
+    direct-to-LDS kernels (csrc/conv_x3.h); its 7x7 / 3-channel stem has no fused statistics (the c4 kernel is bf16-only) unless the
+    generic strict tile takes it."""
     kind, cin, cout, k, s, p, N, H, W_ = case
-    prec = Precision.get('bf16')
+    prec = Precision.get(precname)
     spec = ConvSpec(kind, cin, cout, k, s, p, L.PAD_ZERO, 1 if kind == 'convT' else 0)
     wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
     w = rnd(wshape, 1, prec, 0.05).to(DEV)
@@ -439,7 +442,7 @@ def test_conv_fused_norm_statistics(case, scope):
     x = x.to(prec.dtype).to(DEV)
     be = hip()
     plan = spec.forward_plan()
-    packed = ops.PackedWeights(plan, DEV, False)
+    packed = ops.PackedWeights(plan, DEV, prec.prec == L.PREC_BF16X3)
     be.pack_weights(packed, w)
     ho, wo = spec.out_hw(H, W_)
     hq, wq = (ho, wo) if kind == 'conv' else (H, W_)
@@ -458,9 +461,12 @@ def test_conv_fused_norm_statistics(case, scope):
     sync()
     assert torch.equal(y, y2)
     assert rel(st1[0][:, :cout], st2[0][:, :cout]) < 1e-5 and rel(st1[1][:, :cout], st2[1][:, :cout]) < 1e-5
-    # same scale/shift up to fp32 summation order -> identical up to rare one-ulp bf16 rounding flips
-    assert rel(z1, z2) <= 2.0 ** -7
-    assert float((z1 != z2).float().mean()) < 1e-3
+    # same scale/shift up to fp32 summation order -> identical up to rare one-ulp bf16 rounding flips (fp32 storage: up to ~1e-6)
+    if precname == 'bf16':
+        assert rel(z1, z2) <= 2.0 ** -7
+        assert float((z1 != z2).float().mean()) < 1e-3
+    else:
+        assert rel(z1, z2) <= 1e-5
     assert float(z1[..., cout:].float().abs().max()) == 0.0 if cpad(cout) > cout else True
 
 
