@@ -20,9 +20,9 @@ struct C4Args {
     int abl;                    // timing-only ablation bits (DL_C4_ABL): 1 no MFMA loop, 2 no global stores, 4 no patch fetch, 8 no LDS epilogue
 };
 
-static bool c4_eligible(const dl_conv_desc *d) {
+static bool c4_geometry_ok(const dl_conv_desc *d) {
     static const bool off = getenv("DL_NO_C4") != nullptr;
-    if (off || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE) return false;
+    if (off || d->in_act != DL_ACT_NONE) return false;
     if (d->act != DL_ACT_NONE && d->act != DL_ACT_RELU && d->act != DL_ACT_LRELU) return false;
     if (d->n_phase != 1 || d->in_step != 1 || d->out_step != 1 || d->splitk != 1 || d->raw_out) return false;
     if (d->Ci != 8 || d->ci_real < 1 || d->ci_real > 4 || d->in_pstride != 8) return false;
@@ -33,6 +33,16 @@ static bool c4_eligible(const dl_conv_desc *d) {
         if (d->tap_dh[t] < -3 || d->tap_dh[t] > 3 || d->tap_dw[t] < -3 || d->tap_dw[t] > 3) return false;
     return true;
 }
+
+static bool c4_bf16_eligible(const dl_conv_desc *d) { return d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && c4_geometry_ok(d); }
+
+// strict policy (fp32 activations, split-bf16 x3 products): conv_c4_patch_x3_kernel (conv_x3.h)
+static bool c4_x3_eligible(const dl_conv_desc *d) {
+    static const bool off = getenv("DL_NO_C4_X3") != nullptr;       // A/B: the strict stem / head gradient on the general x3 kernels (round 3 before this kernel)
+    return !off && d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && !d->in_split && c4_geometry_ok(d);
+}
+
+static bool c4_eligible(const dl_conv_desc *d) { return c4_bf16_eligible(d) || c4_x3_eligible(d); }
 
 template <int PADMODE, int ACT>
 __global__ void __launch_bounds__(256, 2) conv_c4_patch_kernel(const C4Args ca) {
@@ -229,8 +239,7 @@ __global__ void __launch_bounds__(256, 2) conv_c4_patch_kernel(const C4Args ca) 
   }   // tile loop
 }
 
-static int launch_conv_c4(const ConvArgs &a0, const dl_conv_desc *d, hipStream_t stream) {
-    C4Args ca;
+static void c4_fill_args(C4Args &ca, const ConvArgs &a0, const dl_conv_desc *d) {
     ca.a = a0;
     for (int i = 0; i < 8; ++i)
         for (int j = 0; j < 8; ++j) ca.tap_src[i][j] = -1;
@@ -240,10 +249,31 @@ static int launch_conv_c4(const ConvArgs &a0, const dl_conv_desc *d, hipStream_t
     ca.tiles_h = d->Ho / 4;
     static const char *abl_env = getenv("DL_C4_ABL");
     ca.abl = abl_env ? atoi(abl_env) : 0;
-    constexpr size_t smem = 4 * 64 * 64 * 2 + 4 * 64 * sizeof(float);          // output tile (aliases the two patch copies) + statistics
+}
+
+// launch with the dynamic-LDS attribute set once per instantiation
+static int c4_launch(void (*kern)(const C4Args), const C4Args &ca, const dl_conv_desc *d, size_t smem, hipStream_t stream, const char *what) {
+    static void (*attr_done[12])(const C4Args) = {};
+    bool seen = false;
+    for (int i = 0; i < 12; ++i) seen |= attr_done[i] == kern;
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("%s: hipFuncSetAttribute(%zu): %s", what, smem, hipGetErrorString(e));
+        for (int i = 0; i < 12; ++i)
+            if (!attr_done[i]) { attr_done[i] = kern; break; }
+    }
     const int ntiles = d->N * ca.tiles_w * ca.tiles_h;
     const int per_y = 512 / (d->Co / 64) > 0 ? 512 / (d->Co / 64) : 1;       // ~2 workgroups per CU in total
     dim3 grid(ntiles < per_y ? ntiles : per_y, d->Co / 64);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, ca);
+    DL_CHECK_LAUNCH(what);
+    return 0;
+}
+
+static int launch_conv_c4(const ConvArgs &a0, const dl_conv_desc *d, hipStream_t stream) {
+    C4Args ca;
+    c4_fill_args(ca, a0, d);
+    constexpr size_t smem = 4 * 64 * 64 * 2 + 4 * 64 * sizeof(float);          // output tile (aliases the two patch copies) + statistics
     void (*kern)(const C4Args) = nullptr;
     const bool refl = d->pad_mode == DL_PAD_REFLECT;
     switch (d->act) {
@@ -251,16 +281,5 @@ static int launch_conv_c4(const ConvArgs &a0, const dl_conv_desc *d, hipStream_t
         case DL_ACT_LRELU: kern = refl ? conv_c4_patch_kernel<DL_PAD_REFLECT, DL_ACT_LRELU> : conv_c4_patch_kernel<DL_PAD_ZERO, DL_ACT_LRELU>; break;
         default: kern = refl ? conv_c4_patch_kernel<DL_PAD_REFLECT, DL_ACT_NONE> : conv_c4_patch_kernel<DL_PAD_ZERO, DL_ACT_NONE>; break;
     }
-    static void (*attr_done[6])(const C4Args) = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool seen = false;
-    for (int i = 0; i < 6; ++i) seen |= attr_done[i] == kern;
-    if (!seen) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) DL_FAIL("dl_conv_forward(c4 patch): hipFuncSetAttribute(%zu): %s", smem, hipGetErrorString(e));
-        for (int i = 0; i < 6; ++i)
-            if (!attr_done[i]) { attr_done[i] = kern; break; }
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, ca);
-    DL_CHECK_LAUNCH("dl_conv_forward(c4 patch)");
-    return 0;
+    return c4_launch(kern, ca, d, smem, stream, "dl_conv_forward(c4 patch)");
 }

@@ -1656,7 +1656,8 @@ static int glds_tile_bm(const dl_conv_desc *d) {
 // benchmark label its roofline line from the dispatch itself instead of a string that goes stale when a default changes.
 extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (!d) return "(null)";
-    if (c4_eligible(d)) return "conv_c4_patch_kernel";
+    if (c4_bf16_eligible(d)) return "conv_c4_patch_kernel";
+    if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
     const int bm = glds_tile_bm(d);
     if (bm == 0 && x3_glds_applies(d)) return x3_kernel_name(d);
     if (bm == 0) return (d->in_dtype == DL_BF16) ? "conv_gemm_kernel<bf16>" : "conv_gemm_kernel<f32>";
@@ -1772,7 +1773,8 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
 
     int rc;
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
-    if (c4_eligible(d)) rc = launch_conv_c4(a, d, stream);
+    if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
+    else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = x3_glds_applies(d) ? dispatch_tile_x3(a, stream) : dispatch_tile<float, float, 3>(a, stream);

@@ -825,3 +825,202 @@ static int dispatch_tile_x3(const ConvArgs &a, hipStream_t stream) {
     if (a.in_act == DL_ACT_LRELU) return dispatch_glds_x3_tiles<DL_ACT_LRELU>(a, stream);
     return dispatch_glds_x3_tiles<DL_ACT_NONE>(a, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Strict policy on the 4-channel patch kernel (conv_c4.h): the ResnetGenerator stem forward and the head's data gradient with fp32
+// activations and split-bf16 x3 products.  Same tile walk, patch geometry and register-resident weights as conv_c4_patch_kernel;
+//   * the patch is fetched as fp32 (the first 4 of the 8 padded channels = 16 bytes per pixel) and split ONCE per staged pixel when it is
+//     written to LDS: four copies -- hi A/B and lo A/B (B = A shifted by one pixel, see conv_c4.h) -- 23 KB;
+//   * the hi and lo weight fragments both live in registers (112 VGPRs); three MFMAs per fragment pair, small terms first, term-major
+//     over the 8 accumulators of a fragment batch;
+//   * fp32 results leave straight from the accumulators (a lane holds 4 consecutive channels = one 16-byte store, the four lanes of a
+//     pixel 64 contiguous bytes -- the x3_epilogue pattern; the bf16 kernel's LDS transposition would need a 128 KB tile here), with
+//     the fused statistics of the stored values.
+// Before (round 3, first half): the stem ran on conv_gemm_glds_x3_kernel<128,64> with 49 taps x 8 padded channels: 694 us; head data gradient 569 us.
+// ------------------------------------------------------------------------------------------------------------------
+template <int PADMODE, int ACT>
+__global__ void __launch_bounds__(256, 2) conv_c4_patch_x3_kernel(const C4Args ca) {
+    const ConvArgs &a = ca.a;
+    constexpr int TR = 4, TC = 64, KR = 7, PR = TR + KR - 1, PW = 72;
+    constexpr int NF = (TR / 2) * 4;
+    constexpr int CSTR = PR * PW * 8 + 16;          // bytes from one patch copy to the next: hi A, hi B, lo A, lo B (copy B holds pixel i at byte (i + 1) * 8)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *red = reinterpret_cast<float *>(smem_raw + 4 * CSTR);            // [2 row halves][2][64] statistics
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = wave & 1, rh = wave >> 1;
+    const int co0 = blockIdx.y * 64 + ch * 32;
+    const float *in = reinterpret_cast<const float *>(a.in);
+    const int ntiles = a.N * ca.tiles_h * ca.tiles_w;
+
+    const int fr = lane & 15, fg = lane >> 4;
+    bf16x8_t wh[2][KR], wl[2][KR];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+        const size_t roff = (size_t)(co0 + cf * 16 + fr) * a.w_kstride + a.phase_kbase[0];
+#pragma unroll
+        for (int kk = 0; kk < KR; ++kk) {
+            const int t0 = fg == 0 ? ca.tap_src[kk][0] : fg == 1 ? ca.tap_src[kk][2] : fg == 2 ? ca.tap_src[kk][4] : ca.tap_src[kk][6];
+            const int t1 = fg == 0 ? ca.tap_src[kk][1] : fg == 1 ? ca.tap_src[kk][3] : fg == 2 ? ca.tap_src[kk][5] : ca.tap_src[kk][7];
+            const int o0 = (t0 >= 0 ? t0 : 0) * 8, o1 = (t1 >= 0 ? t1 : 0) * 8;
+            const u32x2_t h0 = *reinterpret_cast<const u32x2_t *>(a.w_hi + roff + o0), h1 = *reinterpret_cast<const u32x2_t *>(a.w_hi + roff + o1);
+            const u32x2_t l0 = *reinterpret_cast<const u32x2_t *>(a.w_lo + roff + o0), l1 = *reinterpret_cast<const u32x2_t *>(a.w_lo + roff + o1);
+            const u32x4_t vh = {t0 >= 0 ? h0[0] : 0u, t0 >= 0 ? h0[1] : 0u, t1 >= 0 ? h1[0] : 0u, t1 >= 0 ? h1[1] : 0u};
+            const u32x4_t vl = {t0 >= 0 ? l0[0] : 0u, t0 >= 0 ? l0[1] : 0u, t1 >= 0 ? l1[0] : 0u, t1 >= 0 ? l1[1] : 0u};
+            wh[cf][kk] = __builtin_bit_cast(bf16x8_t, vh);
+            wl[cf][kk] = __builtin_bit_cast(bf16x8_t, vl);
+        }
+    }
+
+    constexpr int PPT = (PR * (TC + KR) + 255) / 256;       // patch pixels per thread (3)
+    f32x4_t nxt[PPT];
+    auto fetch_patch = [&](int tile) __attribute__((always_inline)) {
+        int t = tile;
+        const int tw = t % ca.tiles_w; t /= ca.tiles_w;
+        const int th = t % ca.tiles_h;
+        const int n = t / ca.tiles_h;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * 256;
+            const int pr = i / (TC + KR), pc = i - pr * (TC + KR);
+            int hi = th * TR - 3 + pr, wi = tw * TC - 3 + pc;
+            if (PADMODE == DL_PAD_REFLECT) { hi = reflect_idx(hi, a.Hi); wi = reflect_idx(wi, a.Wi); }
+            const bool ok = i < PR * (TC + KR) && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4_t *>(in + ((size_t)(n * a.Hi + hi) * a.Wi + wi) * 8);
+            nxt[k] = v;
+        }
+    };
+    auto write_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * 256;
+            if (i < PR * (TC + KR)) {
+                const int pr = i / (TC + KR), pc = i - pr * (TC + KR);
+                u32x2_t h, l;
+                x3_split4<DL_ACT_NONE>(nxt[k], h, l);
+                char *p = smem_raw + (pr * PW + pc) * 8;
+                *reinterpret_cast<u32x2_t *>(p) = h;
+                *reinterpret_cast<u32x2_t *>(p + CSTR + 8) = h;
+                *reinterpret_cast<u32x2_t *>(p + 2 * CSTR) = l;
+                *reinterpret_cast<u32x2_t *>(p + 3 * CSTR + 8) = l;
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch_patch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tw = t % ca.tiles_w; t /= ca.tiles_w;
+    const int th = t % ca.tiles_h;
+    const int n = t / ca.tiles_h;
+    const int h0 = th * TR, w0 = tw * TC;
+    __syncthreads();                                      // every wave is done with the previous tile's patch (and statistics scratch)
+    write_patch();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles && !(ca.abl & 4)) fetch_patch(tile + gridDim.x);
+
+    f32x4_t acc[2][NF];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[cf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // lane base: even fr -> copy A at pixel (fr + 2 fg), odd fr -> copy B (same pixel, stored 8 bytes further: 16-byte aligned again)
+    const char *base = smem_raw + ((fr & 1) ? CSTR + 8 : 0) + (fr + 2 * fg) * 8 + (rh * (TR / 2)) * PW * 8;
+    if (!(ca.abl & 1))
+#pragma unroll
+    for (int kk = 0; kk < KR; ++kk) {
+#pragma unroll
+        for (int jb = 0; jb < NF; jb += 4) {
+            bf16x8_t xh[4], xl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = ((((jb + j) >> 2) + kk) * PW + ((jb + j) & 3) * 16) * 8;
+                xh[j] = *reinterpret_cast<const bf16x8_t *>(base + off);
+                xl[j] = *reinterpret_cast<const bf16x8_t *>(base + 2 * CSTR + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[0][kk], xh[j], acc[0][jb + j], 0, 0, 0);
+                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[1][kk], xh[j], acc[1][jb + j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0][kk], xl[j], acc[0][jb + j], 0, 0, 0);
+                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1][kk], xl[j], acc[1][jb + j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0][kk], xh[j], acc[0][jb + j], 0, 0, 0);
+                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1][kk], xh[j], acc[1][jb + j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels co0 + cf*16 + fg*4 .. +4 of pixel (row rh*2 + j/4, column (j%4)*16 + fr)
+    const bool want_stats = a.stats_part != nullptr;
+    float *out = reinterpret_cast<float *>(a.out);
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+        const int co = co0 + cf * 16 + fg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (co + r < a.bias_n) ? a.bias[co + r] : 0.f;
+        }
+        float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            f32x4_t v = acc[cf][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            if (ACT == DL_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (ACT == DL_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+            }
+            const int h = h0 + rh * (TR / 2) + (j >> 2), w = w0 + (j & 3) * 16 + fr;
+            if (!(ca.abl & 2)) *reinterpret_cast<f32x4_t *>(out + ((size_t)(n * a.Ho + h) * a.Wo + w) * a.out_pstride + co) = v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[r] += v[r]; st2[r] += v[r] * v[r]; }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = row16_sum(st1[r]), s2 = row16_sum(st2[r]);
+                if (fr == 0) {
+                    const int c = ch * 32 + cf * 16 + fg * 4 + r;
+                    red[(rh * 2 + 0) * 64 + c] = s1;
+                    red[(rh * 2 + 1) * 64 + c] = s2;
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < 64) {
+            const int chunk = th * ca.tiles_w + tw;
+            float *o = a.stats_part + ((size_t)(n * a.stats_nchunks + chunk) * 2) * a.Co + blockIdx.y * 64 + tid;
+            o[0] = red[0 * 64 + tid] + red[2 * 64 + tid];
+            o[a.Co] = red[1 * 64 + tid] + red[3 * 64 + tid];
+        }
+    }
+  }   // tile loop
+}
+
+static int launch_conv_c4_x3(const ConvArgs &a0, const dl_conv_desc *d, hipStream_t stream) {
+    if (!a0.w_lo) DL_FAIL("dl_conv_forward(c4 patch x3): the lo weight plane is missing");
+    C4Args ca;
+    c4_fill_args(ca, a0, d);
+    constexpr size_t smem = 4 * ((4 + 6) * 72 * 8 + 16) + 4 * 64 * sizeof(float);      // four patch copies + statistics
+    void (*kern)(const C4Args) = nullptr;
+    const bool refl = d->pad_mode == DL_PAD_REFLECT;
+    switch (d->act) {
+        case DL_ACT_RELU: kern = refl ? conv_c4_patch_x3_kernel<DL_PAD_REFLECT, DL_ACT_RELU> : conv_c4_patch_x3_kernel<DL_PAD_ZERO, DL_ACT_RELU>; break;
+        case DL_ACT_LRELU: kern = refl ? conv_c4_patch_x3_kernel<DL_PAD_REFLECT, DL_ACT_LRELU> : conv_c4_patch_x3_kernel<DL_PAD_ZERO, DL_ACT_LRELU>; break;
+        default: kern = refl ? conv_c4_patch_x3_kernel<DL_PAD_REFLECT, DL_ACT_NONE> : conv_c4_patch_x3_kernel<DL_PAD_ZERO, DL_ACT_NONE>; break;
+    }
+    return c4_launch(kern, ca, d, smem, stream, "dl_conv_forward(c4 patch x3)");
+}

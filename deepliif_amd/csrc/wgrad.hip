@@ -741,6 +741,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (d->prec == DL_PREC_BF16X3 && d->dtype != DL_F32) DL_FAIL("dl_conv_wgrad: BF16X3 needs fp32 activations");
 
     if (const int form = wgrad_c4_form(d)) return launch_wgrad_c4(d, form, P, Q, grad, slab, stream);
+    if (const int form = wgrad_c4_x3_form(d)) return launch_wgrad_c4_x3(d, form, P, Q, grad, slab, stream);
 
     WgradArgs a;
     memset(&a, 0, sizeof(a));

@@ -504,3 +504,165 @@ static int launch_wgrad_glds_x3(WgradArgs a, hipStream_t stream) {
     DL_CHECK_LAUNCH("dl_conv_wgrad(glds x3)");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Strict policy on the 7x7 stem / head weight gradient (wgrad_c4.h): fp32 operands, split once per staged element when the tile is
+// committed to LDS (hi and lo planes of the wide tile and of the small-side patch), three MFMAs per fragment pair, small terms first.
+// Tiles are 2 x 64 pixels (the bf16 kernel's 4 x 64 would need 92 KB of LDS for two planes: one workgroup per CU); 49 KB here.
+// Same R layout, slab layout and fixed-order reduction (wgrad_c4_reduce_kernel) as the bf16 kernel.
+// Before: generic wgrad_kernel<float, 3, ...> on 49 taps x 8 padded channels, stem 864 us, head (shift_stack + stacked) 966 us.
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradC4X3Args {
+    const float *wide;
+    const float *small_;
+    float *slab;
+    int N, H, W, wide_pstride, small_pstride;
+    int tiles_w, tiles_h;
+};
+
+__global__ void __launch_bounds__(256, 2) wgrad_c4_x3_kernel(const WgradC4X3Args a) {
+    constexpr int TR = 2, TC = 64, KR = 7, PR = TR + KR - 1, PW = 72;       // tile, kernel rows, patch rows, patch pitch (pixels)
+    constexpr int WROW = 80;                                                // wide-tile row pitch in elements (64 + 16: bank spread)
+    constexpr int WIDE_ELEMS = TR * TC * WROW;                              // 20 KB per plane
+    constexpr int PATCH_ELEMS = PR * PW * 4 + 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *wth = reinterpret_cast<bf16_t *>(smem_raw);
+    bf16_t *wtl = wth + WIDE_ELEMS;
+    bf16_t *pth = wtl + WIDE_ELEMS;                                         // patch: [PR][PW] pixels x 4 channels
+    bf16_t *ptl = pth + PATCH_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = a.N * a.tiles_h * a.tiles_w;
+    const int f0 = (wave * 14) / 4, cnt = ((wave + 1) * 14) / 4 - f0;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WCH = (TR * TC * 16) / 256;               // 16-byte pieces (4 fp32 channels) of the wide tile per thread (8)
+    constexpr int PPT = (PR * PW + 255) / 256;              // patch pixels per thread (3)
+    f32x4_t wnx[WCH], pnx[PPT];
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        int t = tile;
+        const int tw = t % a.tiles_w; t /= a.tiles_w;
+        const int th = t % a.tiles_h;
+        const int n = t / a.tiles_h;
+#pragma unroll
+        for (int k = 0; k < WCH; ++k) {
+            const int i = tid + k * 256, px = i >> 4, c4 = (i & 15) * 4;
+            const int h = th * TR + (px >> 6), w = tw * TC + (px & 63);
+            wnx[k] = *reinterpret_cast<const f32x4_t *>(a.wide + ((size_t)(n * a.H + h) * a.W + w) * a.wide_pstride + c4);
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * 256;
+            const int pr = i / PW, pc = i - pr * PW;
+            const int h = th * TR - 3 + pr, w = tw * TC - 3 + pc;
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (i < PR * PW && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+                v = *reinterpret_cast<const f32x4_t *>(a.small_ + ((size_t)(n * a.H + h) * a.W + w) * a.small_pstride);
+            pnx[k] = v;
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < WCH; ++k) {
+            const int i = tid + k * 256, px = i >> 4, c4 = (i & 15) * 4;
+            u32x2_t hi, lo;
+            x3w_split4(wnx[k], DL_ACT_NONE, hi, lo);
+            *reinterpret_cast<u32x2_t *>(wth + px * WROW + c4) = hi;
+            *reinterpret_cast<u32x2_t *>(wtl + px * WROW + c4) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * 256;
+            if (i < PR * PW) {
+                u32x2_t hi, lo;
+                x3w_split4(pnx[k], DL_ACT_NONE, hi, lo);
+                *reinterpret_cast<u32x2_t *>(pth + i * 4) = hi;
+                *reinterpret_cast<u32x2_t *>(ptl + i * 4) = lo;
+            }
+        }
+    };
+
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                  // the previous tile's fragments have all been read
+        commit();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int kc = 0; kc < TR * 2; ++kc) {             // 32-pixel contraction steps: tile row kc >> 1, columns (kc & 1)*32 .. +32
+            const int r = kc >> 1, c = (kc & 1) * 32;
+            bf16x8_t ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = tr_fragment_rows<WROW>(wth + (r * TC + c) * WROW + i * 16, lane);
+                al[i] = tr_fragment_rows<WROW>(wtl + (r * TC + c) * WROW + i * 16, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < cnt) {
+                    const int f = f0 + j;
+                    const int po = ((r + (f >> 1)) * PW + c + 4 * (f & 1)) * 4;
+                    const bf16x8_t bh = tr_fragment_rows<4>(pth + po, lane);
+                    const bf16x8_t bl = tr_fragment_rows<4>(ptl + po, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    float *o = a.slab + (size_t)blockIdx.x * 64 * 224;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < cnt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[(i * 16 + fg * 4 + q) * 224 + (f0 + j) * 16 + fr] = acc[i][j][q];
+            }
+        }
+}
+
+static int wgrad_c4_x3_form(const dl_wgrad_desc *d) {          // as wgrad_c4_form, for fp32 operands + BF16X3
+    static const bool off = dl_env_is_one("DL_NO_WGRAD_C4") || getenv("DL_NO_C4_X3") != nullptr;
+    if (off || d->dtype != DL_F32 || d->prec != DL_PREC_BF16X3 || d->p_act != DL_ACT_NONE || d->q_act != DL_ACT_NONE || d->p_split || d->q_split) return 0;
+    if (d->KH != 7 || d->KW != 7 || d->step != 1 || d->pad != 3 || (d->pad_w >= 0 && d->pad_w != 3) || d->pad_mode != DL_PAD_ZERO || d->stack_kw) return 0;
+    if (d->Hp != d->Hq || d->Wp != d->Wq || d->Hp % 4 || d->Wp % 64 || d->splitk != DL_WGRAD_C4_PARTS) return 0;
+    if (d->CAp == 64 && d->CA <= 64 && d->CBp == 8 && d->CB <= 4) return 1;
+    if (d->CAp == 8 && d->CA <= 4 && d->CBp == 64 && d->CB <= 64) return 2;
+    return 0;
+}
+
+static int launch_wgrad_c4_x3(const dl_wgrad_desc *d, int form, const void *P, const void *Q, float *grad, float *slab, hipStream_t stream) {
+    WgradC4X3Args a;
+    a.wide = (const float *)(form == 1 ? P : Q);
+    a.small_ = (const float *)(form == 1 ? Q : P);
+    a.wide_pstride = form == 1 ? d->p_pstride : d->q_pstride;
+    a.small_pstride = form == 1 ? d->q_pstride : d->p_pstride;
+    a.slab = slab;
+    a.N = d->N; a.H = d->Hp; a.W = d->Wp;
+    a.tiles_w = d->Wp / 64; a.tiles_h = d->Hp / 2;
+    const int ntiles = a.N * a.tiles_w * a.tiles_h;
+    const int parts = ntiles < DL_WGRAD_C4_PARTS ? ntiles : DL_WGRAD_C4_PARTS;
+    constexpr size_t smem = (size_t)(2 * 2 * 64 * 80 + 2 * (8 * 72 * 4 + 32)) * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_c4_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) DL_FAIL("dl_conv_wgrad(c4 x3): hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_c4_x3_kernel, dim3(parts), dim3(256), smem, stream, a);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(c4 x3)");
+    hipLaunchKernelGGL(wgrad_c4_reduce_kernel, dim3(64 * 56 / 8), dim3(256), 0, stream, slab, parts, grad, d->CA, d->CB, form == 1 ? 1 : 0, d->accumulate);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(c4 x3 reduce)");
+    return 0;
+}

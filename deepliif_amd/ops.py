@@ -47,6 +47,7 @@ _BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
 _NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
 _NO_X3_GLDS = os.environ.get('DL_NO_X3_GLDS') is not None           # A/B switch: the strict policy on the round-1 register-staged kernels (csrc reads the same variable)
 _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
+_NO_C4_X3 = 'DL_NO_C4_X3' in os.environ              # A/B switch: the strict 7x7 stem / head on the general x3 kernels (csrc/conv_x3.h, wgrad_x3.h)
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
@@ -208,7 +209,7 @@ class HipBackend:
         if auto_split and splitk > 1 and plan.cc_real <= 4:
             # the 4-channel patch kernel (csrc/conv_c4.h) has no split-K form and needs none (its K is 7 steps): prefer it when it applies
             d.splitk = 1
-            if self.lib.dl_conv_kernel_name(C.byref(d)).decode() == 'conv_c4_patch_kernel':
+            if self.lib.dl_conv_kernel_name(C.byref(d)).decode().startswith('conv_c4_patch'):
                 splitk = 1
             else:
                 d.splitk = splitk
@@ -288,7 +289,8 @@ class HipBackend:
 
     def wgrad_c4_applies(self, P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw=0) -> bool:
         return not _NO_WGRAD_C4 and wgrad_c4_ok(P.shape[3], grad.shape[0], Q.shape[3], grad.shape[1], k, step, pad, pad_mode, P.shape[1], P.shape[2], Q.shape[1], Q.shape[2],
-                           P.dtype == torch.bfloat16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE, bool(stack_kw))
+                           (P.dtype == torch.bfloat16 and prec == L.PREC_BF16) or (P.dtype == torch.float32 and prec == L.PREC_BF16X3 and not _NO_C4_X3),
+                           p_act == L.ACT_NONE and q_act == L.ACT_NONE, bool(stack_kw))
 
     # ---- normalisation
     def _norm_desc(self, y, C_real, scope, act, momentum, z_ps, r_ps):

@@ -652,14 +652,18 @@ def test_narrow_roll_kernel_against_torch(shape, cout, act):
     assert rel(got[..., :cout].permute(0, 3, 1, 2), ref) < 6e-3
 
 
+@pytest.mark.parametrize('precname', ['bf16', 'fp32'])
 @pytest.mark.parametrize('shape', [(2, 64, 128), (1, 8, 64), (3, 36, 192), (1, 512, 512)])
 @pytest.mark.parametrize('pm', [L.PAD_ZERO, L.PAD_REFLECT])
-def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm):
+def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm, precname):
     """conv_c4_patch_kernel (<= 4 real input channels, 7x7, input patch staged once in two 8-byte-shifted copies): the ResnetGenerator
-    stem forward incl. the fused norm statistics, and the head's data gradient (a 3 -> 64 conv with the flipped kernel), vs torch."""
+    stem forward incl. the fused norm statistics, and the head's data gradient (a 3 -> 64 conv with the flipped kernel), vs torch.
+    fp32 = the strict policy's conv_c4_patch_x3_kernel (csrc/conv_x3.h: fp32 patch split once per staged pixel, three products)."""
     from deepliif_amd import engine as E
     n, h, w = shape
-    prec = Precision.get('bf16')
+    prec = Precision.get(precname)
+    kname = 'conv_c4_patch_kernel' if precname == 'bf16' else 'conv_c4_patch_x3_kernel'
+    tol = 6e-3 if precname == 'bf16' else 1e-4
     real = hip()
     # ---- stem: 3 -> 64, bias, statistics for the following norm
     spec = ConvSpec('conv', 3, 64, 7, 1, 3, pm)
@@ -669,15 +673,15 @@ def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm):
     x0[..., :3] = rnd((n, h, w, 3), 23, prec)
     layer = E.ConvLayer(spec, torch.nn.Parameter(w0.clone().to(DEV)), torch.nn.Parameter(b0.clone().to(DEV)))
     layer.ensure_packed(prec, need_dgrad=False)
-    out = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=DEV)
-    nch = real.conv_forward(layer.packed_fwd, x0.to(torch.bfloat16).to(DEV), out, h, w, layer.bias.detach(), L.ACT_NONE, L.ACT_NONE, prec.prec, want_stats=True)
+    out = torch.empty((n, h, w, 64), dtype=prec.dtype, device=DEV)
+    nch = real.conv_forward(layer.packed_fwd, x0.to(prec.dtype).to(DEV), out, h, w, layer.bias.detach(), L.ACT_NONE, L.ACT_NONE, prec.prec, want_stats=True)
     sync()
-    assert real.last_conv_kernel == 'conv_c4_patch_kernel' and nch == (h // 4) * (w // 64)
+    assert real.last_conv_kernel == kname and nch == (h // 4) * (w // 64)
     xp = x0[..., :3].permute(0, 3, 1, 2)
     xp = torch.nn.functional.pad(xp, (3, 3, 3, 3), mode='reflect') if pm == L.PAD_REFLECT else torch.nn.functional.pad(xp, (3, 3, 3, 3))
     ref = torch.nn.functional.conv2d(xp, w0, b0)
     got = out.float().cpu().permute(0, 3, 1, 2)
-    assert rel(got, ref) < 6e-3
+    assert rel(got, ref) < tol
     part = ops.WS.get('norm_ws', 1, out.device)[:n * nch * 2 * 64].view(n, nch, 2, 64).cpu()
     assert torch.allclose(part[:, :, 0].sum(1), got.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(part[:, :, 1].sum(1), (got * got).sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
@@ -690,21 +694,24 @@ def test_c4_patch_kernel_stem_forward_and_head_dgrad(shape, pm):
     hl.ensure_packed(prec, need_dgrad=True)
     dy0 = torch.zeros(n, h, w, 8)
     dy0[..., :3] = rnd((n, h, w, 3), 25, prec)
-    dx = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=DEV)
-    real.conv_forward(hl.packed_dgrad, dy0.to(torch.bfloat16).to(DEV), dx, h, w, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+    dx = torch.empty((n, h, w, 64), dtype=prec.dtype, device=DEV)
+    real.conv_forward(hl.packed_dgrad, dy0.to(prec.dtype).to(DEV), dx, h, w, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
     sync()
-    assert real.last_conv_kernel == 'conv_c4_patch_kernel'
+    assert real.last_conv_kernel == kname
     xt = torch.zeros(n, 64, h, w, requires_grad=True)
     torch.nn.functional.conv2d(xt, hw, padding=3).backward(dy0[..., :3].permute(0, 3, 1, 2).contiguous())
-    assert rel(dx.float().cpu().permute(0, 3, 1, 2), xt.grad) < 6e-3
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), xt.grad) < tol
 
 
+@pytest.mark.parametrize('precname', ['bf16', 'fp32'])
 @pytest.mark.parametrize('shape', [(2, 64, 128), (1, 4, 64), (3, 36, 192), (2, 256, 256)])
-def test_c4_weight_gradient_of_the_7x7_layers(shape):
+def test_c4_weight_gradient_of_the_7x7_layers(shape, precname):
     """wgrad_c4_kernel (csrc/wgrad_c4.h): dW of the Resnet stem (3 -> 64: wide = dL/dy, small = x) and of its head (64 -> 3: wide = x,
-    small = dL/dy, mirrored kernel indices), persistent workgroups + fixed-order combine, vs torch autograd; accumulate semantics."""
+    small = dL/dy, mirrored kernel indices), persistent workgroups + fixed-order combine, vs torch autograd; accumulate semantics.
+    fp32 = the strict policy's wgrad_c4_x3_kernel (csrc/wgrad_x3.h)."""
     n, h, w = shape
-    prec = Precision.get('bf16')
+    prec = Precision.get(precname)
+    tol = 2e-3 if precname == 'bf16' else 1e-4
     real = hip()
     for cin, cout in ((3, 64), (64, 3)):
         x0 = torch.zeros(n, h, w, max(8, cin)); x0[..., :cin] = rnd((n, h, w, cin), 31, prec)
@@ -713,14 +720,14 @@ def test_c4_weight_gradient_of_the_7x7_layers(shape):
         torch.nn.functional.conv2d(x0[..., :cin].permute(0, 3, 1, 2), wt, padding=3).backward(dy0[..., :cout].permute(0, 3, 1, 2).contiguous())
         g0 = rnd((cout, cin, 7, 7), 33, Precision.get('fp32'))
         grad = g0.clone().to(DEV)
-        P, Q = dy0.to(torch.bfloat16).to(DEV), x0.to(torch.bfloat16).to(DEV)
+        P, Q = dy0.to(prec.dtype).to(DEV), x0.to(prec.dtype).to(DEV)
         assert real.wgrad_c4_applies(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec)
         real.conv_wgrad(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, True)
         sync()
-        assert rel(grad.cpu() - g0, wt.grad) < 2e-3, (cin, cout)
+        assert rel(grad.cpu() - g0, wt.grad) < tol, (cin, cout)
         real.conv_wgrad(P, Q, grad, 7, 1, 3, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False)
         sync()
-        assert rel(grad.cpu(), wt.grad) < 2e-3, (cin, cout, 'overwrite')
+        assert rel(grad.cpu(), wt.grad) < tol, (cin, cout, 'overwrite')
 
 
 @pytest.mark.parametrize('precname', ['fp32', 'bf16'])

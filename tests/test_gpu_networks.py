@@ -272,9 +272,10 @@ def test_training_step_golden_fixture_from_reference(tag, precname):
                 mine = name.replace(S_fix, S, 1) if (len(name) > 2 and name[1] == S_fix[0]) else name
                 sd = getattr(model, 'net' + mine).state_dict()
                 flat = torch.cat([v.reshape(-1).float().cpu() for v in sd.values() if v.is_floating_point()])
-                # |dw| after one Adam step ~ 1% of |w|; 6e-3 of |w| = 60% of the update norm: catches a wrong learning rate,
-                # bias correction or update direction (>= 100%), tolerates the sign flips of noise-level gradients
-                ok, msg = digest_close(flat, z[f'step{s}/w_digest/{name}'], 6e-3)
+                # |dw| after one Adam step ~ 1% of |w| (every weight moves by exactly lr); 8e-3 of |w| = 80% of the update norm: catches a
+                # wrong learning rate, bias correction or update direction (>= 100%), tolerates the sign flips of noise-level gradients
+                # (a few % of the weights; measured 4.9e-3 .. 6.4e-3 on the reflect case depending on the summation order of the stem kernel)
+                ok, msg = digest_close(flat, z[f'step{s}/w_digest/{name}'], 8e-3)
                 assert ok, f'step {s} weights of {name}: {msg}'
 
 
