@@ -99,6 +99,8 @@ SIGNATURES = {
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'dl_loss_acc': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _f, _i, _vp, _i, _f, _vp, _vp]),
+    'dl_kldiv_ws_floats': (C.c_size_t, []),
+    'dl_kldiv': (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp, _f, _i, _vp, _i, _f, _vp, _vp]),
     'dl_maxpool2_forward': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_maxpool2_backward': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
@@ -130,8 +132,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 106:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 106 (stale build)')
+    if lib.dl_version() != 107:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 107 (stale build)')
     _lib = lib
     return lib
 

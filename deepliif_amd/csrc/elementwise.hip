@@ -325,6 +325,77 @@ extern "C" int dl_loss(int kind, int dtype, const void *x, int x_ps, const void 
     return dl_loss_acc(kind, dtype, x, x_ps, target, t_ps, tconst, npix, C, Cp, loss_out, 1.0f, 0, grad, g_ps, gscale, ws, stream_);
 }
 
+// ------------------------------------------------------------------------------------------- KL divergence of two whole-tensor softmaxes
+// DeepLIIFKD (DeepLIIFKD_model.py:313-336): KLDivLoss(reduction='batchmean')(LogSoftmax(dim=-1)(x.view(1, 1, -1)), Softmax(dim=-1)(t.view(1, 1, -1)))
+//   = sum_j p_j (log p_j - log q_j),  p = softmax(t), q = softmax(x) over ALL real elements of the tensor (the batch dimension of the view is 1),
+//   d/dx_j = q_j - p_j.
+// With Zx = sum e^x, Zt = sum e^t, A = sum e^t (t - x):  KL = A / Zt - log Zt + log Zx.  Both tensors are generator outputs (tanh, or a
+// convex combination of tanh outputs), so |x|, |t| <= 1 and the exponentials need no running maximum.  fp32 block partials in a fixed order, combined in
+// double by one thread (deterministic); the gradient kernel reads Zx, Zt from device memory -- no host round trip.
+// ws: 3 * LOSS_BLOCKS + 4 floats (dl_kldiv_ws_floats).
+extern "C" size_t dl_kldiv_ws_floats(void) { return 3 * LOSS_BLOCKS + 4; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) kldiv_partial_kernel(const T *x, int x_ps, const T *t, int t_ps, size_t npix, int C, float *part) {
+    __shared__ float red[3][4];
+    const size_t total = npix * C;
+    float zx = 0.f, zt = 0.f, a = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i % C);
+        const float xv = load1<T>(x + p * x_ps + c), tv = load1<T>(t + p * t_ps + c);
+        const float et = expf(tv);
+        zx += expf(xv);
+        zt += et;
+        a += et * (tv - xv);
+    }
+    zx = wave_sum(zx); zt = wave_sum(zt); a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = zx; red[1][threadIdx.x >> 6] = zt; red[2][threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[threadIdx.x * LOSS_BLOCKS + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+__global__ void kldiv_final_kernel(const float *part, float *stats, float *out, float out_scale, int accumulate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double zx = 0.0, zt = 0.0, a = 0.0;
+        for (int i = 0; i < LOSS_BLOCKS; ++i) { zx += (double)part[i]; zt += (double)part[LOSS_BLOCKS + i]; a += (double)part[2 * LOSS_BLOCKS + i]; }
+        const float v = (float)(a / zt - log(zt) + log(zx)) * out_scale;
+        out[0] = accumulate ? out[0] + v : v;
+        stats[0] = (float)(1.0 / zx);
+        stats[1] = (float)(1.0 / zt);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) kldiv_grad_kernel(const T *x, int x_ps, const T *t, int t_ps, size_t npix, int C, int Cp, const float *stats,
+                                                         T *grad, int g_ps, float gscale) {
+    const float izx = stats[0], izt = stats[1];
+    const size_t total = npix * Cp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cp;
+        const int c = (int)(i % Cp);
+        float g = 0.f;                                            // padded channels: clean zeros for the vector kernels downstream
+        if (c < C) g = gscale * (expf(load1<T>(x + p * x_ps + c)) * izx - expf(load1<T>(t + p * t_ps + c)) * izt);
+        store1<T>(grad + p * g_ps + c, g);
+    }
+}
+extern "C" int dl_kldiv(int dtype, const void *x, int x_ps, const void *t, int t_ps, int64_t npix, int C, int Cp, float *loss_out, float out_scale,
+                        int accumulate, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !t || !loss_out || !ws || C <= 0 || C > Cp || npix <= 0) DL_FAIL("dl_kldiv: bad argument");
+    if (dtype != DL_F32 && dtype != DL_BF16) DL_FAIL("dl_kldiv: dtype %d", dtype);
+    float *stats = ws + 3 * LOSS_BLOCKS;
+    if (dtype == DL_F32) hipLaunchKernelGGL(kldiv_partial_kernel<float>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, (const float *)x, x_ps, (const float *)t, t_ps, (size_t)npix, C, ws);
+    else hipLaunchKernelGGL(kldiv_partial_kernel<bf16_t>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, (const bf16_t *)x, x_ps, (const bf16_t *)t, t_ps, (size_t)npix, C, ws);
+    DL_CHECK_LAUNCH("dl_kldiv");
+    hipLaunchKernelGGL(kldiv_final_kernel, dim3(1), dim3(64), 0, stream, ws, stats, loss_out, out_scale, accumulate);
+    DL_CHECK_LAUNCH("dl_kldiv(final)");
+    if (grad) {
+        if (dtype == DL_F32) hipLaunchKernelGGL(kldiv_grad_kernel<float>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, (const float *)x, x_ps, (const float *)t, t_ps, (size_t)npix, C, Cp, stats, (float *)grad, g_ps, gscale);
+        else hipLaunchKernelGGL(kldiv_grad_kernel<bf16_t>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, (const bf16_t *)x, x_ps, (const bf16_t *)t, t_ps, (size_t)npix, C, Cp, stats, (bf16_t *)grad, g_ps, gscale);
+        DL_CHECK_LAUNCH("dl_kldiv(grad)");
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- 2x2 max pooling (VGG19 features)
 // nn.MaxPool2d(kernel_size=2, stride=2): y[n,ho,wo,c] = max over the 2x2 window; backward routes dy to the FIRST maximum of the window in
 // row-major window order (ATen's rule), everything else gets 0 (including a trailing odd row / column).  One thread = one window x 8 channels.

@@ -659,6 +659,19 @@ def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: fl
         ctx.tape.record(backward)
 
 
+def kldiv_op(ctx: Ctx, x: Act, teacher: Act, weight: float, loss_out: torch.Tensor) -> None:
+    """DeepLIIFKD_model.py:313-336: loss_out[0] = KLDivLoss(batchmean)(LogSoftmax(x.view(1,1,-1)), Softmax(teacher.view(1,1,-1))) (unweighted, as the
+    reference logs it); if x needs grad, d(weight * loss)/dx = weight * (softmax(x) - softmax(teacher)) is queued.  The teacher gets no gradient."""
+    be = ops.impl()
+    needs = ctx.tape is not None and x.needs_grad
+    grad = empty_like_act(x.t) if needs else None
+    be.kldiv(x.t, teacher.t, x.C, loss_out, grad, weight)
+    if needs:
+        def backward():
+            x.add_grad(grad)
+        ctx.tape.record(backward)
+
+
 def to_engine(x_nchw: torch.Tensor, prec: Precision) -> Act:
     """NCHW fp32 (the reference's tensors) -> engine NHWC with padded channels."""
     x = x_nchw.detach().contiguous().float()

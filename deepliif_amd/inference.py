@@ -129,6 +129,8 @@ def generator_names(opt):
     M = opt.modalities_no
     if _get(opt, 'model', 'DeepLIIF') in ('DeepLIIFExt', 'SDG'):
         return [f'G_{i + 1}' for i in range(M)], ([f'GS_{i + 1}' for i in range(M)] if opt.seg_gen else [])
+    if _get(opt, 'model', 'DeepLIIF') == 'CycleGAN':          # one direction only (models/__init__.py:193-197)
+        return [f'{"GB" if _get(opt, "BtoA", False) else "GA"}_{i + 1}' for i in range(M)], []
     S, off = _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
     g = [f'G{i + 1}' for i in range(M)]
     gs = [f'G{S}{off + i}' for i in range(M + 1)] if opt.seg_gen else []
@@ -146,8 +148,11 @@ def build_generators(opt, device, precision: Optional[str] = None) -> 'OrderedDi
     model = _get(opt, 'model', 'DeepLIIF')
     cin = opt.input_nc * (_get(opt, 'input_no', 1) if model != 'DeepLIIFExt' else 1)
     cin_s = opt.input_nc * 3 if model in ('DeepLIIFExt', 'SDG') else cin          # GS_i(cat(A, fake_1, fake_i)), DeepLIIFExt_model.py:85,173
+    cout = opt.output_nc
+    if model == 'CycleGAN' and _get(opt, 'BtoA', False):       # GB_i: B -> A (CycleGAN_model.py:82-85)
+        cin, cout = opt.output_nc, opt.input_nc
     for n, arch in zip(g, net_g):
-        nets[n] = networks.define_G(cin, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids, opt.padding)
+        nets[n] = networks.define_G(cin, cout, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids, opt.padding)
     for n, arch in zip(gs, net_gs):
         nets[n] = networks.define_G(cin_s, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids)
     for net in nets.values():
@@ -260,21 +265,26 @@ def _seg_weight_map(opt, seg_weights):
 def _wrapper_flags(opt, seg_only, mod_only):
     """run_wrapper forwards seg_only / mod_only to the generator DAG only for DeepLIIF / DeepLIIFKD; for DeepLIIFExt / SDG it calls
     run_fn(tile, model_path, None, eager_mode, opt) (deepliif/models/__init__.py:446-452), so their tiled inference always produces GS_i"""
-    if _get(opt, 'model', 'DeepLIIF') in ('DeepLIIFExt', 'SDG'):
+    if _get(opt, 'model', 'DeepLIIF') in ('DeepLIIFExt', 'SDG', 'CycleGAN'):
         return False, False
     return seg_only, mod_only
 
 
-def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None) -> 'OrderedDict[str, E.Act]':
+def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None, per_sample_norm=True) -> 'OrderedDict[str, E.Act]':
     """The generator DAG of run_dask (deepliif/models/__init__.py:293-388) on a batch of tiles in ENGINE layout, outputs in engine
     layout, keys and key ORDER as the reference's result dict.
       DeepLIIF / DeepLIIFKD (:293-361): G_i(tile); GS_0(tile); GS_i(G_i(tile)); seg = sum_k w_k * seg_k
-      DeepLIIFExt / SDG     (:362-388): G_i(tile); GS_i(cat(tile, G_1(tile), G_i(tile)))"""
+      DeepLIIFExt / SDG     (:362-388): G_i(tile); GS_i(cat(tile, G_1(tile), G_i(tile)))
+      CycleGAN              (:362-372): GA_i(tile)  (GB_i with opt.BtoA)
+    per_sample_norm: every tile normalised with its own statistics (= the reference's one-tile-at-a-time calls); False = the statistics of the
+    whole batch, which is what a batched call of the reference's nets computes (the DeepLIIFKD teacher on a training batch)."""
     first = next(iter(nets.values()))
     prec = E.Precision.get(first.precision)
-    ctx = E.Ctx(prec, None, training=False, per_sample_norm=True)
+    ctx = E.Ctx(prec, None, training=False, per_sample_norm=per_sample_norm)
     model = _get(opt, 'model', 'DeepLIIF')
     M = opt.modalities_no
+    if model == 'CycleGAN':
+        return OrderedDict((k, nets[k].run(ctx, x)) for k in generator_names(opt)[0])
     if model in ('DeepLIIFExt', 'SDG'):
         names = [f'G_{i}' for i in range(1, M + 1)]
         gens = OrderedDict((k, nets[k].run(ctx, x)) for k in names)
@@ -358,6 +368,8 @@ def empty_tile_colors(opt, seg_only=False, mod_only=False) -> 'OrderedDict[str, 
         res = OrderedDict((f'G_{i}', black) for i in range(1, M + 1))
         res.update((f'GS_{i}', black) for i in range(1, M + 1))
         return res
+    if model == 'CycleGAN':                                                                 # models/__init__.py:453-459: black tiles under the net names
+        return OrderedDict((k, black) for k in generator_names(opt)[0])
     if model not in ('DeepLIIF', 'DeepLIIFKD'):
         raise NotImplementedError(f'run_wrapper is not implemented for model {model}')
     S, bg = _get(opt, 'mod_id_seg', 'S'), _get(opt, 'background_colors', None)

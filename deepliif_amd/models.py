@@ -364,6 +364,7 @@ class DeepLIIFModel(BaseModel):
                 s = getattr(self, 'net' + n).run(ctx, src)
                 parts.append(s)
                 setattr(self, f'fake_B_{S}_{i}', E.from_engine(s))
+            self._fake_seg_parts = parts
             self._fake_seg = E.weighted_sum(ctx, parts, self.seg_weights[:M + 1])
             setattr(self, f'fake_B_{S}', E.from_engine(self._fake_seg))
         self._tape_G = tape
@@ -440,6 +441,7 @@ class DeepLIIFModel(BaseModel):
             # too (:408-409) but never added to loss_G (:418-421), so it is not evaluated here
             for i in range(M):
                 self.criterionVGG.run(ctx, self._fake[i], self._B[i], wG[i] * self.lambda_feat, self._vgg_buf[i:i + 1])
+        self._extra_g_terms(ctx)
         tape.backward()
         self._tape_G = None
         # the reference logs loss_G_L1 already multiplied by lambda_L1 (:398-400)
@@ -448,6 +450,9 @@ class DeepLIIFModel(BaseModel):
             self._vgg_buf *= self.lambda_feat
             for i in range(M):
                 setattr(self, f'loss_G_VGG_{i + 1}', self._vgg_buf[i])
+
+    def _extra_g_terms(self, ctx):
+        """further terms of loss_G on the generator tape, before its backward (DeepLIIFKD: the distillation terms)"""
 
     def _l1_raw(self, i):
         M, S = self.opt.modalities_no, self.mod_id_seg
@@ -710,7 +715,313 @@ class SDGModel(DeepLIIFExtModel):
         return opt.input_nc * _get(opt, 'input_no', 1)
 
 
-_MODEL_CLASSES = {'DeepLIIF': DeepLIIFModel, 'DeepLIIFExt': DeepLIIFExtModel, 'SDG': SDGModel}
+def map_model_names(model_names, mod_id_seg_source, input_id_source, mod_id_seg_target, input_id_target):
+    """deepliif/util/util.py:273-292: teacher network / image names -> the student's naming when the seg id or the input id differ."""
+    res = {}
+    for name in model_names:
+        new = name
+        if len(name) > 2 and name[1] == str(mod_id_seg_source):
+            new = name[0] + str(mod_id_seg_target) + name[2:]
+            if str(input_id_source) != str(input_id_target):
+                new = new[:2] + str(int(new[2:]) + (-1 if int(input_id_target) == 0 else 1))
+        res[name] = new
+    res['G' + str(mod_id_seg_source)] = 'G' + str(mod_id_seg_target)        # the aggregated seg image is not a network name
+    return res
+
+
+class DeepLIIFKDModel(DeepLIIFModel):
+    """deepliif/models/DeepLIIFKD_model.py: DeepLIIF (always with the seg branch; vanilla GAN loss for the modalities, lsgan for seg, :130-132)
+    distilled from a frozen TEACHER model directory (opt.model_dir_teacher, loaded through init_nets(eager_mode=True), :107-118): every student
+    image -- fake_B_i, each seg generator's output fake_B_S_i and the aggregated fake_B_S -- adds
+        10 * KLDivLoss(batchmean)(LogSoftmax(student.view(1,1,-1)), Softmax(teacher.view(1,1,-1)))        (:313-349)
+    to loss_G: ONE softmax over all N*3*H*W values of an image batch (engine.kldiv_op -> dl_kldiv).  The teacher runs in inference mode on the
+    training batch (run_dask(img=real_A, use_dask=False, output_tensor=True), :203) with its default equal seg weights; BatchNorm there
+    normalises with the statistics of the WHOLE batch (the reference's disable_batchnorm_tracking_stats + a batched call), not per sample.
+    Quirks kept: loss_names lists G_KLDiv_S{M} twice and never G_KLDiv_S0 (:36-41) although the latter enters loss_G (:342-343)."""
+
+    FACTOR_KLDIV = 10.0
+
+    def __init__(self, opt):
+        opt.seg_gen = True                          # DeepLIIFKD_model.py builds the seg generators unconditionally (:55-60, 95-98)
+        if getattr(opt, 'netG', None) is None and hasattr(opt, 'net_g'):
+            opt.netG = opt.net_g
+        gm, gms = _get(opt, 'gan_mode', 'vanilla'), _get(opt, 'gan_mode_s', 'lsgan')
+        opt.gan_mode, opt.gan_mode_s = 'vanilla', 'lsgan'          # criterionGAN_BCE / criterionGAN_lsgan are fixed (:130-131)
+        super().__init__(opt)
+        opt.gan_mode, opt.gan_mode_s = gm, gms
+        M, S = opt.modalities_no, self.mod_id_seg
+        # ---- names (:33-45): per modality ..., G_KLDiv_i, G_KLDiv_S{i}; then the seg names, G_KLDiv_S and (again) G_KLDiv_S{M}
+        self.loss_names = []
+        self.visual_names = ['real_A']
+        for i in range(1, M + 1):
+            self.loss_names += [f'G_GAN_{i}', f'G_L1_{i}', f'D_real_{i}', f'D_fake_{i}', f'G_KLDiv_{i}', f'G_KLDiv_{S}{i}']
+            self.visual_names += [f'fake_B_{i}', f'fake_B_{i}_teacher', f'real_B_{i}']
+        self.loss_names += [f'G_GAN_{S}', f'G_L1_{S}', f'D_real_{S}', f'D_fake_{S}', f'G_KLDiv_{S}', f'G_KLDiv_{S}{M}']
+        for i in range(M + 1):
+            self.visual_names += [f'fake_B_{S}{i}', f'fake_B_{S}{i}_teacher']
+        self.visual_names += [f'fake_B_{S}', f'fake_B_{S}_teacher', f'real_B_{S}']
+        slots = list(OrderedDict.fromkeys(self.loss_names + [f'G_KLDiv_{S}0']))      # + the term that is computed but never listed
+        self._loss_index = {n: i for i, n in enumerate(slots)}
+        self._loss_buf = torch.zeros(len(slots), dtype=torch.float32, device=self.device)
+        for n, i in self._loss_index.items():
+            setattr(self, 'loss_' + n, self._loss_buf[i])
+        if hasattr(self, '_l1_slots_cache'):
+            del self._l1_slots_cache
+        if not self.is_train:
+            self.visual_names = [n for n in self.visual_names if not n.endswith('_teacher')]
+            return
+        if self.input_id != '0':
+            # the reference's own loss_G reads loss_G_KLDiv_{S}{M+1}, which backward_G never computes (:323-324, 344-345): only input_id '0' trains
+            raise NotImplementedError("DeepLIIFKD trains with input_id '0' only (the reference's backward_G fails for other ids)")
+        from . import inference as I
+        tdir = opt.model_dir_teacher
+        self.opt_teacher = I.get_opt(tdir, mode='test')
+        self.opt_teacher.gpu_ids = opt.gpu_ids                       # use the student's device (:110)
+        self.opt_teacher.precision = self.precision.name             # same storage type: the distillation kernel reads both tensors
+        self.nets_teacher = I.init_nets(tdir, eager_mode=True, opt=self.opt_teacher, phase='test')
+        t_seg, t_in = _get(self.opt_teacher, 'mod_id_seg', 'S'), str(_get(self.opt_teacher, 'input_id', '0'))
+        self.opt_teacher.mod_id_seg, self.opt_teacher.input_id = t_seg, t_in
+        self.d_mapping_model_name = map_model_names(list(self.nets_teacher.keys()), t_seg, t_in, S, self.input_id)
+        print('Model name mapping, teacher model to student model:', self.d_mapping_model_name)
+
+    def _teacher_attr(self, key):
+        """:205-214: teacher result key -> 'fake_B_<suffix>_teacher' (the characters of the mapped name joined by '_': 'GS1' -> 'S_1')"""
+        suffix = list(self.d_mapping_model_name[key][1:])
+        if suffix[0] == str(self.opt_teacher.mod_id_seg) and suffix[0] != str(self.mod_id_seg):
+            suffix[0] = str(self.mod_id_seg)
+        return 'fake_B_' + '_'.join(suffix) + '_teacher'
+
+    def forward(self, record: Optional[bool] = None):
+        super().forward(record)
+        if self.is_train:
+            from . import inference as I
+            res = I.run_generators_engine(self._A, self.nets_teacher, self.opt_teacher, per_sample_norm=False)
+            self._teacher = {}
+            for k, v in res.items():
+                name = self._teacher_attr(k)
+                self._teacher[name] = v
+                setattr(self, name, E.from_engine(v))
+
+    def _extra_g_terms(self, ctx):
+        M, S, f = self.opt.modalities_no, self.mod_id_seg, self.FACTOR_KLDIV
+        slot = lambda n: self._loss_buf[self._loss_index[n]].view(1)
+        for i in range(M):
+            E.kldiv_op(ctx, self._fake[i], self._teacher[f'fake_B_{i + 1}_teacher'], f, slot(f'G_KLDiv_{i + 1}'))
+        E.kldiv_op(ctx, self._fake_seg, self._teacher[f'fake_B_{S}_teacher'], f, slot(f'G_KLDiv_{S}'))
+        for i in range(M + 1):                       # i = 0 (base input) enters loss_G through the input_id == '0' branch (:342-343)
+            E.kldiv_op(ctx, self._fake_seg_parts[i], self._teacher[f'fake_B_{S}_{i}_teacher'], f, slot(f'G_KLDiv_{S}{i}'))
+
+
+class ImagePool:
+    """deepliif/util/image_pool.py: history of generated images for the CycleGAN discriminators.  Same decisions from the same `random`
+    stream (one uniform per image once the pool is full, one randint when it swaps), on per-sample engine tensors."""
+
+    def __init__(self, pool_size):
+        self.pool_size = pool_size
+        self.num_imgs = 0
+        self.images: List[torch.Tensor] = []
+
+    def query(self, a: E.Act) -> E.Act:
+        import random
+        if self.pool_size == 0:
+            return a.detach()
+        out = []
+        for j in range(a.t.shape[0]):
+            img = a.t[j:j + 1]
+            if self.num_imgs < self.pool_size:
+                self.num_imgs += 1
+                self.images.append(img.clone())
+                out.append(img)
+            elif random.uniform(0, 1) > 0.5:
+                k = random.randint(0, self.pool_size - 1)
+                out.append(self.images[k])
+                self.images[k] = img.clone()
+            else:
+                out.append(img)
+        return E.Act(torch.cat(out, 0), a.C, False)
+
+
+class CycleGANModel(BaseModel):
+    """deepliif/models/CycleGAN_model.py: per modality i two generators GA_i: A -> B_i, GB_i: B_i -> A and two UNCONDITIONAL discriminators
+    DA_i (on B_i images), DB_i (on A images).  One step (:266-282): forward (fake_B = GA(A), rec_A = GB(fake_B), fake_A = GB(B), rec_B = GA(fake_A)),
+    the GENERATOR update first -- loss_G = sum_i w_i [GAN(DA_i(fake_B_i)) + VGG(fake_B_i, B_i) + GAN(DB_i(fake_A_i)) + VGG(fake_A_i, A)]
+    + 10/M sum_i [L1(rec_A_i, A) + L1(rec_B_i, B_i)], identity terms off (:207-208, 213) -- then the discriminators on the pooled, detached fakes,
+    one backward per discriminator of (real + fake) * 0.5 * w_i (:172-205).  Every generator runs TWICE on the generator tape.
+    The VGG term carries no lambda here (:232, 238): it needs the weight file like everywhere else (BaseModel._make_vgg rules)."""
+
+    LAMBDA_A = LAMBDA_B = 10.0
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        M = self.mod_gen_no = opt.modalities_no
+        if not hasattr(opt, 'upsample'):
+            opt.upsample = 'convtranspose'
+        if not hasattr(opt, 'label_smoothing'):
+            opt.label_smoothing = 0
+        self.loss_G_weights, self.loss_D_weights = list(opt.loss_G_weights), list(opt.loss_D_weights)
+        self.loss_cyc_weights = [1 / M] * M
+        opt.lambda_identity = 0
+        self.loss_names = ['D_A', 'G_A', 'cycle_A', 'idt_A', 'D_B', 'G_B', 'cycle_B', 'idt_B']
+        suf = range(1, M + 1)
+        self.visual_names = [f'real_As_{i}' for i in suf] + [f'fake_Bs_{i}' for i in suf] + [f'rec_As_{i}' for i in suf] + \
+                            [f'real_Bs_{i}' for i in suf] + [f'fake_As_{i}' for i in suf] + [f'rec_Bs_{i}' for i in suf]
+        btoa = _get(opt, 'BtoA', False)
+        if self.is_train:
+            self.model_names = [f'GA_{i}' for i in suf] + [f'GB_{i}' for i in suf] + [f'DA_{i}' for i in suf] + [f'DB_{i}' for i in suf]
+        else:
+            self.model_names = [f'GB_{i}' for i in suf] if btoa else [f'GA_{i}' for i in suf]
+        net_g = opt.net_g if isinstance(opt.net_g, (list, tuple)) else [opt.net_g] * M
+        opt.net_g = list(net_g)
+        use_dropout = not _get(opt, 'no_dropout', True)
+        gpu = self._net_gpu_ids()
+        self.netGA, self.netGB, self.netDA, self.netDB = [], [], [], []
+        for i in range(M):                       # construction order = the reference's (:77-85), so a seeded init draws the same weights
+            if self.is_train or not btoa:
+                self.netGA.append(networks.define_G(opt.input_nc, opt.output_nc, opt.ngf, net_g[i], opt.norm, use_dropout, opt.init_type, opt.init_gain,
+                                                    gpu, opt.padding, opt.upsample))
+            if self.is_train or btoa:
+                self.netGB.append(networks.define_G(opt.output_nc, opt.input_nc, opt.ngf, net_g[i], opt.norm, use_dropout, opt.init_type, opt.init_gain,
+                                                    gpu, opt.padding, opt.upsample))
+        if self.is_train:
+            nl, nd = _get(opt, 'n_layers_D', 4), _get(opt, 'net_d', 'n_layers')
+            for i in range(M):
+                self.netDA.append(networks.define_D(opt.output_nc, opt.ndf, nd, nl, opt.norm, opt.init_type, opt.init_gain, gpu))
+                self.netDB.append(networks.define_D(opt.input_nc, opt.ndf, nd, nl, opt.norm, opt.init_type, opt.init_gain, gpu))
+        for _, net in self._nets():
+            net.set_precision(self.precision.name)
+        self._loss_index = {n: i for i, n in enumerate(self.loss_names)}
+        self._loss_buf = torch.zeros(len(self.loss_names), dtype=torch.float32, device=self.device)
+        for n, i in self._loss_index.items():
+            setattr(self, 'loss_' + n, self._loss_buf[i])
+        if self.is_train:
+            self.fake_A_pools = [ImagePool(_get(opt, 'pool_size', 50)) for _ in range(M)]
+            self.fake_B_pools = [ImagePool(_get(opt, 'pool_size', 50)) for _ in range(M)]
+            self.criterionGAN = networks.GANLoss(_get(opt, 'gan_mode', 'lsgan'), label_smoothing=opt.label_smoothing).to(self.device)
+            self.criterionVGG = self._make_cycle_vgg(opt)
+            params_g = [p for net in self.netGA + self.netGB for p in net.parameters()]
+            params_d = [p for net in self.netDA + self.netDB for p in net.parameters()]
+            OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
+            try:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g, betas=(opt.beta1, 0.999))
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d, betas=(opt.beta1, 0.999))
+            except TypeError:
+                self.optimizer_G = OptCls(params_g, lr=opt.lr_g)
+                self.optimizer_D = OptCls(params_d, lr=opt.lr_d)
+            self.optimizers += [self.optimizer_G, self.optimizer_D]
+            self.exchange = GradExchanger()
+        self._tape_G = None
+
+    def _make_cycle_vgg(self, opt):
+        path = networks.vgg_weights_path(opt)
+        if path:
+            return networks.VGGLoss(path, self.device, self.precision.name)
+        if _get(opt, 'allow_no_vgg', False) or os.environ.get('DEEPLIIF_AMD_ALLOW_NO_VGG') == '1':
+            print('deepliif_amd: CycleGAN without a VGG19 weight file: training WITHOUT the perceptual term (explicit opt-out)')
+            return None
+        raise RuntimeError('CycleGAN_model.py:232,238 adds the VGG19 perceptual loss to both generator terms, which needs torchvision\'s pretrained vgg19 '
+                           'weights; pass them as a file (opt.vgg_weights or DEEPLIIF_VGG19_WEIGHTS=/path/vgg19.pth) or opt out with opt.allow_no_vgg / '
+                           'DEEPLIIF_AMD_ALLOW_NO_VGG=1')
+
+    def set_input(self, input):
+        """CycleGAN_model.py:148-159: dict{'A': Tensor, 'Bs': list[Tensor], 'A_paths'}"""
+        M, p = self.mod_gen_no, self.precision
+        self.real_As = [input['A'].to(self.device) for _ in range(M)]
+        self.real_Bs = [x.to(self.device) for x in input['Bs']]
+        self.image_paths = input.get('A_paths', [])
+        self._A = E.to_engine(self.real_As[0], p)
+        self._Bs = [E.to_engine(b, p) for b in self.real_Bs]
+        for i in range(M):
+            setattr(self, f'real_As_{i + 1}', self.real_As[i])
+            setattr(self, f'real_Bs_{i + 1}', self.real_Bs[i])
+
+    def forward(self, record: Optional[bool] = None):
+        """CycleGAN_model.py:161-170; with only one direction loaded (test time) the other lists stay empty"""
+        record = self.is_train if record is None else record
+        tape = E.Tape() if record else None
+        ctx = E.Ctx(self.precision, self._hook_tape(tape), training=record)
+        for net in self.netGA + self.netGB:            # every generator runs twice below: mark before the first use
+            self._mark_net(tape, net)
+        self._fake_B = [net.run(ctx, self._A) for net in self.netGA]
+        self._rec_A = [net.run(ctx, f) for net, f in zip(self.netGB, self._fake_B)]
+        self._fake_A = [net.run(ctx, b) for net, b in zip(self.netGB, self._Bs)]
+        self._rec_B = [net.run(ctx, f) for net, f in zip(self.netGA, self._fake_A)]
+        for fam, acts in (('fake_Bs', self._fake_B), ('rec_As', self._rec_A), ('fake_As', self._fake_A), ('rec_Bs', self._rec_B)):
+            ts = [E.from_engine(a) for a in acts]
+            setattr(self, fam, ts)
+            for i, t in enumerate(ts):
+                setattr(self, f'{fam}_{i + 1}', t)
+        self._tape_G = tape
+
+    def _slot(self, name):
+        return self._loss_buf[self._loss_index[name]].view(1)
+
+    def backward_G(self):
+        """CycleGAN_model.py:207-264"""
+        tape = self._tape_G
+        assert tape is not None, 'forward() must run in training mode before backward_G()'
+        ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
+        cg, wG, cyc = self.criterionGAN, self.loss_G_weights, self.loss_cyc_weights
+        self._loss_buf.zero_()
+        for i in range(self.mod_gen_no):
+            E.loss_op(ctx, cg.kind, self.netDA[i].run(ctx, self._fake_B[i]), None, cg.target(True), wG[i], self._slot('G_A'), wG[i], True)
+            if self.criterionVGG is not None:
+                self.criterionVGG.run(ctx, self._fake_B[i], self._Bs[i], wG[i], self._slot('G_A'), wG[i], True)
+        for i in range(self.mod_gen_no):
+            E.loss_op(ctx, cg.kind, self.netDB[i].run(ctx, self._fake_A[i]), None, cg.target(True), wG[i], self._slot('G_B'), wG[i], True)
+            if self.criterionVGG is not None:
+                self.criterionVGG.run(ctx, self._fake_A[i], self._A, wG[i], self._slot('G_B'), wG[i], True)
+        for i in range(self.mod_gen_no):
+            w = self.LAMBDA_A * cyc[i]
+            E.loss_op(ctx, L.LOSS_L1, self._rec_A[i], self._A, 0.0, w, self._slot('cycle_A'), w, True)
+        for i in range(self.mod_gen_no):
+            w = self.LAMBDA_B * cyc[i]
+            E.loss_op(ctx, L.LOSS_L1, self._rec_B[i], self._Bs[i], 0.0, w, self._slot('cycle_B'), w, True)
+        tape.backward()
+        self._tape_G = None
+
+    def _backward_D_family(self, nets, reals, fakes, slot):
+        """backward_D_basic per discriminator (:172-191): (GAN(D(real), True) + GAN(D(fake.detach()), False)) * 0.5 * loss_D_weights[i]"""
+        cg = self.criterionGAN
+        for i, (net, real, fake) in enumerate(zip(nets, reals, fakes)):
+            tape = E.Tape()
+            ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
+            self._mark_net(tape, net)
+            w = 0.5 * self.loss_D_weights[i]
+            E.loss_op(ctx, cg.kind, net.run(ctx, real), None, cg.target(True), w, slot, w, True)
+            E.loss_op(ctx, cg.kind, net.run(ctx, fake), None, cg.target(False), w, slot, w, True)
+            tape.backward()
+
+    def backward_D_A(self):
+        fakes = [pool.query(f) for pool, f in zip(self.fake_B_pools, self._fake_B)]
+        self._backward_D_family(self.netDA, self._Bs, fakes, self._slot('D_A'))
+
+    def backward_D_B(self):
+        fakes = [pool.query(f) for pool, f in zip(self.fake_A_pools, self._fake_A)]
+        self._backward_D_family(self.netDB, [self._A] * self.mod_gen_no, fakes, self._slot('D_B'))
+
+    def _d_nets(self):
+        return self.netDA + self.netDB
+
+    def optimize_parameters(self):
+        """CycleGAN_model.py:266-282: generators first, then both discriminator families"""
+        self._sync_replicas()
+        self.forward()
+        self.set_requires_grad(self._d_nets(), False)
+        self.optimizer_G.zero_grad()
+        self.exchange.begin(self.optimizer_G)
+        self.backward_G()
+        self.exchange.finish(self.optimizer_G)
+        self.optimizer_G.step()
+        self.set_requires_grad(self._d_nets(), True)
+        self.optimizer_D.zero_grad()
+        self.exchange.begin(self.optimizer_D)
+        self.backward_D_A()
+        self.backward_D_B()
+        self.exchange.finish(self.optimizer_D)
+        self.optimizer_D.step()
+
+
+_MODEL_CLASSES = {'DeepLIIF': DeepLIIFModel, 'DeepLIIFExt': DeepLIIFExtModel, 'SDG': SDGModel, 'DeepLIIFKD': DeepLIIFKDModel, 'CycleGAN': CycleGANModel}
 
 
 def create_model(opt):

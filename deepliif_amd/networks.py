@@ -665,12 +665,13 @@ class VGGLoss(nn.Module):
             sd = torch.load(weights_path, map_location='cpu')
             self.vgg.load_torchvision_state_dict(sd.get('state_dict', sd) if isinstance(sd, dict) else sd)
 
-    def run(self, ctx: E.Ctx, x: E.Act, y: E.Act, weight: float, loss_out: torch.Tensor):
-        """loss_out[0] = the VGG loss (unweighted); queues d(weight * loss)/dx on the tape.  The target features carry no gradient."""
+    def run(self, ctx: E.Ctx, x: E.Act, y: E.Act, weight: float, loss_out: torch.Tensor, out_scale: float = 1.0, accumulate: bool = False):
+        """loss_out[0] (+)= out_scale * the VGG loss (unweighted by `weight`); queues d(weight * loss)/dx on the tape.  The target features carry
+        no gradient."""
         fy = self.vgg.run(E.Ctx(ctx.prec, None, training=False), y.detach())
         fx = self.vgg.run(ctx, x)
         for i, (a, b) in enumerate(zip(fx, fy)):
-            E.loss_op(ctx, L.LOSS_L1, a, b, 0.0, weight * self.weights[i], loss_out, out_scale=self.weights[i], accumulate=i > 0)
+            E.loss_op(ctx, L.LOSS_L1, a, b, 0.0, weight * self.weights[i], loss_out, out_scale=out_scale * self.weights[i], accumulate=accumulate or i > 0)
 
 
 def vgg_weights_path(opt):

@@ -471,6 +471,15 @@ class HipBackend:
                                      float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale), 1 if accumulate else 0, _ptr(grad),
                                      pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss_acc')
 
+    def kldiv(self, x, t, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
+        """loss_out[0] (+)= out_scale * KL(softmax(t) || softmax(x)) over ALL real elements (DeepLIIFKD_model.py:313-336); grad = grad_scale * (softmax(x) - softmax(t))"""
+        _need_cuda(x, t, loss_out, grad)
+        assert x.shape == t.shape and x.dtype == t.dtype
+        npix = x.shape[0] * x.shape[1] * x.shape[2]
+        ws = WS.get('kldiv_ws', self.lib.dl_kldiv_ws_floats(), x.device)
+        L.check(self.lib.dl_kldiv(dl_dtype(x), _ptr(x), pstride(x), _ptr(t), pstride(t), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale),
+                                  1 if accumulate else 0, _ptr(grad), pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_kldiv')
+
     # ---- 2x2 max pooling (VGG19 features)
     def maxpool2_forward(self, x, y):
         _need_cuda(x, y)

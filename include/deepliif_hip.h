@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 106
+#define DL_VERSION 107
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -291,6 +291,14 @@ int dl_loss(int kind, int dtype, const void *x, int x_pstride, const void *targe
 int dl_loss_acc(int kind, int dtype, const void *x, int x_pstride, const void *target, int t_pstride, float target_const,
                 int64_t npix, int C, int Cp, float *loss_out, float out_scale, int accumulate, void *grad, int g_pstride, float grad_scale,
                 float *ws, void *stream);
+
+/* DeepLIIFKD's distillation term (DeepLIIFKD_model.py:313-336): KLDivLoss(reduction='batchmean') between LogSoftmax(x.view(1, 1, -1)) and
+ * Softmax(t.view(1, 1, -1)) -- ONE softmax over all npix * C real elements of each tensor:  KL = sum_j p_j (log p_j - log q_j), p = softmax(t),
+ * q = softmax(x).  loss_out[0] = (accumulate ? loss_out[0] : 0) + out_scale * KL;  grad (may be NULL) = grad_scale * (q - p), padded channels 0.
+ * Inputs are generator outputs (|x|, |t| <= 1): the exponentials are taken without a running maximum.  ws: dl_kldiv_ws_floats() floats. */
+size_t dl_kldiv_ws_floats(void);
+int dl_kldiv(int dtype, const void *x, int x_pstride, const void *t, int t_pstride, int64_t npix, int C, int Cp,
+             float *loss_out, float out_scale, int accumulate, void *grad, int g_pstride, float grad_scale, float *ws, void *stream);
 
 /* nn.MaxPool2d(kernel_size=2, stride=2) of torchvision's VGG19 `features` (networks.py:698-731 slices them): y [N, H/2, W/2, Cp];
  * backward routes dy to the first maximum of each window in row-major window order (ATen's tie rule) and zeroes everything else. */

@@ -720,3 +720,159 @@ class OracleSDG(OracleDeepLIIFExt):
         for i in range(self.cfg.modalities_no):
             out[f'G_VGG_{i + 1}'] = 0.0
         return out
+
+
+# ----------------------------------------------------------------------------------------------
+# DeepLIIFKD: DeepLIIF distilled from a frozen teacher  (deepliif/models/DeepLIIFKD_model.py)
+# ----------------------------------------------------------------------------------------------
+def kldiv_whole_tensor(x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """KLDivLoss(reduction='batchmean')(LogSoftmax(dim=-1)(x.view(1, 1, -1)), Softmax(dim=-1)(t.view(1, 1, -1)))  (DeepLIIFKD_model.py:148-151,
+    313-336): ONE softmax over all elements of each tensor; 'batchmean' divides by the size of the view's first dimension, which is 1.
+    KL(p || q) = sum_j p_j (log p_j - log q_j) with p = softmax(t), q = softmax(x)."""
+    lq = torch.log_softmax(x.reshape(-1), 0)
+    lp = torch.log_softmax(t.reshape(-1), 0)
+    return (lp.exp() * (lp - lq)).sum()
+
+
+class OracleDeepLIIFKD(OracleDeepLIIF):
+    """Functional DeepLIIFKDModel: OracleDeepLIIF with the seg branch, vanilla / lsgan GAN losses (:130-131), plus the distillation terms
+    (:313-349): 10 * KL for every modality image, every seg generator's image and the aggregated seg image, against a frozen teacher that is run
+    like run_dask(img=real_A, nets=teacher, use_dask=False, output_tensor=True) (:203): G_i(A), GS_0(A), GS_i(G_i(A)), seg = mean of the seg
+    images (run_dask's default weights 1/(M+1), models/__init__.py:310), BatchNorm on the statistics of the batch, nothing updated."""
+
+    def __init__(self, cfg: OracleConfig, nets, teacher_cfg: OracleConfig, teacher_nets, train_bn_running: bool = True, vgg_sd=None):
+        assert cfg.seg_gen and teacher_cfg.seg_gen
+        cfg.gan_mode, cfg.gan_mode_s = 'vanilla', 'lsgan'
+        super().__init__(cfg, nets, train_bn_running, vgg_sd)
+        self.tcfg, self.tnets = teacher_cfg, teacher_nets
+
+    def forward(self):
+        super().forward()
+        tc = self.tcfg
+        tg, tgs, _, _ = tc.names()
+        with torch.no_grad():
+            self.teacher_B = [run_generator(tc.net_g, self.tnets[n], self.real_A, tc.norm, tc.padding, False) for n in tg]
+            parts = [run_generator(tc.net_gs, self.tnets[tgs[0]], self.real_A, tc.norm, 'reflect', False)]
+            parts += [run_generator(tc.net_gs, self.tnets[n], self.teacher_B[i], tc.norm, 'reflect', False) for i, n in enumerate(tgs[1:])]
+            self.teacher_seg_parts = parts
+            self.teacher_seg = sum(p * (1.0 / (tc.modalities_no + 1)) for p in parts)
+
+    def loss_G(self):
+        total = super().loss_G()
+        c, L = self.cfg, self.losses
+        for i in range(c.modalities_no):
+            L[f'G_KLDiv_{i + 1}'] = kldiv_whole_tensor(self.fake_B[i], self.teacher_B[i])
+        L['G_KLDiv_S'] = kldiv_whole_tensor(self.fake_seg, self.teacher_seg)
+        for i in range(c.modalities_no + 1):
+            L[f'G_KLDiv_S{i}'] = kldiv_whole_tensor(self.fake_seg_parts[i], self.teacher_seg_parts[i])
+        for i in range(c.modalities_no):
+            total = total + (L[f'G_KLDiv_{i + 1}'] + L[f'G_KLDiv_S{i + 1}']) * 10
+        return total + L['G_KLDiv_S'] * 10 + L['G_KLDiv_S0'] * 10            # input_id '0' (:342-343)
+
+
+# ----------------------------------------------------------------------------------------------
+# CycleGAN  (deepliif/models/CycleGAN_model.py, deepliif/util/image_pool.py)
+# ----------------------------------------------------------------------------------------------
+class OracleImagePool:
+    """util/image_pool.py: per image -- fill the pool first; afterwards one random.uniform decides between returning the new image and
+    swapping it against a stored one chosen by random.randint (inclusive)."""
+
+    def __init__(self, pool_size):
+        self.pool_size, self.images = pool_size, []
+
+    def query(self, images: torch.Tensor) -> torch.Tensor:
+        import random
+        if self.pool_size == 0:
+            return images
+        out = []
+        for img in images:
+            img = img.detach().unsqueeze(0)
+            if len(self.images) < self.pool_size:
+                self.images.append(img)
+                out.append(img)
+            elif random.uniform(0, 1) > 0.5:
+                k = random.randint(0, self.pool_size - 1)
+                out.append(self.images[k].clone())
+                self.images[k] = img
+            else:
+                out.append(img)
+        return torch.cat(out, 0)
+
+
+class OracleCycleGAN:
+    """Functional CycleGANModel.  nets: {'GA_i', 'GB_i', 'DA_i', 'DB_i'} reference-keyed state_dicts.  One step (:266-282): forward; generator
+    update on  sum_i w_i [lsgan(DA_i(fake_B_i), 1) + lsgan(DB_i(fake_A_i), 1)] + 10/M sum_i [L1(rec_A_i, A) + L1(rec_B_i, B_i)]  (identity terms
+    off :213; the VGG terms :232,238 only with vgg_sd); then per discriminator (lsgan(D(real), 1) + lsgan(D(pool(fake)), 0)) * 0.5 * w_i."""
+
+    def __init__(self, cfg: OracleConfig, nets, pool_size=50, gan_mode='lsgan', train_bn_running: bool = True, vgg_sd=None):
+        self.cfg, self.nets, self.gan_mode, self.vgg_sd = cfg, nets, gan_mode, vgg_sd
+        M = cfg.modalities_no
+        self.ga = [f'GA_{i + 1}' for i in range(M)]
+        self.gb = [f'GB_{i + 1}' for i in range(M)]
+        self.da = [f'DA_{i + 1}' for i in range(M)]
+        self.db = [f'DB_{i + 1}' for i in range(M)]
+        self.train_bn_running = train_bn_running
+        self.losses: Dict[str, torch.Tensor] = {}
+        self.pools_A = [OracleImagePool(pool_size) for _ in range(M)]
+        self.pools_B = [OracleImagePool(pool_size) for _ in range(M)]
+
+        def trainable(names):
+            ps = []
+            for n in names:
+                for k, v in nets[n].items():
+                    if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
+                        v.requires_grad_(True)
+                        ps.append(v)
+            return ps
+        self.params_g = trainable(self.ga + self.gb)           # optimizer_G: all GA then all GB (:124-128)
+        self.params_d = trainable(self.da + self.db)
+        self.adam_g = AdamState(self.params_g, cfg.lr_g, cfg.beta1)
+        self.adam_d = AdamState(self.params_d, cfg.lr_d, cfg.beta1)
+
+    def _G(self, name, x):
+        return run_generator(self.cfg.net_g, self.nets[name], x, self.cfg.norm, self.cfg.padding, self.train_bn_running)
+
+    def _D(self, name, x):
+        return nlayer_discriminator(self.nets[name], x, self.cfg.norm, self.cfg.n_layers_D, self.train_bn_running)
+
+    def set_input(self, batch):
+        self.real_A, self.real_Bs = batch['A'], list(batch['Bs'])
+
+    def forward(self):
+        self.fake_Bs = [self._G(n, self.real_A) for n in self.ga]
+        self.rec_As = [self._G(n, f) for n, f in zip(self.gb, self.fake_Bs)]
+        self.fake_As = [self._G(n, b) for n, b in zip(self.gb, self.real_Bs)]
+        self.rec_Bs = [self._G(n, f) for n, f in zip(self.ga, self.fake_As)]
+
+    def loss_G(self):
+        c, L, M = self.cfg, self.losses, self.cfg.modalities_no
+        w = c.loss_G_weights
+        vgg = (lambda a, b: vgg_loss(self.vgg_sd, a, b)) if self.vgg_sd is not None else (lambda a, b: 0.0)
+        L['G_A'] = sum((gan_loss(self._D(n, f), True, self.gan_mode) + vgg(f, b)) * w[i] for i, (n, f, b) in enumerate(zip(self.da, self.fake_Bs, self.real_Bs)))
+        L['G_B'] = sum((gan_loss(self._D(n, f), True, self.gan_mode) + vgg(f, self.real_A)) * w[i] for i, (n, f) in enumerate(zip(self.db, self.fake_As)))
+        L['cycle_A'] = sum((r - self.real_A).abs().mean() * 10 / M for r in self.rec_As)
+        L['cycle_B'] = sum((r - b).abs().mean() * 10 / M for r, b in zip(self.rec_Bs, self.real_Bs))
+        L['idt_A'] = L['idt_B'] = torch.zeros(())
+        return L['G_A'] + L['G_B'] + L['cycle_A'] + L['cycle_B']
+
+    def loss_D(self):
+        c, L = self.cfg, self.losses
+        fb = [p.query(f) for p, f in zip(self.pools_B, self.fake_Bs)]            # backward_D_A first (:193-199), then backward_D_B: pool order matters
+        L['D_A'] = sum((gan_loss(self._D(n, r), True, self.gan_mode) + gan_loss(self._D(n, f.detach()), False, self.gan_mode)) * 0.5 * c.loss_D_weights[i]
+                       for i, (n, r, f) in enumerate(zip(self.da, self.real_Bs, fb)))
+        fa = [p.query(f) for p, f in zip(self.pools_A, self.fake_As)]
+        L['D_B'] = sum((gan_loss(self._D(n, self.real_A), True, self.gan_mode) + gan_loss(self._D(n, f.detach()), False, self.gan_mode)) * 0.5 * c.loss_D_weights[i]
+                       for i, (n, f) in enumerate(zip(self.db, fa)))
+        return L['D_A'] + L['D_B']
+
+    def optimize_parameters(self):
+        self.forward()
+        gg = torch.autograd.grad(self.loss_G(), self.params_g)
+        self.adam_g.step(gg)
+        gd = torch.autograd.grad(self.loss_D(), self.params_d)
+        self.adam_d.step(gd)
+        self.last_grads_d, self.last_grads_g = gd, gg
+
+    def current_losses(self):
+        order = ['D_A', 'G_A', 'cycle_A', 'idt_A', 'D_B', 'G_B', 'cycle_B', 'idt_B']
+        return OrderedDict((k, float(self.losses[k].detach()) if torch.is_tensor(self.losses[k]) else float(self.losses[k])) for k in order)

@@ -354,6 +354,16 @@ class FakeBackend:
             grad.zero_()
             grad[..., :C_real] = (g * grad_scale / v.numel()).to(grad.dtype)
 
+    def kldiv(self, x, t, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
+        self._count('kldiv')
+        v, tv = x[..., :C_real].double().reshape(-1), t[..., :C_real].double().reshape(-1)
+        q, p = torch.softmax(v, 0), torch.softmax(tv, 0)
+        kl = (p * (torch.log_softmax(tv, 0) - torch.log_softmax(v, 0))).sum()
+        loss_out[0] = (loss_out[0] if accumulate else 0.0) + out_scale * kl.float()
+        if grad is not None:
+            grad.zero_()
+            grad[..., :C_real] = (grad_scale * (q - p)).reshape(x[..., :C_real].shape).to(grad.dtype)
+
     def maxpool2_forward(self, x, y):
         self._count('maxpool_fwd')
         n, h, w, c = x.shape

@@ -30,6 +30,24 @@ def build_checkpoint_dir(tmp_path, tag, nf=8):
     return d
 
 
+# the DeepLIIFKD teacher of tests/golden/step_kd_m2.npz: (network, architecture, padding of define_G), seeds 800 + index; ngf = 64 because the
+# reference's test-mode Options force it (options/__init__.py:75) and DeepLIIFKD_model.py:107-112 cannot override it
+KD_TEACHER_NETS = (('G1', 'resnet_9blocks', 'zero'), ('G2', 'resnet_9blocks', 'zero'), ('GS0', 'unet_64', 'reflect'), ('GS1', 'unet_64', 'reflect'),
+                   ('GS2', 'unet_64', 'reflect'))
+
+
+def build_kd_teacher_dir(tmp_path):
+    """<tmp>/kd_teacher: train_opt.txt of the 'dl_m2' seam case (DeepLIIF, 2 modalities + seg, unet_64 seg generators, BatchNorm) + seeded
+    generator checkpoints at ngf 64"""
+    d = os.path.join(str(tmp_path), 'kd_teacher')
+    os.makedirs(d, exist_ok=True)
+    shutil.copy(os.path.join(G, 'seam_train_opt_dl_m2.txt'), os.path.join(d, 'train_opt.txt'))
+    for j, (name, arch, pad) in enumerate(KD_TEACHER_NETS):
+        sd = O.random_state_dict(arch, 3, 3, 64, 'batch', pad, 4, generator=torch.Generator().manual_seed(800 + j))
+        torch.save(sd, os.path.join(d, f'latest_net_{name}.pth'))
+    return d
+
+
 def close_u8(got, exp, max_mismatch):
     """uint8 images produced through float -> uint8 TRUNCATION: a 1e-5 difference in the float flips a pixel that sits on an integer
     boundary, so equality is 'never more than one step apart, and only in a small fraction of the pixels'"""

