@@ -40,6 +40,7 @@ GF_PER_TILE_INFER = 1828.0
 GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 + 5 UNet-512 generators, 9 NLayerD) step
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+STRICT_PMC_FILE = os.path.join('r03', 'pmc_strict_conv256.json')     # the same passes over the strict ResnetBlock kernel (tools/gpu_r03_pmc_strict.sh)
 PMC_FILE = os.path.join('r02', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
@@ -376,6 +377,15 @@ def main():
                                   'kernel': f'{timer.kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv fwd + dgrad (fp32 storage, split-bf16 x3); timed by events around the host call',
                                   'launches_timed': len(timer.pairs), 'avg_launch_us': round(skt * 1e6, 2),
                                   'note': 'achieved = algorithmic conv flops per launch / launch time; mfma_pipe_frac counts the 3 MFMA passes the policy issues per product'}
+            try:        # HBM-side bytes per launch from the committed --pmc passes over this kernel and shape (not measured in this run)
+                with open(os.path.join(ROOT, 'profiles', STRICT_PMC_FILE)) as f:
+                    spmc = json.load(f)
+                if (n, s, args.ngf) == (8, 512, 64) and timer.kernel.split('<')[0] in spmc.get('kernel', ''):
+                    strict['roofline']['traffic'] = spmc['traffic_bytes']
+                    strict['roofline']['traffic_note'] = (f'NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same kernel and '
+                                                          f'shape (profiles/{STRICT_PMC_FILE}); algorithmic bytes {spmc["algorithmic_bytes"]}')
+            except Exception:
+                pass
         del smodel, sstep
     roofline = None
     traffic, traffic_note = None, None
