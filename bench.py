@@ -41,7 +41,7 @@ GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 +
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 STRICT_PMC_FILE = os.path.join('r03', 'pmc_strict_conv256.json')     # the same passes over the strict ResnetBlock kernel (tools/gpu_r03_pmc_strict.sh)
-PMC_FILE = os.path.join('r02', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
+PMC_FILE = os.path.join('r03', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
 def make_opt(args, device_index, M=5, seg_gen=False):

@@ -31,6 +31,7 @@ struct ConvArgs {
     int epi_old;            // DL_OLD_EPILOGUE=1: per-fragment stores instead of the LDS-transposed whole-row stores (A/B switch)
     int tiles_m, tiles_n, Mtot;
     int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
+    int k_order8;                   // the same choice for the 8-phase kernels (bf16: DL_8PH_KORDER, strict: DL_X3_KORDER)
     float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
     int stats_nchunks;
     // fused norm-backward reductions (dl_conv_forward_bnstats): y tile read next to the dz tile in the store epilogue
@@ -973,8 +974,9 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_kernel(const ConvArgs a) {
     };
 
     // K step u (counted from kt_begin) covers channels [ch, ch + BK) of tap tl: tap-major order, stateless (wave-uniform SALU)
-#define DL_STEP_TL(u) ((((kt_begin + (u)) * BK) >> a.log2Ci))
-#define DL_STEP_CH(u) ((((kt_begin + (u)) * BK) & (a.Ci - 1)))
+    // a.k_order8 (default; DL_8PH_KORDER=0 = tap-major): channel-chunk-major, as in conv_gemm_8ph_x3_kernel (conv_x3.h)
+#define DL_STEP_TL(u) (a.k_order8 ? ((kt_begin + (u)) % ntaps) : (((kt_begin + (u)) * BK) >> a.log2Ci))
+#define DL_STEP_CH(u) (a.k_order8 ? (((kt_begin + (u)) / ntaps) * BK) : (((kt_begin + (u)) * BK) & (a.Ci - 1)))
 
     f32x4_t acc[FN][FM];
 #pragma unroll
@@ -1119,6 +1121,11 @@ static int launch_conv_8ph(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
+    // channel-chunk-major K order by default (DL_8PH_KORDER=0: tap-major).  Same-box A/B (r03, two alternations): step 101.64 / 101.88 ms tap-major,
+    // 100.97 / 101.00 ms chunk-major (78.6 -> 79.2 tiles/s); isolated launches within noise (165-177 us).  r01 had measured the same idea on the
+    // one-barrier kernel as a loss inside the step; on the 8-phase kernels it is a small gain for bf16 and -2.8 % of the strict step.
+    static const char *korder = getenv("DL_8PH_KORDER");
+    a.k_order8 = (korder && korder[0] == '0') ? 0 : 1;
     constexpr size_t smem_loop = (size_t)8 * 128 * 64 * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int);
     constexpr size_t smem = smem_loop > epilogue_lds_bytes<256, 256, 2>() ? smem_loop : epilogue_lds_bytes<256, 256, 2>();
     static bool attr_set = false;

@@ -255,8 +255,11 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_x3_kernel(const ConvArgs a)
     };
 
     // K step u (counted from kt_begin) covers channels [ch, ch + KC) of tap tl: tap-major order, stateless (wave-uniform SALU)
-#define DL_X3_TL(u) ((((kt_begin + (u)) * KC) >> a.log2Ci))
-#define DL_X3_CH(u) ((((kt_begin + (u)) * KC) & (a.Ci - 1)))
+    // a.k_order8 (default for this kernel; DL_X3_KORDER=0 = tap-major): channel-chunk-major -- the taps of one 32-channel chunk back to back, so that the
+    // kernel rows re-read the halo slab while it is still in the XCD's L2 (PMC: 2.8-5.1x HBM-side read amplification in tap-major order,
+    // profiles/r03/pmc_strict_conv256.json).  Same-box A/B (r03): isolated forward 485 -> 465 us, strict step 218.0 -> 211.8 ms (two alternations)
+#define DL_X3_TL(u) (a.k_order8 ? ((kt_begin + (u)) % ntaps) : (((kt_begin + (u)) * KC) >> a.log2Ci))
+#define DL_X3_CH(u) (a.k_order8 ? (((kt_begin + (u)) / ntaps) * KC) : (((kt_begin + (u)) * KC) & (a.Ci - 1)))
 
     f32x4_t acc[FN][FM];
 #pragma unroll
@@ -531,6 +534,8 @@ static int launch_conv_8ph_x3(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
+    static const char *korder = getenv("DL_X3_KORDER");
+    a.k_order8 = (korder && korder[0] == '0') ? 0 : 1;
     constexpr size_t smem = (size_t)8 * 128 * 128 + DL_MAX_TAPS * sizeof(int);
     auto kern = conv_gemm_8ph_x3_kernel<IN_ACT, ABL, VAR>;
     static bool attr_set = false;
