@@ -230,6 +230,7 @@ def init_nets(model_dir, eager_mode=False, opt=None, phase='test'):
     for n, net in nets.items():
         load_generator_weights(net, model_dir, n, epoch, eager_mode)
     _NETS_CACHE[key] = nets
+    E.settle_gc()
     return nets
 
 

@@ -136,6 +136,7 @@ class BaseModel:
             suffix = 'iter_%d' % opt.load_iter if _get(opt, 'load_iter', 0) > 0 else opt.epoch
             self.load_networks(suffix)
         self.print_networks(_get(opt, 'verbose', False))
+        E.settle_gc()                       # the model is long-lived: keep full garbage collections from walking it (engine.settle_gc)
 
     def _net(self, name):
         # 'G_1' -> self.netG[0] (list-valued models: DeepLIIFExt/SDG, base_model.py:96-98), 'G1' -> self.netG1
