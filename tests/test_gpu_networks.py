@@ -197,6 +197,46 @@ def test_inference_golden_fixture_from_reference():
             assert e < 1e-3, (t, k, e)
 
 
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_inference_dag_replays_from_a_captured_hip_graph(precname):
+    """All launches of the engine go to torch's current HIP stream through ctypes, so torch.cuda.graph captures a whole generator DAG
+    (DESIGN 5): the replayed graph must reproduce the eager outputs bit for bit, also after the input buffer has been overwritten in place."""
+    from deepliif_amd import inference as I
+    torch.manual_seed(11)
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=2, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_64', input_no=1,
+                                modalities_names=['input1', 'mod1', 'mod2'], gpu_ids=[0])
+    nets = I.build_generators(opt, torch.device('cuda', 0), precname)
+    prec = E.Precision.get(precname)
+    x = E.to_engine(seeded_uniform((4, 3, 64, 64), 5).to(DEV), prec)
+    x2 = E.to_engine(seeded_uniform((4, 3, 64, 64), 6).to(DEV), prec)
+    run = lambda: I.run_generators_engine(x, nets, opt)
+    eager1 = {k: v.t.clone() for k, v in run().items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):             # warm-up on a side stream: grow-only scratch buffers and packed weight images exist before the capture
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in eager1:
+        assert torch.equal(out[k].t, eager1[k]), k
+    keep = x.t.clone()
+    x.t.copy_(x2.t)                           # new tiles in the captured input buffer
+    g.replay()
+    torch.cuda.synchronize()
+    replay2 = {k: v.t.clone() for k, v in out.items()}
+    eager2 = {k: v.t.clone() for k, v in run().items()}
+    torch.cuda.synchronize()
+    for k in eager2:
+        assert torch.equal(replay2[k], eager2[k]), k
+        assert not torch.equal(replay2[k], eager1[k]), k
+    x.t.copy_(keep)
+
+
 def make_opt(modalities_no, seg_gen, norm, net_gs, nf, precision):
     n = modalities_no + 1
     w = [0.25, 0.15, 0.25, 0.1, 0.25] if modalities_no == 4 else [1.0 / n] * n
