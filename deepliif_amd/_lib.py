@@ -13,7 +13,7 @@ PREC_BF16, PREC_BF16X3 = 1, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 NORM_INSTANCE, NORM_BATCH = 0, 1
-LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1 = 0, 1, 2, 3
+LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1, LOSS_LINEAR = 0, 1, 2, 3, 4
 MAX_TAPS, MAX_PHASES = 64, 4
 
 i32 = C.c_int32
@@ -99,6 +99,7 @@ SIGNATURES = {
     'dl_loss_ws_floats': (C.c_size_t, []),
     'dl_loss': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _vp, _i, _f, _vp, _vp]),
     'dl_loss_acc': (_i, [_i, _i, _vp, _i, _vp, _i, _f, _i64, _i, _i, _vp, _f, _i, _vp, _i, _f, _vp, _vp]),
+    'dl_upsample2_nearest': (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_kldiv_ws_floats': (C.c_size_t, []),
     'dl_kldiv': (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _i, _vp, _f, _i, _vp, _i, _f, _vp, _vp]),
     'dl_maxpool2_forward': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -132,8 +133,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 107:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 107 (stale build)')
+    if lib.dl_version() != 108:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 108 (stale build)')
     _lib = lib
     return lib
 

@@ -181,6 +181,55 @@ extern "C" int dl_copy_channels(int dtype, const void *src, int s_ps, int s_c0, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- nn.Upsample(scale_factor=2, mode='nearest')
+// ResnetGenerator with --upsample resize_conv (networks.py:409-415): y[n, 2h + a, 2w + b, c] = x[n, h, w, c]; backward dx = sum of the 2 x 2 block.
+// One thread = one INPUT pixel x 8 channels (16-byte accesses).
+template <typename T, int BWD>
+__global__ void __launch_bounds__(256) upsample2_kernel(const T *src, int s_ps, T *dst, int d_ps, int N, int H, int W, int Cp) {
+    const int cvec = Cp / 8;
+    const size_t total = (size_t)N * H * W * cvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cvec) * 8;
+        size_t p = i / cvec;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const size_t big = ((size_t)n * 2 * H + 2 * h) * (2 * W) + 2 * w;          // pixel (2h, 2w) of the [N, 2H, 2W] tensor
+        const size_t small_ = ((size_t)n * H + h) * W + w;
+        float v[8];
+        if (BWD) {
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Vec8<T>::load(src + (big + (size_t)(q >> 1) * 2 * W + (q & 1)) * s_ps + c8, a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += a[k];
+            }
+            Vec8<T>::store(dst + small_ * d_ps + c8, v);
+        } else {
+            Vec8<T>::load(src + small_ * s_ps + c8, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Vec8<T>::store(dst + (big + (size_t)(q >> 1) * 2 * W + (q & 1)) * d_ps + c8, v);
+        }
+    }
+}
+extern "C" int dl_upsample2_nearest(int dtype, int backward, const void *src, int s_ps, void *dst, int d_ps, int N, int H, int W, int Cp, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || s_ps % 8 || d_ps % 8) DL_FAIL("dl_upsample2_nearest: bad argument");
+    const size_t total = (size_t)N * H * W * (Cp / 8);
+    if (dtype == DL_F32) {
+        if (backward) hipLaunchKernelGGL((upsample2_kernel<float, 1>), dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)src, s_ps, (float *)dst, d_ps, N, H, W, Cp);
+        else hipLaunchKernelGGL((upsample2_kernel<float, 0>), dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const float *)src, s_ps, (float *)dst, d_ps, N, H, W, Cp);
+    } else if (dtype == DL_BF16) {
+        if (backward) hipLaunchKernelGGL((upsample2_kernel<bf16_t, 1>), dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)src, s_ps, (bf16_t *)dst, d_ps, N, H, W, Cp);
+        else hipLaunchKernelGGL((upsample2_kernel<bf16_t, 0>), dim3(EW_BLOCKS(total)), dim3(256), 0, stream, (const bf16_t *)src, s_ps, (bf16_t *)dst, d_ps, N, H, W, Cp);
+    } else DL_FAIL("dl_upsample2_nearest: dtype %d", dtype);
+    DL_CHECK_LAUNCH("dl_upsample2_nearest");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- per-channel sum over pixels
 #define CS_BLOCKS 256
 template <typename T>
@@ -273,6 +322,9 @@ __global__ void __launch_bounds__(256) loss_kernel(int kind, const T *x, int x_p
             const float d = v - t;
             l = d * d;
             g = 2.f * d;
+        } else if (kind == DL_LOSS_LINEAR) {
+            l = t * v;                                   // GANLoss('wgangp'): -mean(pred) for real, +mean(pred) for fake; the sign is the "target"
+            g = t;
         } else if (kind == DL_LOSS_L1) {
             const float d = v - t;                       // nn.L1Loss: |d|, gradient sign(d) with sign(0) = 0
             l = fabsf(d);
@@ -311,7 +363,7 @@ extern "C" int dl_loss_acc(int kind, int dtype, const void *x, int x_ps, const v
                            float *loss_out, float out_scale, int accumulate, void *grad, int g_ps, float gscale, float *ws, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !loss_out || !ws || C <= 0 || C > Cp) DL_FAIL("dl_loss: bad argument");
-    if (kind < 0 || kind > 3) DL_FAIL("dl_loss: kind %d", kind);
+    if (kind < 0 || kind > 4) DL_FAIL("dl_loss: kind %d", kind);
     const float inv = 1.0f / (float)((double)npix * C);
     if (dtype == DL_F32) hipLaunchKernelGGL(loss_kernel<float>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const float *)x, x_ps, (const float *)target, t_ps, tconst, (size_t)npix, C, inv, (float *)grad, g_ps, gscale, Cp, ws);
     else hipLaunchKernelGGL(loss_kernel<bf16_t>, dim3(LOSS_BLOCKS), dim3(256), 0, stream, kind, (const bf16_t *)x, x_ps, (const bf16_t *)target, t_ps, tconst, (size_t)npix, C, inv, (bf16_t *)grad, g_ps, gscale, Cp, ws);

@@ -674,6 +674,27 @@ def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: fl
         ctx.tape.record(backward)
 
 
+def upsample2(ctx: Ctx, x: Act) -> Act:
+    """nn.Upsample(scale_factor=2, mode='nearest') (ResnetGenerator --upsample resize_conv, networks.py:409-411)"""
+    be = ops.impl()
+    n, h, w, cp = x.t.shape
+    out = torch.empty((n, 2 * h, 2 * w, cp), dtype=x.t.dtype, device=x.t.device)
+    be.upsample2(x.t, out)
+    needs = ctx.tape is not None and x.needs_grad
+    z = Act(out, x.C, needs)
+    if needs:
+        def backward():
+            g = z.grad
+            z.grad = None
+            if g is None:
+                return
+            dx = empty_like_act(x.t)
+            be.upsample2(g, dx, backward=True)
+            x.add_grad(dx)
+        ctx.tape.record(backward)
+    return z
+
+
 def kldiv_op(ctx: Ctx, x: Act, teacher: Act, weight: float, loss_out: torch.Tensor) -> None:
     """DeepLIIFKD_model.py:313-336: loss_out[0] = KLDivLoss(batchmean)(LogSoftmax(x.view(1,1,-1)), Softmax(teacher.view(1,1,-1))) (unweighted, as the
     reference logs it); if x needs grad, d(weight * loss)/dx = weight * (softmax(x) - softmax(teacher)) is queued.  The teacher gets no gradient."""

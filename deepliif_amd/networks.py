@@ -133,8 +133,10 @@ class ResnetGenerator(EngineNet):
                  upsample='convtranspose', use_spectral_norm=False):
         assert n_blocks >= 0
         super().__init__()
-        if upsample != 'convtranspose' or use_spectral_norm:
-            raise NotImplementedError('only upsample=convtranspose without spectral norm is on the MI355X hot path')
+        if upsample not in ('convtranspose', 'resize_conv') or use_spectral_norm:
+            # 'pixel_shuffle' cannot be constructed in the reference either (networks.py:416-420 passes kernel_size to SpectralNorm: TypeError)
+            raise NotImplementedError('upsample=convtranspose | resize_conv without spectral norm are on the MI355X hot path')
+        self.upsample = upsample
         self.norm_kind = _norm_kind(norm_layer)
         self.padding_type = padding_type
         self.n_blocks = n_blocks
@@ -149,6 +151,10 @@ class ResnetGenerator(EngineNet):
             seq.append(ResnetBlock(ngf * 4, padding_type, norm_layer, use_dropout, use_bias))
         for i in range(2):
             m = 2 ** (2 - i)
+            if upsample == 'resize_conv':       # networks.py:409-415: nearest x2, ReflectionPad2d(1), Conv2d(k3, default bias)
+                seq += [nn.Upsample(scale_factor=2, mode='nearest'), nn.ReflectionPad2d(1), nn.Conv2d(ngf * m, ngf * m // 2, kernel_size=3, stride=1, padding=0),
+                        norm_layer(ngf * m // 2), nn.ReLU(True)]
+                continue
             seq += [nn.ConvTranspose2d(ngf * m, ngf * m // 2, kernel_size=3, stride=2, padding=1, output_padding=1, bias=use_bias),
                     norm_layer(ngf * m // 2), nn.ReLU(True)]
         seq.append(nn.ReflectionPad2d(3) if padding_type == 'reflect' else nn.ZeroPad2d(3))
@@ -181,6 +187,11 @@ class ResnetGenerator(EngineNet):
         b['up'] = []
         for i in range(2):
             c = ngf * 2 ** (2 - i)
+            if self.upsample == 'resize_conv':
+                b['up'].append((E.ConvLayer(ConvSpec('conv', c, c // 2, 3, 1, 1, L.PAD_REFLECT), m[idx + 2].weight, m[idx + 2].bias),
+                                _norm_binding(k, c // 2, m[idx + 3])))
+                idx += 5
+                continue
             b['up'].append((E.ConvLayer(ConvSpec('convT', c, c // 2, 3, 2, 1, out_pad=1), m[idx].weight, m[idx].bias),
                             _norm_binding(k, c // 2, m[idx + 1])))
             idx += 3
@@ -201,6 +212,8 @@ class ResnetGenerator(EngineNet):
                 r = E.dropout(ctx, r, 0.5)
             h = E.norm_act(ctx, E.conv(ctx, r, c2, stats=n2 is not None), n2, L.ACT_NONE, residual=h)
         for c, n in b['up']:
+            if self.upsample == 'resize_conv':
+                h = E.upsample2(ctx, h)
             h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU)
         return E.conv(ctx, h, b['head'], act=L.ACT_TANH)
 
@@ -533,6 +546,37 @@ class NLayerDiscriminator(EngineNet):
         return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
 
 
+class PixelDiscriminator(EngineNet):
+    """networks.py:667-696 (--net-d pixel): a 1x1 PatchGAN -- conv1x1 (bias) + LeakyReLU, conv1x1 + norm + LeakyReLU, conv1x1 -> 1 channel."""
+
+    def __init__(self, input_nc, ndf=64, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.norm_kind = _norm_kind(norm_layer)
+        use_bias = _uses_bias(norm_layer)
+        self.input_nc, self.ndf = input_nc, ndf
+        self.net = nn.Sequential(nn.Conv2d(input_nc, ndf, kernel_size=1, stride=1, padding=0), nn.LeakyReLU(0.2, True),
+                                 nn.Conv2d(ndf, ndf * 2, kernel_size=1, stride=1, padding=0, bias=use_bias), norm_layer(ndf * 2), nn.LeakyReLU(0.2, True),
+                                 nn.Conv2d(ndf * 2, 1, kernel_size=1, stride=1, padding=0, bias=use_bias))
+
+    def _bind(self):
+        m = self.net
+        return {'c0': E.ConvLayer(ConvSpec('conv', self.input_nc, self.ndf, 1, 1, 0), m[0].weight, m[0].bias),
+                'c1': (E.ConvLayer(ConvSpec('conv', self.ndf, self.ndf * 2, 1, 1, 0), m[2].weight, m[2].bias), _norm_binding(self.norm_kind, self.ndf * 2, m[3])),
+                'c2': E.ConvLayer(ConvSpec('conv', self.ndf * 2, 1, 1, 1, 0), m[5].weight, m[5].bias)}
+
+    def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
+        b = self._layers()
+        h = E.conv(ctx, x, b['c0'], act=L.ACT_LRELU)
+        c, n = b['c1']
+        h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_LRELU)
+        return E.conv(ctx, h, b['c2'])
+
+    def forward(self, x):
+        prec = E.Precision.get(self.precision)
+        ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
+        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+
+
 # -------------------------------------------------------------------------------------------------------------
 # factories / init  (networks.py:84-238)
 # -------------------------------------------------------------------------------------------------------------
@@ -591,6 +635,8 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal'
         net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer)
     elif netD == 'n_layers':
         net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer)
+    elif netD == 'pixel':
+        net = PixelDiscriminator(input_nc, ndf, norm_layer=norm_layer)
     else:
         raise NotImplementedError('Discriminator model name [%s] is not on the MI355X hot path' % netD)
     return init_net(net, init_type, init_gain, gpu_ids)
@@ -696,10 +742,14 @@ class GANLoss(nn.Module):
             self.kind = L.LOSS_MSE
         elif gan_mode == 'vanilla':
             self.kind = L.LOSS_BCE_LOGITS
+        elif gan_mode == 'wgangp':
+            self.kind = L.LOSS_LINEAR            # -mean(pred) for real, +mean(pred) for fake (networks.py:307-311); no model class adds the gradient penalty
         else:
             raise NotImplementedError('gan mode %s is not on the MI355X hot path' % gan_mode)
 
     def target(self, target_is_real: bool) -> float:
+        if self.gan_mode == 'wgangp':
+            return -1.0 if target_is_real else 1.0       # the sign dl_loss multiplies the prediction with (DL_LOSS_LINEAR)
         if target_is_real:
             return float(self.real_label) * (1 - self.label_smoothing)
         return float(self.fake_label) * self.label_smoothing

@@ -471,6 +471,16 @@ class HipBackend:
                                      float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale), 1 if accumulate else 0, _ptr(grad),
                                      pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss_acc')
 
+    def upsample2(self, src, dst, backward=False):
+        """nn.Upsample(scale_factor=2, mode='nearest') (backward=False: src [N,H,W,Cp] -> dst [N,2H,2W,Cp]) or its gradient (2 x 2 block sums)"""
+        _need_cuda(src, dst)
+        small = dst if backward else src
+        n, h, w, cp = small.shape
+        big = src if backward else dst
+        assert tuple(big.shape) == (n, 2 * h, 2 * w, cp), (big.shape, small.shape)
+        L.check(self.lib.dl_upsample2_nearest(dl_dtype(src), 1 if backward else 0, _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, cp, _stream()),
+                'dl_upsample2_nearest')
+
     def kldiv(self, x, t, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
         """loss_out[0] (+)= out_scale * KL(softmax(t) || softmax(x)) over ALL real elements (DeepLIIFKD_model.py:313-336); grad = grad_scale * (softmax(x) - softmax(t))"""
         _need_cuda(x, t, loss_out, grad)

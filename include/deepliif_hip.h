@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 107
+#define DL_VERSION 108
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -36,7 +36,8 @@ enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3,     
        DL_ACT_SIGMOID = 4 };   /* nn.Sigmoid of the attention gate (att_unet.py:100-104): elementwise entry points only (dl_act_forward / _backward) */
 enum { DL_PAD_ZERO = 0, DL_PAD_REFLECT = 1 };
 enum { DL_NORM_INSTANCE = 0, DL_NORM_BATCH = 1 };
-enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L1 = 3 };
+enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L1 = 3,
+       DL_LOSS_LINEAR = 4 };     /* target_const * x: GANLoss('wgangp') = -mean(pred) for real, +mean(pred) for fake (networks.py:307-311) */
 
 #define DL_MAX_TAPS 64
 #define DL_MAX_PHASES 4
@@ -291,6 +292,10 @@ int dl_loss(int kind, int dtype, const void *x, int x_pstride, const void *targe
 int dl_loss_acc(int kind, int dtype, const void *x, int x_pstride, const void *target, int t_pstride, float target_const,
                 int64_t npix, int C, int Cp, float *loss_out, float out_scale, int accumulate, void *grad, int g_pstride, float grad_scale,
                 float *ws, void *stream);
+
+/* nn.Upsample(scale_factor=2, mode='nearest') of ResnetGenerator's --upsample resize_conv route (networks.py:409-415).
+ * backward == 0: src [N, H, W, Cp] -> dst [N, 2H, 2W, Cp];  backward != 0: src = dL/dy [N, 2H, 2W, Cp] -> dst = dL/dx [N, H, W, Cp] (2 x 2 block sums). */
+int dl_upsample2_nearest(int dtype, int backward, const void *src, int src_pstride, void *dst, int dst_pstride, int N, int H, int W, int Cp, void *stream);
 
 /* DeepLIIFKD's distillation term (DeepLIIFKD_model.py:313-336): KLDivLoss(reduction='batchmean') between LogSoftmax(x.view(1, 1, -1)) and
  * Softmax(t.view(1, 1, -1)) -- ONE softmax over all npix * C real elements of each tensor:  KL = sum_j p_j (log p_j - log q_j), p = softmax(t),

@@ -96,7 +96,7 @@ def _pad(x, p, mode):
 # networks
 # ----------------------------------------------------------------------------------------------
 def resnet_generator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str = 'batch', padding_type: str = 'zero',
-                     n_blocks: int = 9, update_running: bool = False) -> torch.Tensor:
+                     n_blocks: int = 9, update_running: bool = False, upsample: str = 'convtranspose') -> torch.Tensor:
     """ResnetGenerator.forward, networks.py:357-450 (+ ResnetBlock :453-513), dropout off, upsample='convtranspose'.
 
     state_dict keys follow nn.Sequential indices of the reference: with no dropout
@@ -131,8 +131,15 @@ def resnet_generator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str = '
         r = _norm_from_sd(sd, f'{pre}.{n2}', r, norm, update_running)
         h = h + r
         idx += 1
-    # two ConvTranspose2d k3 s2 p1 op1 (networks.py:425-436)
+    # two ConvTranspose2d k3 s2 p1 op1 (networks.py:425-436), or with upsample='resize_conv' (:409-415)
+    # [Upsample(x2, nearest), ReflectionPad2d(1), Conv2d(k3, bias)] at model.idx .. idx+2, norm at idx+3
     for _ in range(2):
+        if upsample == 'resize_conv':
+            h = F.interpolate(h, scale_factor=2, mode='nearest')
+            h = F.conv2d(_pad(h, 1, 'reflect'), sd[f'model.{idx + 2}.weight'], sd[f'model.{idx + 2}.bias'])
+            h = torch.relu(_norm_from_sd(sd, f'model.{idx + 3}', h, norm, update_running))
+            idx += 5
+            continue
         h = F.conv_transpose2d(h, sd[f'model.{idx}.weight'], bias(f'model.{idx}.bias'), stride=2, padding=1,
                                output_padding=1)
         h = torch.relu(_norm_from_sd(sd, f'model.{idx + 1}', h, norm, update_running))
@@ -242,11 +249,27 @@ def nlayer_discriminator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str
     return F.conv2d(h, sd[f'model.{idx}.weight'], sd[f'model.{idx}.bias'], stride=1, padding=1)
 
 
+def pixel_discriminator(sd: Dict[str, torch.Tensor], x: torch.Tensor, norm: str = 'batch', update_running: bool = False) -> torch.Tensor:
+    """PixelDiscriminator.forward, networks.py:667-696: conv1x1(bias) + lrelu, conv1x1 + norm + lrelu, conv1x1 -> 1 channel."""
+    h = F.leaky_relu(F.conv2d(x, sd['net.0.weight'], sd['net.0.bias']), 0.2)
+    h = F.conv2d(h, sd['net.2.weight'], sd.get('net.2.bias'))
+    h = F.leaky_relu(_norm_from_sd(sd, 'net.3', h, norm, update_running), 0.2)
+    return F.conv2d(h, sd['net.5.weight'], sd.get('net.5.bias'))
+
+
+def run_discriminator(arch: str, sd, x, norm='batch', n_layers=4, update_running=False):
+    """define_D dispatch, networks.py:222-238."""
+    if arch == 'pixel':
+        return pixel_discriminator(sd, x, norm, update_running)
+    return nlayer_discriminator(sd, x, norm, 3 if arch == 'basic' else n_layers, update_running)
+
+
 def run_generator(arch: str, sd, x, norm='batch', padding_type='zero', update_running=False):
-    """define_G dispatch, networks.py:175-188."""
+    """define_G dispatch, networks.py:175-188.  'resnet_9blocks:resize_conv' = the same generator built with upsample='resize_conv'."""
     if arch.startswith('resnet_'):
+        arch, _, ups = arch.partition(':')
         n_blocks = int(arch.split('_')[1].replace('blocks', ''))
-        return resnet_generator(sd, x, norm, padding_type, n_blocks, update_running)
+        return resnet_generator(sd, x, norm, padding_type, n_blocks, update_running, ups or 'convtranspose')
     table = {'unet_32': 5, 'unet_64': 6, 'unet_128': 7, 'unet_256': 8, 'unet_512': 9}
     if arch in table:
         return unet_generator(sd, x, norm, table[arch], update_running)
@@ -267,6 +290,8 @@ def gan_loss(pred: torch.Tensor, target_is_real: bool, mode: str) -> torch.Tenso
         return (pred.clamp(min=0) - pred * t + torch.log1p(torch.exp(-pred.abs()))).mean()
     if mode == 'lsgan':
         return ((pred - t) ** 2).mean()
+    if mode == 'wgangp':                       # networks.py:307-311 (no gradient penalty is ever added by the model classes)
+        return -pred.mean() if target_is_real else pred.mean()
     raise NotImplementedError(mode)
 
 
@@ -334,6 +359,7 @@ def layer_table(arch: str, input_nc: int, output_nc: int = 3, nf: int = 64, norm
     use_bias = norm == 'instance'
     out = []
     if arch.startswith('resnet_'):
+        arch, _, ups = arch.partition(':')
         n_blocks = int(arch.split('_')[1].replace('blocks', ''))
         out.append(('conv', 'model.1', nf, input_nc, 7, use_bias, False)); out.append(('norm', 'model.2', nf))
         idx = 4
@@ -349,10 +375,19 @@ def layer_table(arch: str, input_nc: int, output_nc: int = 3, nf: int = 64, norm
             idx += 1
         for i in range(2):
             m = 2 ** (2 - i)
+            if ups == 'resize_conv':           # [Upsample, ReflectionPad2d(1), Conv2d(k3, bias=True), norm, ReLU] (networks.py:409-415, 434-436)
+                out.append(('conv', f'model.{idx + 2}', nf * m // 2, nf * m, 3, True, False)); out.append(('norm', f'model.{idx + 3}', nf * m // 2))
+                idx += 5
+                continue
             out.append(('conv', f'model.{idx}', nf * m // 2, nf * m, 3, use_bias, True)); out.append(('norm', f'model.{idx + 1}', nf * m // 2))
             idx += 3
         idx += 1
         out.append(('conv', f'model.{idx}', output_nc, nf, 7, True, False))
+        return out
+    if arch == 'pixel':                        # PixelDiscriminator (networks.py:684-690)
+        out.append(('conv', 'net.0', nf, input_nc, 1, True, False))
+        out.append(('conv', 'net.2', nf * 2, nf, 1, use_bias, False)); out.append(('norm', 'net.3', nf * 2))
+        out.append(('conv', 'net.5', 1, nf * 2, 1, use_bias, False))
         return out
     if arch == 'unet_512_attention':
         # att_unet.py:120-151: registration order Conv1..Conv8, Up8, Att8, Up7, Att7, ..., Up2, Att2, Up1; widths fixed; BatchNorm2d always
@@ -441,8 +476,9 @@ class OracleConfig:
     def __init__(self, modalities_no=4, seg_gen=True, net_g='resnet_9blocks', net_gs='unet_512', norm='batch',
                  padding='zero', ngf=64, ndf=64, n_layers_D=4, gan_mode='vanilla', gan_mode_s='lsgan',
                  lambda_L1=100.0, lr_g=2e-4, lr_d=2e-4, beta1=0.5, seg_weights=None, loss_G_weights=None,
-                 loss_D_weights=None, input_nc=3, output_nc=3, lambda_feat=0.0):
+                 loss_D_weights=None, input_nc=3, output_nc=3, lambda_feat=0.0, net_d='n_layers', upsample='convtranspose'):
         self.lambda_feat = lambda_feat
+        self.net_d, self.upsample = net_d, upsample        # cli.py:103 --upsample (translation generators only, DeepLIIF_model.py:92-99), --net-d
         self.modalities_no = modalities_no
         self.seg_gen = seg_gen
         self.net_g = net_g
@@ -524,10 +560,12 @@ class OracleDeepLIIF:
 
     # -- helpers
     def _G(self, name, x, arch, padding):
+        if name in self.g_names and self.cfg.upsample != 'convtranspose' and arch.startswith('resnet_'):
+            arch = f'{arch}:{self.cfg.upsample}'
         return run_generator(arch, self.nets[name], x, self.cfg.norm, padding, self.train_bn_running)
 
     def _D(self, name, x):
-        return nlayer_discriminator(self.nets[name], x, self.cfg.norm, self.cfg.n_layers_D, self.train_bn_running)
+        return run_discriminator(self.cfg.net_d, self.nets[name], x, self.cfg.norm, self.cfg.n_layers_D, self.train_bn_running)
 
     def set_input(self, batch):
         """DeepLIIF_model.py:153-173."""

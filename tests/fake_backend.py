@@ -345,6 +345,9 @@ class FakeBackend:
         elif kind == L.LOSS_L1:
             l = (v - t).abs()
             g = torch.sign(v - t)
+        elif kind == L.LOSS_LINEAR:
+            l = t * v
+            g = t
         else:
             d = v - t
             l = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
@@ -353,6 +356,14 @@ class FakeBackend:
         if grad is not None:
             grad.zero_()
             grad[..., :C_real] = (g * grad_scale / v.numel()).to(grad.dtype)
+
+    def upsample2(self, src, dst, backward=False):
+        self._count('upsample2')
+        if backward:
+            n, h2, w2, c = src.shape
+            dst.copy_(src.float().reshape(n, h2 // 2, 2, w2 // 2, 2, c).sum(dim=(2, 4)).to(dst.dtype))
+        else:
+            dst.copy_(src.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2))
 
     def kldiv(self, x, t, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
         self._count('kldiv')

@@ -2,7 +2,8 @@
     step_kd_m2.npz        deepliif/models/DeepLIIFKD_model.py: 2 optimize_parameters() steps of a student distilled from the 'dl_m2' teacher directory
     step_cyclegan_m2.npz  deepliif/models/CycleGAN_model.py: 2 steps with pool_size = 2 and batch 2, so that the image pools fill in step 0 and
                           draw from Python's `random` stream in step 1 (whose discriminator losses then depend on the draws)
-Runs only in the build container (needs /root/reference):  python tests/golden/make_golden_zoo.py
+    step_options_m1.npz   DeepLIIF_model.py with the CLI-exposed non-default options --upsample resize_conv --net-d pixel --gan-mode wgangp
+Runs only in the build container (needs /root/reference):  python tests/golden/make_golden_zoo.py [kd] [cyclegan] [options]
 Data only (seeds, sub-sampled expected images, losses, weight digests); network weights are regenerated from seeds (make_golden.py).  The teacher
 directory (tests/seam_util.build_kd_teacher_dir) is the 'dl_m2' training options file of the seam fixtures + seeded weights at ngf = 64: the
 reference's test-mode Options force ngf = 64 (options/__init__.py:75) and DeepLIIFKD_model.py:107-112 gives the caller no way to override it.  The VGG terms are zeroed as in every other fixture (_ref_import.py, SURVEY 0 #4)."""
@@ -117,8 +118,42 @@ def make_cyclegan(tag='cyclegan_m2', size=64, nf=8, batch=2, steps=2, pool_size=
     print(f'step_{tag}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw', dict(zip(model.loss_names, out['step0/losses'])))
 
 
+def make_options(tag='options_m1', size=64, nf=8, batch=2, steps=2):
+    """DeepLIIF with the CLI-exposed non-default options --upsample resize_conv, --net-d pixel, --gan-mode wgangp (cli.py:103, 176-182)"""
+    out = {}
+    p = MG.base_params(1, False, 'batch', 'zero', 'unet_64', nf)
+    p.update(upsample='resize_conv', net_d='pixel', gan_mode='wgangp')
+    opt = Options(d_params=p)
+    model = models.create_model(opt)
+    model.setup(opt)
+    assert type(model.netD1).__name__ == 'PixelDiscriminator' and model.criterionGAN_mod.gan_mode == 'wgangp'
+    seeds = {}
+    for j, n in enumerate(model.model_names):
+        net = getattr(model, 'net' + n)
+        arch, cin = ('pixel', 6) if n.startswith('D') else ('resnet_9blocks:resize_conv', 3)
+        MG.load_seeded(net, arch, cin, nf, 'batch', 'zero', 600 + j)
+        seeds[n] = 600 + j
+    A = seeded_uniform((batch, 3, size, size), 62)
+    B = [seeded_uniform((batch, 3, size, size), 63)]
+    out['meta'] = np.array(['1', 'batch', 'zero', 'resnet_9blocks', str(size), str(nf), str(batch), str(steps), 'resize_conv', 'pixel', 'wgangp'])
+    out['model_names'] = np.array(model.model_names)
+    out['net_seeds'] = np.array([seeds[n] for n in model.model_names])
+    out['loss_names'] = np.array(model.loss_names)
+    for s in range(steps):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        losses = model.get_current_losses()
+        out[f'step{s}/losses'] = np.array([losses[k] for k in model.loss_names], dtype=np.float64)
+        out[f'step{s}/fake_B_1'] = model.fake_B_1.detach().numpy()[:, :, ::2, ::2]
+        weight_digests(model, out, s)
+    np.savez_compressed(os.path.join(HERE, f'step_{tag}.npz'), **out)
+    print(f'step_{tag}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw', dict(zip(model.loss_names, out['step0/losses'])))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['kd', 'cyclegan']
+    which = sys.argv[1:] or ['kd', 'cyclegan', 'options']
+    if 'options' in which:
+        make_options()
     if 'kd' in which:
         make_kd()
     if 'cyclegan' in which:

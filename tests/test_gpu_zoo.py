@@ -161,3 +161,51 @@ def test_cyclegan_step_golden_fixture_from_reference(precname):
                 ok, msg = digest_close(flat_weights(model._net(n)), z[f'step{s}/w_digest/{n}'], 8e-3)
                 assert ok, f'step {s} weights of {n}: {msg}'
     assert random.random() == float(z['random_after'][0]), 'the image pools must consume exactly the reference\'s draws'
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+def test_non_default_cli_options_step_golden_fixture_from_reference(precname):
+    """--upsample resize_conv, --net-d pixel, --gan-mode wgangp (cli.py:103, 176-182): dl_upsample2_nearest, the 1x1 PatchGAN and DL_LOSS_LINEAR in
+    one DeepLIIF trajectory recorded from the reference (tests/golden/step_options_m1.npz)"""
+    z = Z.opt_fixture()
+    opt = make_opt(1, False, str(z['meta'][1]), 'unet_64', int(z['meta'][5]), precname)
+    opt.upsample, opt.net_d, opt.gan_mode = str(z['meta'][8]), str(z['meta'][9]), str(z['meta'][10])
+    model = M.create_model(opt)
+    model.setup(opt)
+    assert type(model.netD1).__name__ == 'PixelDiscriminator' and model.netG1.upsample == 'resize_conv'
+    for name, sd in Z.opt_state_dicts(z).items():
+        getattr(model, 'net' + name).load_state_dict(sd, strict=True)
+    A, B = Z.opt_inputs(z)
+    ltol, otol = LTOL[precname], OTOL[precname]
+    for s in range(int(z['meta'][7])):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        for name, exp in zip(model.loss_names, z[f'step{s}/losses']):
+            err = abs(got[name] - exp) / max(abs(exp), 0.25)           # the Wasserstein terms are +-0.012 ... 0.017: judged against the floor
+            ERRLOG[f'zoo/options/{precname}/s{s}/{name}'] = err
+            assert err <= ltol[s], (s, name, got[name], exp)
+        e = rel(model.fake_B_1[:, :, ::2, ::2], z[f'step{s}/fake_B_1'])
+        ERRLOG[f'zoo/options/{precname}/s{s}/fake_B_1'] = e
+        assert e < otol[s], (s, e)
+        if precname == 'fp32':
+            for n in model.model_names:
+                ok, msg = digest_close(flat_weights(getattr(model, 'net' + n)), z[f'step{s}/w_digest/{n}'], 8e-3)
+                assert ok, f'step {s} weights of {n}: {msg}'
+
+
+@pytest.mark.parametrize('precname', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 5, 7, 8), (1, 64, 64, 256), (3, 1, 1, 16)])
+def test_upsample2_nearest_kernel(shape, precname):
+    n, h, w, c = shape
+    prec = E.Precision.get(precname)
+    x = torch.randn(n, h, w, c, generator=torch.Generator().manual_seed(1)).to(prec.dtype).to(DEV)
+    y = torch.empty(n, 2 * h, 2 * w, c, dtype=prec.dtype, device=DEV)
+    be = ops.impl()
+    be.upsample2(x, y)
+    assert torch.equal(y, x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2))
+    g = torch.randn(n, 2 * h, 2 * w, c, generator=torch.Generator().manual_seed(2)).to(prec.dtype).to(DEV)
+    dx = torch.empty_like(x)
+    be.upsample2(g, dx, backward=True)
+    ref = g.float().reshape(n, h, 2, w, 2, c).sum(dim=(2, 4))
+    assert rel(dx.float(), ref) < (1e-6 if precname == 'fp32' else 2.0 ** -8)

@@ -38,13 +38,19 @@ CASES = [
     ('resnet_9blocks', 3, 8, 'instance', 'zero', (1, 3, 36, 52)),   # batch 1, H != W
     ('resnet_2blocks', 3, 8, 'instance', 'reflect', (2, 3, 20, 28)),  # ReflectionPad2d(3) stem / head on 20x28 -> 5x7 block maps
     ('resnet_9blocks', 3, 8, 'batch', 'reflect', (1, 3, 32, 32)),
+    # CLI-exposed non-default options (cli.py:103, 176-179): --upsample resize_conv, --net-d pixel
+    ('resnet_9blocks:resize_conv', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
+    ('resnet_2blocks:resize_conv', 3, 8, 'instance', 'reflect', (1, 3, 20, 28)),
+    ('pixel', 6, 8, 'batch', 'zero', (2, 6, 24, 40)),
+    ('pixel', 6, 8, 'instance', 'zero', (1, 6, 16, 16)),
 ]
 
 
 def build(arch, cin, nf, norm, pad):
-    if arch == 'n_layers':
-        return N.define_D(cin, nf, 'n_layers', 4, norm, 'normal', 0.02, [])
-    return N.define_G(cin, 3, nf, arch, norm, False, 'normal', 0.02, [], pad)
+    if arch in ('n_layers', 'pixel'):
+        return N.define_D(cin, nf, arch, 4, norm, 'normal', 0.02, [])
+    arch, _, ups = arch.partition(':')
+    return N.define_G(cin, 3, nf, arch, norm, False, 'normal', 0.02, [], pad, ups or 'convtranspose')
 
 
 @pytest.mark.parametrize('arch,cin,nf,norm,pad,shape', CASES)
@@ -68,8 +74,8 @@ def test_forward_backward_matches_oracle(arch, cin, nf, norm, pad, shape):
     sdo = {k: v.clone() for k, v in sd.items()}
     params = {k: v.requires_grad_(True) for k, v in sdo.items() if v.is_floating_point() and 'running' not in k}
     xo = x.clone().requires_grad_(True)
-    if arch == 'n_layers':
-        yo = O.nlayer_discriminator(sdo, xo, norm, 4, update_running=(norm == 'batch'))
+    if arch in ('n_layers', 'pixel'):
+        yo = O.run_discriminator(arch, sdo, xo, norm, 4, update_running=(norm == 'batch'))
     else:
         yo = O.run_generator(arch, sdo, xo, norm, pad, update_running=(norm == 'batch'))
     assert rel(y, yo.detach()) < 2e-4

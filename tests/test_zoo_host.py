@@ -168,3 +168,31 @@ def test_cyclegan_inference_direction_and_result_names():
         res = I.run_dask(x, nets=nets, opt=opt, output_tensor=True)
         assert list(res) == names and all(v.shape == (1, 3, 64, 64) for v in res.values())
         assert list(I.empty_tile_colors(opt)) == names
+
+
+class CpuDeepLIIF(_Cpu, M.DeepLIIFModel):
+    pass
+
+
+def test_non_default_cli_options_follow_the_reference():
+    """--upsample resize_conv (nearest x2 + reflect-padded 3x3 conv), --net-d pixel (1x1 PatchGAN), --gan-mode wgangp (+-mean of the prediction)"""
+    z = Z.opt_fixture()
+    opt = make_opt(1, False, str(z['meta'][1]), nf=int(z['meta'][5]))
+    opt.upsample, opt.net_d, opt.gan_mode = str(z['meta'][8]), str(z['meta'][9]), str(z['meta'][10])
+    model = CpuDeepLIIF(opt)
+    model.setup(opt)
+    assert type(model.netD1).__name__ == 'PixelDiscriminator' and model.netG1.upsample == 'resize_conv'
+    for name, sd in Z.opt_state_dicts(z).items():
+        getattr(model, 'net' + name).load_state_dict(sd, strict=True)
+    A, B = Z.opt_inputs(z)
+    for s in range(int(z['meta'][7])):
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        tol = 5e-4 if s == 0 else 5e-3
+        for name, exp in zip(model.loss_names, z[f'step{s}/losses']):
+            assert abs(got[name] - exp) <= tol * max(1.0, abs(exp)), (s, name, got[name], exp)
+        assert rel(model.fake_B_1[:, :, ::2, ::2], z[f'step{s}/fake_B_1']) < (5e-4 if s == 0 else 3e-2)
+        for n in model.model_names:
+            ok, msg = digest_close(flat_weights(getattr(model, 'net' + n)), z[f'step{s}/w_digest/{n}'], 1e-3)
+            assert ok, f'step {s} weights of {n}: {msg}'

@@ -83,3 +83,22 @@ def test_cyclegan_two_step_trajectory_with_image_pool_draws():
             ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
             assert ok, f'step {s} weights of {n}: {msg}'
     assert random.random() == float(z['random_after'][0]), 'the image pools must have consumed exactly the reference\'s draws'
+
+
+def test_non_default_cli_options_two_step_trajectory():
+    """--upsample resize_conv, --net-d pixel, --gan-mode wgangp (cli.py:103, 176-182) in one DeepLIIF trajectory of the reference"""
+    z = Z.opt_fixture()
+    model = Z.opt_oracle(z)
+    A, B = Z.opt_inputs(z)
+    for s in range(int(z['meta'][7])):
+        model.set_input({'A': A, 'B': B})
+        model.optimize_parameters()
+        got = model.current_losses()
+        tol = 2e-4 if s == 0 else 3e-3
+        for name, exp in zip(z['loss_names'], z[f'step{s}/losses']):
+            assert abs(got[str(name)] - exp) <= tol * max(1.0, abs(exp)), (s, str(name), got[str(name)], exp)
+        assert rel_err(model.fake_B[0].detach()[:, :, ::2, ::2], z[f'step{s}/fake_B_1']) < (tol if s == 0 else 2e-2)
+        for n in z['model_names']:
+            flat = torch.cat([v.detach().reshape(-1).float() for v in model.nets[str(n)].values() if v.is_floating_point()])
+            ok, msg = digest_close(flat, z[f'step{s}/w_digest/{n}'], 1e-3)
+            assert ok, f'step {s} weights of {n}: {msg}'

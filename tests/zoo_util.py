@@ -75,3 +75,29 @@ def cyc_oracle(z):
     nf = int(z['meta'][5])
     cfg = O.OracleConfig(modalities_no=2, seg_gen=False, net_g=str(z['meta'][3]), norm=str(z['meta'][1]), padding=str(z['meta'][2]), ngf=nf, ndf=nf)
     return O.OracleCycleGAN(cfg, cyc_state_dicts(z), pool_size=int(z['meta'][8]), gan_mode=str(z['meta'][9]))
+
+
+def opt_fixture():
+    return np.load(os.path.join(G, 'step_options_m1.npz'))
+
+
+def opt_state_dicts(z):
+    nf = int(z['meta'][5])
+    nets = {}
+    for name, seed in zip(z['model_names'], z['net_seeds']):
+        name = str(name)
+        arch, cin = (str(z['meta'][9]), 6) if name.startswith('D') else (f"{z['meta'][3]}:{z['meta'][8]}", 3)
+        nets[name] = O.random_state_dict(arch, cin, 3, nf, str(z['meta'][1]), str(z['meta'][2]), 4, generator=torch.Generator().manual_seed(int(seed)))
+    return nets
+
+
+def opt_inputs(z):
+    size, batch = int(z['meta'][4]), int(z['meta'][6])
+    return seeded_uniform((batch, 3, size, size), 62), [seeded_uniform((batch, 3, size, size), 63)]
+
+
+def opt_oracle(z):
+    nf = int(z['meta'][5])
+    cfg = O.OracleConfig(modalities_no=1, seg_gen=False, net_g=str(z['meta'][3]), norm=str(z['meta'][1]), padding=str(z['meta'][2]), ngf=nf, ndf=nf,
+                         gan_mode=str(z['meta'][10]), net_d=str(z['meta'][9]), upsample=str(z['meta'][8]))
+    return O.OracleDeepLIIF(cfg, opt_state_dicts(z))
