@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                     o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
                     bs[k] += o[k];
                 }
-                Vec8<T>::store(dy + ((size_t)n * g.HW + p + u * pstep) * dy_ps + c0, o);
+                if (dy) Vec8<T>::store(dy + ((size_t)n * g.HW + p + u * pstep) * dy_ps + c0, o);       // dy == NULL: only the split copy is wanted
                 if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, o);
             }
         }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                 o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
                 bs[k] += o[k];
             }
-            Vec8<T>::store(dy + pix * dy_ps + c0, o);
+            if (dy) Vec8<T>::store(dy + pix * dy_ps + c0, o);
             if (split) store_split8(split + pix * split_ps + c0, o);
         }
         }
@@ -485,7 +485,8 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_backward")) return -1;
     if (dy_split && d->dtype != DL_F32) DL_FAIL("dl_norm_backward: the split copy belongs to the fp32 (strict) policy");
-    if (!dz || !y || !dy || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
+    if (!dz || !y || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_backward: null argument");
+    if (!dy && !dy_split) DL_FAIL("dl_norm_backward: dy may only be NULL when dy_split receives the result");
     // ext_nchunks > 0: the producer of dz (dl_conv_forward_bnstats) already left the [N][ext_nchunks][2][Cp] partials at the start of ws
     const bool ext = d->ext_nchunks > 0;
     const NormGeom g = make_geom_fwd(d);

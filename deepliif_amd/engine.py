@@ -40,7 +40,8 @@ class Precision:
 
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
-    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only', 'split', 'grad_split')
+    __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only', 'split', 'grad_split',
+                 'split_backward_ok', 'grad_values_stored')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -57,6 +58,10 @@ class Act:
         # norm kernel that produced the tensor, so that the convolutions consuming it skip their in-kernel hi / lo split (csrc/conv_x3.h)
         self.split: Optional[torch.Tensor] = None         # of .t
         self.grad_split: Optional[torch.Tensor] = None    # of .grad, valid only while .grad is that ONE contribution
+        # conv output: callable(dy-like tensor, bias_done) -> bool, "my whole backward can run from the SPLIT copy of dL/dy" (conv() sets it); a
+        # norm_act behind a norm_only conv output then skips the fp32 store of dL/dy (csrc/norm.hip: dy == NULL) and clears grad_values_stored
+        self.split_backward_ok = None
+        self.grad_values_stored = True                    # False: .grad only carries the geometry, the values live in .grad_split
 
     @property
     def shape(self):
@@ -70,6 +75,7 @@ class Act:
         if self.grad is None:
             self.grad = g
         else:
+            assert self.grad_values_stored, 'a split-only gradient cannot take a second contribution (norm_only promise broken)'
             ops.impl().axpby(1.0, self.grad, 1.0, g, self.grad)
             self.grad_stats = None          # reductions fused into the first contribution's producer no longer describe the sum
             self.grad_split = None          # ... nor does its split copy
@@ -336,6 +342,26 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     if w_needs:
         ctx.tape.use(layer.weight, layer.bias)
 
+    def split_backward_ok(g_like: torch.Tensor, bias_done: bool) -> bool:
+        """True if every consumer of dL/dy in backward_body() below reads the split copy (mirrors its branches one by one)"""
+        if not (getattr(be, 'supports_split', False) and ops._SPLIT_ONLY_GRAD) or act != L.ACT_NONE or layer.narrow:
+            return False
+        if w_needs:
+            if spec.kind == 'conv':
+                if not be.wgrad_takes_split(g_like, x.t, layer.weight.grad, spec.k, spec.pad_mode, ctx.prec.prec):
+                    return False
+            elif not be.wgrad_takes_split(x.t, g_like, layer.weight.grad, spec.k, L.PAD_ZERO, ctx.prec.prec):
+                return False
+            if layer.bias is not None and layer.bias.requires_grad and not bias_done:
+                return False
+        if x_needs:
+            if spec.kind == 'conv' and spec.pad_mode == L.PAD_REFLECT:
+                return False
+            if not be.conv_takes_split(g_like, ctx.prec.prec, L.ACT_NONE, L.PAD_ZERO):
+                return False
+        return True
+    y.split_backward_ok = split_backward_ok
+
     def backward():
         try:
             backward_body()
@@ -346,9 +372,13 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     def backward_body():
         g = y.grad
         gs = y.grad_split if (y.norm_only and getattr(be, 'supports_split', False)) else None       # split copy of g (norm_act's backward wrote it)
-        y.grad, y.grad_split = None, None
+        stored = y.grad_values_stored
+        y.grad, y.grad_split, y.grad_values_stored = None, None, True
         if g is None:
             return
+        if not stored:
+            # g only carries the geometry (the norm backward skipped its fp32 store): every branch below must take gs
+            assert gs is not None and split_backward_ok(g, y.bias_done), 'split-only gradient reached a consumer that needs the fp32 values'
         if act != L.ACT_NONE:                       # epilogue activation: derivative from the saved output
             gp = empty_like_act(g)
             be.act_backward(act, g, y.t, gp)
@@ -495,13 +525,21 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
             if y.norm_only and y.needs_grad and y.grad is None and ctx.prec.prec == L.PREC_BF16X3 and dy.dtype == torch.float32 and \
                     getattr(be, 'supports_split', False):
                 dys = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+            # ... and when its whole backward can run from that copy, the fp32 values are not stored at all (one 4-byte store per element less)
+            split_only = dys is not None and y.split_backward_ok is not None and y.split_backward_ok(dy, fuse_bias or y.bias_done)
+            kw = {}
+            if dys is not None:
+                kw['dy_split'] = dys
+            if split_only:
+                kw['store_dy'] = False
             be.norm_backward(g, y.t, dy, stats, norm.C, scope, act, gamma, m.weight.grad if affine else None, m.bias.grad if affine else None,
-                             y.bias_grad if fuse_bias else None, ext_nchunks=ext_b, **({'dy_split': dys} if dys is not None else {}))
+                             y.bias_grad if fuse_bias else None, ext_nchunks=ext_b, **kw)
             if fuse_bias:
                 y.bias_done = True
             if y.needs_grad:
                 y.add_grad(dy)
                 y.grad_split = dys
+                y.grad_values_stored = not split_only
 
     ctx.tape.record(backward)
     return z

@@ -47,6 +47,7 @@ _BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
 _NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
 _NO_X3_GLDS = os.environ.get('DL_NO_X3_GLDS') is not None           # A/B switch: the strict policy on the round-1 register-staged kernels (csrc reads the same variable)
 _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
+_SPLIT_ONLY_GRAD = os.environ.get('DL_NO_SPLIT_ONLY_GRAD', '0') != '1'     # A/B switch: 1 = the norm backward always stores the fp32 gradient next to its split copy
 _NO_C4_X3 = 'DL_NO_C4_X3' in os.environ              # A/B switch: the strict 7x7 stem / head on the general x3 kernels (csrc/conv_x3.h, wgrad_x3.h)
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
@@ -318,17 +319,19 @@ class HipBackend:
                                          _ptr(ws), _ptr(z_split), _stream()), 'dl_norm_forward')
         return stats
 
-    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0, dy_split=None):
+    def norm_backward(self, dz, y, dy, stats, C_real, scope, act, gamma, dgamma, dbeta, dy_chansum=None, ext_nchunks=0, dy_split=None, store_dy=True):
         """ext_nchunks > 0: the conv that produced dz already left the reductions in the 'norm_ws' workspace (conv_forward(bn=...)).
-        dy_split: see norm_forward(z_split)"""
+        dy_split: see norm_forward(z_split).  store_dy=False (needs dy_split): `dy` only gives the geometry, its fp32 values are NOT written."""
         _need_cuda(dz, y, dy, dy_chansum, dy_split)
+        assert store_dy or dy_split is not None
         assert dy_split is None or (dy_split.is_contiguous() and dy_split.dtype == torch.float32 and dy_split.shape == dy.shape)
         d = self._norm_desc(y, C_real, scope, act, -1.0, pstride(dz), pstride(dy))
         d.ext_nchunks = ext_nchunks
         WS.bump_norm_token()
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
-                                          _ptr(stats[3]), _ptr(dy), _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _ptr(dy_split), _stream()),
+                                          _ptr(stats[3]), _ptr(dy) if store_dy else None, _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _ptr(dy_split),
+                                          _stream()),
                 'dl_norm_backward')
 
     # ---- elementwise

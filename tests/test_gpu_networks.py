@@ -754,6 +754,18 @@ def test_strict_step_with_and_without_split_copies_is_bit_identical(monkeypatch)
     w1, l1 = run(True)
     w0, l0 = run(False)
     assert l1 == l0 and torch.equal(w1, w0)
+    # ... and with the split copies on, skipping the fp32 store of the norm backward where every consumer reads the copy (engine.conv:
+    # split_backward_ok) changes nothing either, while it does skip stores (otherwise this would test nothing)
+    calls = []
+    orig = ops.HipBackend.norm_backward
+    monkeypatch.setattr(ops.HipBackend, 'norm_backward', lambda self, *a, **k: (calls.append(k.get('store_dy', True)), orig(self, *a, **k))[1])
+    w2, l2 = run(True)
+    assert calls.count(False) > 0 and calls.count(True) > 0
+    monkeypatch.setattr(ops, '_SPLIT_ONLY_GRAD', False)
+    calls.clear()
+    w3, l3 = run(True)
+    assert calls.count(False) == 0
+    assert l2 == l1 and torch.equal(w2, w1) and l3 == l1 and torch.equal(w3, w1)
 
 
 def _unet_chain(net):
