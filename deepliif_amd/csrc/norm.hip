@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[u][k] += r[u][k];
                 }
-                Vec8<T>::store(z + ((size_t)n * g.HW + p + u * pstep) * z_ps + c0, v[u]);
+                if (z) Vec8<T>::store(z + ((size_t)n * g.HW + p + u * pstep) * z_ps + c0, v[u]);       // z == NULL: only the split copy is wanted
                 if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, v[u]);
             }
         }
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
-            Vec8<T>::store(z + pix * z_ps + c0, v);
+            if (z) Vec8<T>::store(z + pix * z_ps + c0, v);
             if (split) store_split8(split + pix * split_ps + c0, v);
         }
     }
@@ -443,7 +443,8 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
     hipStream_t stream = (hipStream_t)stream_;
     if (check_desc(d, "dl_norm_forward")) return -1;
     if (z_split && d->dtype != DL_F32) DL_FAIL("dl_norm_forward: the split copy belongs to the fp32 (strict) policy");
-    if (!y || !z || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_forward: null argument");
+    if (!y || !mean || !rstd || !scale || !shift || !ws) DL_FAIL("dl_norm_forward: null argument");
+    if (!z && !z_split) DL_FAIL("dl_norm_forward: z may only be NULL when z_split receives the result");
     const NormGeom g = make_geom_fwd(d);
     const int pblocks = g.N * g.nchunks;
     if (d->ext_nchunks > 0) {

@@ -41,7 +41,7 @@ class Precision:
 class Act:
     """An activation in engine layout: t = [N, H, W, Cp] view (bf16/fp32), C real channels; padded channels hold zeros."""
     __slots__ = ('t', 'C', 'grad', 'needs_grad', 'bias_grad', 'bias_done', 'stats', 'bn_ctx', 'grad_stats', 'norm_only', 'split', 'grad_split',
-                 'split_backward_ok', 'grad_values_stored')
+                 'split_backward_ok', 'grad_values_stored', 'values_stored')
 
     def __init__(self, t: torch.Tensor, C: int, needs_grad: bool = False):
         self.t = t
@@ -62,6 +62,7 @@ class Act:
         # norm_act behind a norm_only conv output then skips the fp32 store of dL/dy (csrc/norm.hip: dy == NULL) and clears grad_values_stored
         self.split_backward_ok = None
         self.grad_values_stored = True                    # False: .grad only carries the geometry, the values live in .grad_split
+        self.values_stored = True                         # False: .t only carries the geometry, the values live in .split (norm_act(sole_reader=...))
 
     @property
     def shape(self):
@@ -274,6 +275,24 @@ class Ctx:
         self.per_sample_norm = per_sample_norm
 
 
+def conv_reads_split_only(ctx: Ctx, layer: 'ConvLayer', x_t: torch.Tensor, in_act: int = L.ACT_NONE) -> bool:
+    """Will conv(ctx, x, layer, in_act=in_act) -- forward AND backward -- read x only through its split copy?  Mirrors the branches of conv()."""
+    be = ops.impl()
+    spec = layer.spec
+    if not (getattr(be, 'supports_split', False) and ops._SPLIT_ONLY_GRAD) or in_act != L.ACT_NONE or layer.narrow or ctx.prec.prec != L.PREC_BF16X3:
+        return False
+    if not be.conv_takes_split(x_t, ctx.prec.prec, L.ACT_NONE, spec.pad_mode):
+        return False
+    if layer.weight.requires_grad and ctx.tape is not None:
+        n, hi, wi, _ = x_t.shape
+        ho, wo = spec.out_hw(hi, wi)
+        g_like = torch.empty((n, ho, wo, cpad(spec.cout)), dtype=x_t.dtype, device='meta')
+        if spec.kind == 'conv':
+            return be.wgrad_takes_split(g_like, x_t, layer.weight.grad, spec.k, spec.pad_mode, ctx.prec.prec)
+        return be.wgrad_takes_split(x_t, g_like, layer.weight.grad, spec.k, L.PAD_ZERO, ctx.prec.prec)
+    return True
+
+
 def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
          stats: bool = False) -> Act:
     """y = act(conv(in_act(x)) + bias).  `out` may be a channel-slice view of a concat buffer.
@@ -291,6 +310,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     hq, wq = (ho, wo) if spec.kind == 'conv' else (hi, wi)
     if spec.kind == 'convT':
         assert (ho, wo) == (2 * hi, 2 * wi)
+    assert x.values_stored or not layer.narrow, 'a split-only activation reached the narrow-Cout path'
     if layer.narrow and in_act == L.ACT_NONE and ctx.prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
         # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
         be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
@@ -327,6 +347,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             fwd_in_act = L.ACT_NONE
         x_split = x.split is not None and fwd_in_act == L.ACT_NONE and xin is x.t and getattr(be, 'supports_split', False) and \
             be.conv_takes_split(x.t, ctx.prec.prec, fwd_in_act, spec.pad_mode)
+        assert x.values_stored or x_split, 'a split-only activation reached a convolution that needs its fp32 values'
         nch = be.conv_forward(layer.packed_fwd, x.split if x_split else xin, out, hq, wq, layer.bias.detach() if layer.bias is not None else None, act,
                               fwd_in_act, ctx.prec.prec, want_stats=stats and act == L.ACT_NONE, **({'in_split': True} if x_split else {}))
         del xin
@@ -384,6 +405,8 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             be.act_backward(act, g, y.t, gp)
             g, gs = gp, None
         xs = x.split if (x.split is not None and in_act == L.ACT_NONE and getattr(be, 'supports_split', False)) else None
+        if w_needs and not x.values_stored:
+            assert xs is not None and conv_reads_split_only(ctx, layer, x.t, in_act), 'split-only activation reached a weight gradient that needs fp32 values'
         if w_needs:
             if layer.narrow and spec.pad_mode == L.PAD_ZERO and getattr(be, 'wgrad_c4_applies', None) is not None and \
                     be.wgrad_c4_applies(g, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec):
@@ -442,8 +465,10 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
 
 
 def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE, residual: Optional[Act] = None,
-             out: Optional[torch.Tensor] = None) -> Act:
-    """z = act(norm(y)) (+ residual).  norm None = identity norm (norm='none')."""
+             out: Optional[torch.Tensor] = None, sole_reader: Optional['ConvLayer'] = None) -> Act:
+    """z = act(norm(y)) (+ residual).  norm None = identity norm (norm='none').
+    sole_reader: the caller's promise that the result is read by conv(ctx, z, sole_reader) and by NOTHING else (no residual use, no dropout, no
+    concat, not returned): under the strict policy the fp32 values are then not stored when that conv reads the split copy everywhere."""
     be = ops.impl()
     own_out = out is None
     if out is None:
@@ -485,10 +510,17 @@ def norm_act(ctx: Ctx, y: Act, norm: Optional[NormLayer], act: int = L.ACT_NONE,
     zs = None
     if own_out and ctx.prec.prec == L.PREC_BF16X3 and out.dtype == torch.float32 and getattr(be, 'supports_split', False):
         zs = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+    split_only = zs is not None and sole_reader is not None and conv_reads_split_only(ctx, sole_reader, out)
+    kwf = {}
+    if zs is not None:
+        kwf['z_split'] = zs
+    if split_only:
+        kwf['store_z'] = False
     stats = be.norm_forward(y.t, out, norm.C, scope, act, gamma, beta, rm, rv, momentum, residual.t if residual is not None else None,
-                            ext_nchunks=ext, **({'z_split': zs} if zs is not None else {}))
+                            ext_nchunks=ext, **kwf)
     z = Act(out, y.C, needs)
     z.split = zs
+    z.values_stored = not split_only
     if not needs:
         return z
     if residual is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and y.t.dtype == torch.bfloat16 and y.needs_grad:

@@ -201,20 +201,28 @@ class ResnetGenerator(EngineNet):
 
     def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
         b = self._layers()
+        # sole_reader: the next convolution is the only reader of these activations (engine.norm_act); the last down stage's output is also the first
+        # block's residual, so it is not promised to anyone
         c, n = b['stem']
-        h = E.norm_act(ctx, E.conv(ctx, x, c, stats=n is not None), n, L.ACT_RELU)
-        for c, n in b['down']:
-            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU)
-        for ent, blk in b['blocks']:
+        h = E.norm_act(ctx, E.conv(ctx, x, c, stats=n is not None), n, L.ACT_RELU, sole_reader=b['down'][0][0])
+        for i, (c, n) in enumerate(b['down']):
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU, sole_reader=b['down'][i + 1][0] if i + 1 < len(b['down']) else None)
+        nblk = len(b['blocks'])
+        for ib, (ent, blk) in enumerate(b['blocks']):
             (c1, n1), (c2, n2) = ent
-            r = E.norm_act(ctx, E.conv(ctx, h, c1, stats=n1 is not None), n1, L.ACT_RELU)
-            if blk.use_dropout and blk.training:       # nn.Dropout(0.5) after the first norm+ReLU (networks.py:493-494)
+            drop = blk.use_dropout and blk.training
+            # without dropout the block's inner activation is read by its second conv only: the strict policy keeps just its split copy
+            r = E.norm_act(ctx, E.conv(ctx, h, c1, stats=n1 is not None), n1, L.ACT_RELU, sole_reader=None if drop else c2)
+            if drop:                                   # nn.Dropout(0.5) after the first norm+ReLU (networks.py:493-494)
                 r = E.dropout(ctx, r, 0.5)
-            h = E.norm_act(ctx, E.conv(ctx, r, c2, stats=n2 is not None), n2, L.ACT_NONE, residual=h)
-        for c, n in b['up']:
+            # the last block's output is read by the first up-convolution only (every other one is the next block's residual as well)
+            last_out = b['up'][0][0] if (ib == nblk - 1 and self.upsample == 'convtranspose') else None
+            h = E.norm_act(ctx, E.conv(ctx, r, c2, stats=n2 is not None), n2, L.ACT_NONE, residual=h, sole_reader=last_out)
+        for i, (c, n) in enumerate(b['up']):
             if self.upsample == 'resize_conv':
                 h = E.upsample2(ctx, h)
-            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU)
+            nxt = b['up'][i + 1][0] if (i + 1 < len(b['up']) and self.upsample == 'convtranspose') else None
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_RELU, sole_reader=nxt)
         return E.conv(ctx, h, b['head'], act=L.ACT_TANH)
 
 
@@ -536,8 +544,9 @@ class NLayerDiscriminator(EngineNet):
     def run(self, ctx: E.Ctx, x: E.Act) -> E.Act:
         b = self._layers()
         h = E.conv(ctx, x, b['first'], act=L.ACT_LRELU)
-        for c, n in b['mid']:
-            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_LRELU)
+        for i, (c, n) in enumerate(b['mid']):
+            nxt = b['mid'][i + 1][0] if i + 1 < len(b['mid']) else b['last']          # the only reader of this activation
+            h = E.norm_act(ctx, E.conv(ctx, h, c, stats=n is not None), n, L.ACT_LRELU, sole_reader=nxt)
         return E.conv(ctx, h, b['last'])
 
     def forward(self, x):

@@ -303,10 +303,12 @@ class HipBackend:
         d.eps, d.momentum = 1e-5, momentum
         return d
 
-    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0, z_split=None):
+    def norm_forward(self, y, z, C_real, scope, act, gamma, beta, running_mean, running_var, momentum, residual, ext_nchunks=0, z_split=None, store_z=True):
         """ext_nchunks > 0: the convolution that produced y already left its partial sums in the 'norm_ws' workspace.
-        z_split (fp32 policy): dense buffer shaped like z that receives the split copy of z ([8 bf16 hi | 8 bf16 lo] per 8 channels)"""
+        z_split (fp32 policy): dense buffer shaped like z that receives the split copy of z ([8 bf16 hi | 8 bf16 lo] per 8 channels);
+        store_z=False (needs z_split): `z` only gives the geometry, its fp32 values are NOT written"""
         _need_cuda(y, z, gamma, beta, residual, z_split)
+        assert store_z or z_split is not None
         assert z_split is None or (z_split.is_contiguous() and z_split.dtype == torch.float32 and z_split.shape == z.shape)
         d = self._norm_desc(y, C_real, scope, act, momentum, pstride(z), pstride(residual) if residual is not None else 8)
         d.ext_nchunks = ext_nchunks
@@ -315,7 +317,7 @@ class HipBackend:
         stats = torch.empty(4, y.shape[0], y.shape[3], dtype=torch.float32, device=y.device)   # mean, rstd, scale, shift
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
         L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                         _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(z),
+                                         _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(z) if store_z else None,
                                          _ptr(ws), _ptr(z_split), _stream()), 'dl_norm_forward')
         return stats
 

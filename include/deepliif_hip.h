@@ -229,7 +229,8 @@ int dl_norm_forward(const dl_norm_desc *d, const void *y, const float *gamma, co
                     float *running_mean, float *running_var,
                     float *mean, float *rstd, float *scale, float *shift,
                     const void *residual, void *z, float *ws, void *z_split, void *stream);
-/* dl_norm_backward: dy may be NULL when dy_split is given (the consumers of this gradient all read the split copy: one 4-byte store per element less).
+/* dl_norm_forward: z / dl_norm_backward: dy may be NULL when z_split / dy_split is given (every consumer of the tensor reads the split copy: one 4-byte
+ * store per element less).
  * z_split / dy_split (may be NULL; DL_F32 only): a dense [N][H][W][Cp] buffer of the SAME byte size as the fp32 tensor that receives the split
  * copy of z / dy -- per group of 8 channels 16 bytes of bf16 hi = bf16(v) followed by 16 bytes of bf16 lo = bf16(v - hi) -- for the strict-policy
  * convolutions that consume the tensor next (dl_conv_desc.in_split, dl_wgrad_desc.p_split / q_split): the hi / lo split a conv kernel would redo

@@ -756,15 +756,17 @@ def test_strict_step_with_and_without_split_copies_is_bit_identical(monkeypatch)
     assert l1 == l0 and torch.equal(w1, w0)
     # ... and with the split copies on, skipping the fp32 store of the norm backward where every consumer reads the copy (engine.conv:
     # split_backward_ok) changes nothing either, while it does skip stores (otherwise this would test nothing)
-    calls = []
-    orig = ops.HipBackend.norm_backward
+    calls, fcalls = [], []
+    orig, forig = ops.HipBackend.norm_backward, ops.HipBackend.norm_forward
     monkeypatch.setattr(ops.HipBackend, 'norm_backward', lambda self, *a, **k: (calls.append(k.get('store_dy', True)), orig(self, *a, **k))[1])
+    monkeypatch.setattr(ops.HipBackend, 'norm_forward', lambda self, *a, **k: (fcalls.append(k.get('store_z', True)), forig(self, *a, **k))[1])
     w2, l2 = run(True)
     assert calls.count(False) > 0 and calls.count(True) > 0
+    assert fcalls.count(False) > 0 and fcalls.count(True) > 0        # the ResnetBlocks' inner activations (norm_act(sole_reader=...)) keep only their split copy
     monkeypatch.setattr(ops, '_SPLIT_ONLY_GRAD', False)
-    calls.clear()
+    calls.clear(); fcalls.clear()
     w3, l3 = run(True)
-    assert calls.count(False) == 0
+    assert calls.count(False) == 0 and fcalls.count(False) == 0
     assert l2 == l1 and torch.equal(w2, w1) and l3 == l1 and torch.equal(w3, w1)
 
 
