@@ -779,6 +779,7 @@ static int launch_conv_glds_x3(const ConvArgs &a, hipStream_t stream) {
 template <int IN_ACT>
 static int dispatch_glds_x3_tiles(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds_x3<256, 16, 4, 1, IN_ACT>(a, stream);
+    if (a.Co <= 32) return launch_conv_glds_x3<256, 32, 4, 1, IN_ACT>(a, stream);      // the head's (co, kw)-stacked rows (21 -> 32): half the MFMAs of the 64-wide tile
     if (a.Co <= 64) return launch_conv_glds_x3<128, 64, 2, 2, IN_ACT>(a, stream);
     return launch_conv_glds_x3<128, 128, 2, 2, IN_ACT>(a, stream);
 }
@@ -799,12 +800,13 @@ static bool x3_big_tile(int in_act, int pad_mode, int Ci, int mtot, int Co, int 
 // tile height (pixels) of the strict direct-to-LDS dispatch (for dl_conv_stats_chunks)
 static int x3_tile_bm(const dl_conv_desc *d) {
     if (x3_big_tile(d->in_act, d->pad_mode, d->Ci, d->N * d->Hq * d->Wq, d->Co, d->n_phase, d->splitk)) return 256;
-    return d->Co <= 16 ? 256 : 128;
+    return d->Co <= 32 ? 256 : 128;
 }
 
 static const char *x3_kernel_name(const dl_conv_desc *d) {
     if (x3_big_tile(d->in_act, d->pad_mode, d->Ci, d->N * d->Hq * d->Wq, d->Co, d->n_phase, d->splitk)) return "conv_gemm_8ph_x3_kernel";
     if (d->Co <= 16) return "conv_gemm_glds_x3_kernel<256,16>";
+    if (d->Co <= 32) return "conv_gemm_glds_x3_kernel<256,32>";
     if (d->Co <= 64) return "conv_gemm_glds_x3_kernel<128,64>";
     return "conv_gemm_glds_x3_kernel<128,128>";
 }
