@@ -352,10 +352,18 @@ __global__ void __launch_bounds__(256) loss_kernel(int kind, const T *x, int x_p
     }
 }
 __global__ void loss_final_kernel(const float *part, int n, float inv_count, float *out, float out_scale, int accumulate) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += (double)part[i];
-        const float v = (float)(s * (double)inv_count) * out_scale;
+    // 64 lanes, each the double sum of a contiguous slice of the partials, then lane 0 adds the 64 slice sums in lane order: a fixed summation
+    // tree (deterministic), 6 us instead of the 20 us one thread needed for 512 dependent-latency loads (80 launches per step)
+    __shared__ double sl[64];
+    const int per = (n + 63) / 64;
+    double s = 0.0;
+    for (int i = threadIdx.x * per; i < min(n, (int)(threadIdx.x + 1) * per); ++i) s += (double)part[i];
+    sl[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 64; ++i) tot += sl[i];
+        const float v = (float)(tot * (double)inv_count) * out_scale;
         out[0] = accumulate ? out[0] + v : v;
     }
 }
