@@ -1,0 +1,87 @@
+"""The data-parallel exchange with the model-zoo graphs (gloo, world 2, emulated ops backend): CycleGAN runs every generator TWICE on the generator tape and
+updates the generators before the discriminators (CycleGAN_model.py:266-282); DeepLIIFKD adds a frozen teacher that must stay out of the exchange.  Ranks
+must end bit-identical, and equal to one process over the concatenated batch (InstanceNorm: per-sample statistics)."""
+import os
+import random
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _paths():
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _build_cyclegan(seed):
+    import fake_backend
+    import test_host_model as T
+    from test_zoo_host import CpuCycleGAN
+    fake_backend.install()
+    torch.manual_seed(seed)
+    opt = T.make_opt(2, False, 'instance')
+    opt.model, opt.gan_mode, opt.pool_size, opt.BtoA, opt.allow_no_vgg = 'CycleGAN', 'lsgan', 0, False, True       # pool 0: no rank-local history
+    model = CpuCycleGAN(opt)
+    model.setup(opt)
+    return model
+
+
+def _batch(n0, n1):
+    from golden_util import seeded_uniform
+    return {'A': seeded_uniform((4, 3, 64, 64), 1)[n0:n1], 'Bs': [seeded_uniform((4, 3, 64, 64), 2 + i)[n0:n1] for i in range(2)], 'A_paths': ['x']}
+
+
+def _flat(model):
+    return torch.cat([p.detach().reshape(-1) for n in model.model_names for p in model._net(n).parameters()])
+
+
+def _worker(rank, world, port, out):
+    _paths()
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from deepliif_amd import distributed as D
+    D.init_process_group_from_env('gloo')
+    model = _build_cyclegan(seed=rank)          # differently seeded replicas: the one-time broadcast makes them identical
+    per = 4 // world
+    for _ in range(2):
+        model.set_input(_batch(rank * per, (rank + 1) * per))
+        model.optimize_parameters()
+    log = list(model.exchange.launch_log)
+    flat = model.optimizer_D.flat
+    # the last exchange was the discriminators': one slice per discriminator, each sent once although backward_D runs one tape per net
+    assert sorted(log) == sorted(flat.slice_of(list(net.parameters())) for net in model.netDA + model.netDB), log
+    torch.save(_flat(model), os.path.join(out, f'w{rank}.pt'))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_cyclegan_two_rank_data_parallel_equals_single_process(tmp_path):
+    _paths()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = torch.load(tmp_path / 'w0.pt'), torch.load(tmp_path / 'w1.pt')
+    assert torch.equal(w0, w1), 'ranks diverged after the gradient exchange'
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    model = _build_cyclegan(seed=0)
+    for _ in range(2):
+        model.set_input(_batch(0, 4))
+        model.optimize_parameters()
+    ws = _flat(model)
+    import fake_backend
+    fake_backend.uninstall()
+    assert float((w0 - ws).norm() / ws.norm()) < 2e-3
