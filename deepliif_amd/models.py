@@ -962,7 +962,8 @@ class CycleGANModel(BaseModel):
         assert tape is not None, 'forward() must run in training mode before backward_G()'
         ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
         cg, wG, cyc = self.criterionGAN, self.loss_G_weights, self.loss_cyc_weights
-        self._loss_buf.zero_()
+        for n in ('G_A', 'G_B', 'cycle_A', 'cycle_B'):           # the terms below ACCUMULATE into their slots (sums over the modalities)
+            self._slot(n).zero_()
         for i in range(self.mod_gen_no):
             E.loss_op(ctx, cg.kind, self.netDA[i].run(ctx, self._fake_B[i]), None, cg.target(True), wG[i], self._slot('G_A'), wG[i], True)
             if self.criterionVGG is not None:
@@ -994,10 +995,12 @@ class CycleGANModel(BaseModel):
 
     def backward_D_A(self):
         fakes = [pool.query(f) for pool, f in zip(self.fake_B_pools, self._fake_B)]
+        self._slot('D_A').zero_()
         self._backward_D_family(self.netDA, self._Bs, fakes, self._slot('D_A'))
 
     def backward_D_B(self):
         fakes = [pool.query(f) for pool, f in zip(self.fake_A_pools, self._fake_A)]
+        self._slot('D_B').zero_()
         self._backward_D_family(self.netDB, [self._A] * self.mod_gen_no, fakes, self._slot('D_B'))
 
     def _d_nets(self):
