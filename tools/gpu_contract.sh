@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 t0=$(date +%s)
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
 t1=$(date +%s); echo "smoke wall $((t1-t0)) s"
-timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench rc=$?"
 t2=$(date +%s); echo "bench wall $((t2-t1)) s"
 python - <<'PY'
 import json
