@@ -5,8 +5,10 @@ update_learning_rate -- the surface cli.py:403-449, train.py and test.py:90-113 
 DeepLIIFModel mirrors deepliif/models/DeepLIIF_model.py (network naming :49-115, forward :175-203, backward_D :205-332,
 backward_G :334-429, optimize_parameters :431-467) but executes on the MI355X engine: explicit forward/backward tape over
 hand-written HIP kernels, one fused Adam kernel per parameter set, gradient exchange on flat buffers.
-The VGG19 perceptual term of the reference (:406-409) needs downloaded torchvision weights and is not on this path
-(SURVEY 0 #4): lambda_feat is accepted and ignored with a one-time notice.
+The VGG19 perceptual term of the reference (:406-409) runs on the engine as well (networks.VGGLoss) but needs torchvision's weights as a FILE
+(opt.vgg_weights / DEEPLIIF_VGG19_WEIGHTS; nothing is downloaded): BaseModel._make_vgg raises when lambda_feat > 0 and none is given.
+DeepLIIFExtModel / SDGModel, DeepLIIFKDModel (teacher through inference.init_nets, distillation terms through engine.kldiv_op) and CycleGANModel
+(image pools, generator update first) follow the same pattern; create_model() dispatches on opt.model like deepliif/models/__init__.py:101-114.
 """
 from __future__ import annotations
 
