@@ -12,44 +12,11 @@
 #include "common.h"
 #include <stdlib.h>
 
-struct ConvArgs {
-    const void *in;
-    const bf16_t *w_hi;
-    const bf16_t *w_lo;
-    const float *bias;
-    void *out;
-    float *slab;
-    int N, Hi, Wi, Ci, log2Ci, in_pstride;
-    int Ho, Wo, Co, out_pstride;
-    int Hq, Wq, out_step, in_step;
-    int n_phase, splitk;
-    int phase_oh[DL_MAX_PHASES], phase_ow[DL_MAX_PHASES];
-    int phase_tap_begin[DL_MAX_PHASES + 1];
-    int phase_kbase[DL_MAX_PHASES];
-    int pad_mode, w_kstride, act, in_act, bias_n, raw_out;
-    int in_split;           // strict kernels: the input is the producer-written split copy ([8 hi | 8 lo] per 8 channels): no in-kernel split
-    int epi_old;            // DL_OLD_EPILOGUE=1: per-fragment stores instead of the LDS-transposed whole-row stores (A/B switch)
-    int tiles_m, tiles_n, Mtot;
-    int k_order;                    // direct-to-LDS UTAP path: 0 = K steps tap-major, 1 = channel-chunk-major (L2 reuse of the halo slab)
-    int k_order8;                   // the same choice for the 8-phase kernels (bf16: DL_8PH_KORDER, strict: DL_X3_KORDER)
-    float *stats_part;              // fused norm statistics: part[((n*nchunks + chunk)*2 + {sum,sumsq})*Co + c]
-    int stats_nchunks;
-    // fused norm-backward reductions (dl_conv_forward_bnstats): y tile read next to the dz tile in the store epilogue
-    const bf16_t *bn_y;
-    const float *bn_mean, *bn_rstd, *bn_scale, *bn_shift;
-    int bn_y_pstride, bn_act;
-    int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
-};
+#include "conv_args.h"
 
-template <int CPR> __device__ __forceinline__ int swz_chunk(int row, int c) {
-    if constexpr (CPR == 4) {
-        // f(q) = {0,2,3,1}[q], q = (row >> 2) & 3
-        const int q = (row >> 2) & 3;
-        return c ^ ((0x1320 >> (4 * q)) & 3);
-    } else {
-        return c ^ ((row >> 1) & (CPR - 1));
-    }
-}
+// conv_w4.hip: the one-wave-per-SIMD kernel of the ResnetBlock shape
+bool w4_eligible(const ConvArgs &a);
+int launch_conv_w4(const ConvArgs &a0, hipStream_t stream);
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -1551,6 +1518,11 @@ static bool big_tile_fills_gpu(int mtot, int Co, int n_phase, int splitk) {
     return Co >= 256 && (Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (Co / 256) * n_phase * splitk >= 224;
 }
 
+static bool w4_enabled() {
+    static const char *w4 = getenv("DL_CONV_W4");
+    return w4 && w4[0] == '1';
+}
+
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
@@ -1563,6 +1535,8 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
         // tools/ab_bench.sh): 121.7-122.0 ms vs 121.4-122.1 ms for the 8-phase kernel, 123.4-123.6 ms for the one-barrier kernel;
         // launch time 175 vs 168 vs 183 us.  The step is power-capped (profiles/r01/clock_probe.txt), so the 8-phase kernel
         // stays the default and this one is kept for the next tuning pass (it moves 33% fewer bytes into LDS).
+        // "1": 4 waves x (128 px x 128 ch) on v_mfma_32x32x16, kernel-column reuse, one barrier per K step (conv_w4.hip) for the ResnetBlock shape
+        if (w4_enabled() && w4_eligible(a)) return launch_conv_w4(a, stream);
         static const char *p32 = getenv("DL_CONV_P32");
         if (p32 && p32[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) {
             static const char *ablp = getenv("DL_CONV_ABLATE");
@@ -1647,6 +1621,20 @@ static int dispatch_tile(const ConvArgs &a, hipStream_t stream) {
     return launch_conv<TIn, TOut, PREC, 128, 128, BK, 2, 2>(a, stream);
 }
 
+// descriptor -> the geometry fields of the kernel argument block (everything but pointers and per-call switches)
+static void fill_conv_geometry(ConvArgs &a, const dl_conv_desc *d) {
+    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.log2Ci = ilog2_exact(d->Ci); a.in_pstride = d->in_pstride;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.out_pstride = d->out_pstride;
+    a.Hq = d->Hq; a.Wq = d->Wq; a.out_step = d->out_step; a.in_step = d->in_step;
+    a.n_phase = d->n_phase; a.splitk = d->splitk;
+    for (int p = 0; p < DL_MAX_PHASES; ++p) { a.phase_oh[p] = d->phase_oh[p]; a.phase_ow[p] = d->phase_ow[p]; a.phase_kbase[p] = d->phase_kbase[p]; }
+    for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
+    for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
+    a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
+    a.in_split = d->in_split;
+    a.Mtot = d->N * d->Hq * d->Wq;
+}
+
 // tile height (pixels) the dispatch picks for the bf16 direct-to-LDS path; 0 when that path is not taken
 static int glds_tile_bm(const dl_conv_desc *d) {
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
@@ -1671,6 +1659,12 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (d->Co <= 16) return "conv_gemm_glds_kernel<256,16,32>";
     if (d->Co <= 64) return "conv_gemm_glds_kernel<128,64,64>";
     if (bm != 256) return "conv_gemm_glds_kernel<128,128,64>";
+    if (w4_enabled()) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        fill_conv_geometry(a, d);
+        if (w4_eligible(a)) return "conv_gemm_w4_kernel";
+    }
     const bool utap = d->Ci >= 64 && d->pad_mode == DL_PAD_ZERO;
     static const char *korder_env = getenv("DL_CONV_KORDER");
     const bool korder = korder_env && korder_env[0] == '1';
@@ -1747,15 +1741,7 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in; a.w_hi = (const bf16_t *)w_hi; a.w_lo = (const bf16_t *)w_lo; a.bias = bias; a.out = out; a.slab = slab;
-    a.N = d->N; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.log2Ci = l2; a.in_pstride = d->in_pstride;
-    a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.out_pstride = d->out_pstride;
-    a.Hq = d->Hq; a.Wq = d->Wq; a.out_step = d->out_step; a.in_step = d->in_step;
-    a.n_phase = d->n_phase; a.splitk = d->splitk;
-    for (int p = 0; p < DL_MAX_PHASES; ++p) { a.phase_oh[p] = d->phase_oh[p]; a.phase_ow[p] = d->phase_ow[p]; a.phase_kbase[p] = d->phase_kbase[p]; }
-    for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
-    for (int t = 0; t < DL_MAX_TAPS; ++t) a.taps[t] = (int16_t)(((uint16_t)(uint8_t)d->tap_dh[t]) | ((uint16_t)(uint8_t)d->tap_dw[t] << 8));
-    a.pad_mode = d->pad_mode; a.w_kstride = d->w_kstride; a.act = d->act; a.in_act = d->in_act; a.bias_n = d->bias_n; a.raw_out = d->raw_out;
-    a.in_split = d->in_split;
+    fill_conv_geometry(a, d);
     if (d->in_split && !(d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && d->in_act == DL_ACT_NONE && x3_glds_applies(d)))
         DL_FAIL("dl_conv_forward: in_split needs the strict policy (fp32 + BF16X3) on the direct-to-LDS kernels and no input activation");
     static const bool epi_old = getenv("DL_OLD_EPILOGUE") != nullptr;
