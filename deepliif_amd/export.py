@@ -1,0 +1,237 @@
+"""TorchScript EXPORT of the generators: `deepliif serialize` (cli.py:770-830) for nets that live on the MI355X engine.
+
+The engine nets (deepliif_amd.networks) keep the reference's module TREE -- stock torch.nn leaf modules in the reference's positions, used
+as parameter containers -- but their forward() drives HIP kernels over ctypes, which torch.jit.trace cannot see.  What `serialize` has to
+produce, though, is not a trace of THIS implementation: it is `<name>.pt`, a stock ATen graph with the reference's parameter paths that
+`torch.jit.load` in the unmodified reference (models/__init__.py:117-121,216-219), TorchServe, or this package's own init_nets
+(inference.load_generator_weights: the file as a weight container) can read.  So export = a plain-torch TWIN of each net:
+
+  * `aten_twin(net)`: a module with the same children names (hence the same state_dict keys) whose forward is the reference's arithmetic
+    written with the stock modules' own forwards (networks.py:444-445 ResnetGenerator, :510-513 ResnetBlock, :611-615 UnetSkipConnectionBlock,
+    att_unet.py:46-55,75-85,105-115,153-199).  The leaves are deep copies on the CPU: tracing never touches the live engine net.
+  * `serialize(model_dir, output_dir, device, epoch, verbose)`: the CLI command's steps -- copy train_opt.txt, init_nets(eager_mode=True),
+    eval() + disable_batchnorm_tracking_stats (util/__init__.py:743-755: BatchNorm runs on the statistics of the tile, also in eval mode),
+    torch.jit.trace on the blank `transform(Image.new('RGB', (scale_size, scale_size)))` sample (3x channels for DeepLIIFExt's GS nets),
+    save -- followed by the reference's similarity test (util/__init__.py:718-741: sum |original - serialized| <= 10 on that sample), where
+    "original" is the ENGINE's own output on the GPU (strict policy: the only one held to 1e-3) and "serialized" the traced file
+    re-loaded with torch.jit.load and run by ATen on the CPU.  Without a visible GPU the original is the eager twin (the check the reference
+    makes with --device cpu: eager vs traced)."""
+from __future__ import annotations
+
+import copy
+import os
+import shutil
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import networks as N
+
+SIMILARITY_THRESHOLD = 10.0        # util/__init__.py:719
+
+
+# ---------------------------------------------------------------------------------------------------------------- plain-torch twins
+class _ResnetBlockT(nn.Module):
+    def __init__(self, blk: N.ResnetBlock):
+        super().__init__()
+        self.conv_block = blk.conv_block
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class _ResnetGeneratorT(nn.Module):
+    def __init__(self, net: N.ResnetGenerator):
+        super().__init__()
+        self.model = nn.Sequential(*[_ResnetBlockT(m) if isinstance(m, N.ResnetBlock) else m for m in net.model])
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _UnetBlockT(nn.Module):
+    def __init__(self, blk: N.UnetSkipConnectionBlock):
+        super().__init__()
+        self.outermost = blk.outermost
+        self.model = nn.Sequential(*[_UnetBlockT(m) if isinstance(m, N.UnetSkipConnectionBlock) else m for m in blk.model])
+
+    def forward(self, x):
+        # the in-place LeakyReLU at the head of the inner Sequential rewrites x before the concatenation, exactly as in the reference
+        # (SURVEY 2.2b): the stock modules are the same, so the twin inherits the quirk
+        return self.model(x) if self.outermost else torch.cat([x, self.model(x)], 1)
+
+
+class _UnetGeneratorT(nn.Module):
+    def __init__(self, net: N.UnetGenerator):
+        super().__init__()
+        self.model = _UnetBlockT(net.model)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _SeqChildT(nn.Module):
+    """conv_block / up_conv of the attention U-Net: one Sequential under the reference's attribute name"""
+
+    def __init__(self, attr: str, seq: nn.Sequential):
+        super().__init__()
+        self.attr = attr
+        setattr(self, attr, seq)
+
+    def forward(self, x):
+        return getattr(self, self.attr)(x)
+
+
+class _AttentionBlockT(nn.Module):
+    def __init__(self, a: N.Attention_block):
+        super().__init__()
+        self.W_g, self.W_x, self.psi, self.relu = a.W_g, a.W_x, a.psi, a.relu
+
+    def forward(self, g, x):
+        return x * self.psi(self.relu(self.W_g(g) + self.W_x(x)))
+
+
+class _AttUNetT(nn.Module):
+    def __init__(self, net: N.AttU_Net):
+        super().__init__()
+        for k in range(1, 9):
+            setattr(self, f'Conv{k}', _SeqChildT('conv', getattr(net, f'Conv{k}').conv))
+        for k in range(8, 0, -1):
+            setattr(self, f'Up{k}', _SeqChildT('up', getattr(net, f'Up{k}').up))
+            if k >= 2:
+                setattr(self, f'Att{k}', _AttentionBlockT(getattr(net, f'Att{k}')))
+
+    def forward(self, x):
+        xs = []
+        h = x
+        for k in range(1, 9):
+            h = getattr(self, f'Conv{k}')(h)
+            xs.append(h)
+        src = xs[7]
+        for k in range(8, 1, -1):
+            d = getattr(self, f'Up{k}')(src)
+            gated = getattr(self, f'Att{k}')(d, xs[k - 2])
+            src = torch.cat((gated, d), dim=1)
+        return self.Up1(src)
+
+
+def aten_twin(net: nn.Module) -> nn.Module:
+    """Plain-torch module with the state_dict keys of `net` (and of the reference class it mirrors) and the reference's forward, holding
+    CPU copies of the parameters.  The engine net is left untouched."""
+    bound = getattr(net, '_bound', None)
+    if bound is not None:
+        net._bound = None               # bindings point at packed device buffers: not part of the module tree, not worth copying
+    try:
+        src = copy.deepcopy(net).cpu()
+    finally:
+        if bound is not None:
+            net._bound = bound
+    if isinstance(src, N.ResnetGenerator):
+        twin = _ResnetGeneratorT(src)
+    elif isinstance(src, N.UnetGenerator):
+        twin = _UnetGeneratorT(src)
+    elif isinstance(src, N.AttU_Net):
+        twin = _AttUNetT(src)
+    else:
+        raise NotImplementedError(f'no plain-torch twin for {type(net).__name__}: serialize exports the generators init_nets returns')
+    got, exp = list(twin.state_dict().keys()), list(net.state_dict().keys())
+    assert got == exp, f'twin state_dict keys differ from the engine net: {sorted(set(got) ^ set(exp))[:6]}'
+    twin.train(net.training)
+    return twin
+
+
+def disable_batchnorm_tracking_stats(model: nn.Module) -> nn.Module:
+    """util/__init__.py:743-755: BatchNorm2d forgets its running statistics, so eval() normalises with the statistics of the input."""
+    for m in model.modules():
+        if type(m) is nn.BatchNorm2d:
+            m.track_running_stats = False
+            m.running_mean_backup, m.running_var_backup = m.running_mean, m.running_var
+            m.running_mean = None
+            m.running_var = None
+    return model
+
+
+def example_input(opt, name: str) -> torch.Tensor:
+    """cli.py:789-790,806-807: the blank RGB image through `transform`, input_no copies on the channel axis; DeepLIIFExt's seg generators
+    read cat(A, fake_1, fake_i) = 3x the channels."""
+    from PIL import Image
+    from . import inference as I
+    sample = I.transform(Image.new('RGB', (opt.scale_size, opt.scale_size)))
+    sample = torch.cat([sample] * int(getattr(opt, 'input_no', 1) or 1), 1)
+    if getattr(opt, 'model', 'DeepLIIF') == 'DeepLIIFExt' and name[1] == 'S':
+        sample = torch.cat([sample, sample, sample], 1)
+    return sample
+
+
+def trace_net(net: nn.Module, example: torch.Tensor):
+    """eval() + nulled BatchNorm statistics + torch.jit.trace on the CPU (cli.py:796-811).  Returns (traced module, eager twin)."""
+    twin = disable_batchnorm_tracking_stats(aten_twin(net).eval()).cpu()
+    with torch.no_grad():
+        traced = torch.jit.trace(twin, example.clone())         # the UNet's in-place LeakyReLU must not rewrite the caller's sample
+    return traced, twin
+
+
+def diff_original_serialized(original, serialized, example: torch.Tensor, verbose: int = 0, threshold: float = SIMILARITY_THRESHOLD) -> float:
+    """util/__init__.py:718-741 on two callables; returns the sum of absolute differences and raises like the reference when it is too large."""
+    with torch.no_grad():
+        a = original(example.clone()).detach().float().cpu()
+        b = serialized(example.clone()).detach().float().cpu()
+    d = (a - b).abs()
+    total = float(d.sum())
+    if verbose > 0:
+        print('Original:', tuple(a.shape), 'min abs value:{}'.format(float(a.abs().min())))
+        print('Torchscript:', tuple(b.shape), 'min abs value:{}'.format(float(b.abs().min())))
+        print('Dif sum:', total, 'max dif:{}'.format(float(d.max())))
+    assert total <= threshold, f'Sum of difference in predicted values {total} is larger than threshold {threshold}'
+    return total
+
+
+def serialize(model_dir: str, output_dir: Optional[str] = None, device: str = 'cpu', epoch: str = 'latest', verbose: int = 0,
+              opt=None, check_precision: str = 'fp32') -> Dict[str, float]:
+    """`deepliif serialize --model-dir ... --output-dir ... --device cpu|gpu --epoch ... --verbose N` (cli.py:760-830).
+    Writes `<output_dir>/<name>.pt` for every generator + train_opt.txt, then runs the similarity test.  Returns {name: sum |diff|}.
+
+    device: the reference traces on the CPU either way (cli.py:802) and uses `device` for the similarity test.  Here 'gpu' compares the
+    ENGINE (precision policy `check_precision`, default the strict fp32 policy) with the traced file; 'cpu' compares the eager ATen twin with
+    the traced file, because the engine has no CPU path.  Building the nets needs the GPU in both cases only when it is visible:
+    without one the weights are read straight from the checkpoints into CPU-resident module trees."""
+    from . import inference as I
+    output_dir = output_dir or model_dir
+    os.makedirs(output_dir, exist_ok=True)
+    if os.path.abspath(model_dir) != os.path.abspath(output_dir):
+        shutil.copy(os.path.join(model_dir, 'train_opt.txt'), os.path.join(output_dir, 'train_opt.txt'))
+    if opt is None:
+        opt = I.get_opt(model_dir, mode='test')
+    opt.epoch = epoch
+    use_gpu = device == 'gpu'
+    if use_gpu and not torch.cuda.is_available():
+        raise RuntimeError('serialize --device gpu: no GPU is visible')
+    opt.gpu_ids = [0] if use_gpu else []
+    if use_gpu:
+        opt.precision = check_precision
+        nets = I.init_nets(model_dir, eager_mode=True, opt=opt, phase='test')
+    else:
+        nets = I.build_generators(opt, torch.device('cpu'), None)
+        for n, net in nets.items():
+            I.load_generator_weights(net, model_dir, n, epoch, eager_mode=True)
+    report: 'OrderedDict[str, float]' = OrderedDict()
+    eager = {}
+    for name, net in nets.items():
+        example = example_input(opt, name)
+        traced, twin = trace_net(net, example)
+        traced.save(os.path.join(output_dir, f'{name}.pt'))
+        eager[name] = twin
+    print('testing similarity between prediction from original vs serialized models...')
+    for name, net in nets.items():
+        example = example_input(opt, name)
+        reloaded = torch.jit.load(os.path.join(output_dir, f'{name}.pt'), map_location='cpu').eval()
+        print(name, ':')
+        if use_gpu:
+            original = lambda t, net=net: net(t.to(next(net.parameters()).device))          # noqa: E731  (engine forward, NCHW fp32 in / out)
+        else:
+            original = eager[name]
+        report[name] = diff_original_serialized(original, reloaded, example, verbose)
+        print('PASS')
+    return report
