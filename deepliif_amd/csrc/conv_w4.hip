@@ -10,15 +10,22 @@
 //   * a K=16 sub-step needs 8 fragments (32 VGPRs) for 16 MFMAs = 512 matrix-pipe cycles, so the fragments are double-buffered
 //     in registers and every wave overlaps its OWN ds_reads and DMA issue with its OWN MFMAs: one barrier per K step, no
 //     role exchange;
-//   * kernel-column reuse: the three kw taps of one (64-channel chunk, kh) read ONE staged slab of 2 x (1 + 128 + 1) pixel rows
-//     at row offsets dw + 1 (pad columns zeroed once), so the activations cost 32 KB of DMA per THREE K steps: 43 KB per step
-//     instead of 64 KB;
+//   * kernel-column reuse: the three kw taps of one (64-channel chunk, kh) read ONE staged slab of 2 image rows x 128 pixels at
+//     row offsets dw: 32 KB of activation DMA per THREE K steps, 43 KB per step instead of 64 KB.  The slab has NO pad pixels
+//     (they would not fit, below): the one fragment lane per wave that falls off the image row (pixel -1 / 128) is zeroed in
+//     registers -- the kw order is a template parameter (FLIP: the data gradient walks dw = +1, 0, -1), so only the two outer
+//     taps pay 4 v_cndmask per sub-step;
 //   * K order (chunk, kh, kw): the 9 taps of a 64-channel chunk run back to back (the slab of a chunk stays in the XCD's L2).
-// Pipeline per K step t (W double buffer, X slab double buffer):  sub-steps 0..2 issue the ds_reads of the next sub-step
-// before their MFMAs and carry the DMA of W(t+1) [+ a third of slab(g+1)]; then s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
-// (the DMA was issued >= 1000 cycles earlier); sub-step 3's MFMAs run AFTER the barrier and cover the first fragment reads
-// of step t+1.  The steps past the end re-stage the last step into the idle buffers (no branches in the loop).
-// Epilogue: as tile_epilogue_lds of conv_gemm.hip for the 32x32 accumulator layout -- bias / activation, bf16 tile transposed
+// LDS: three weight buffers (3 x 32 KB) + two slabs (2 x 32 KB) = 163 840 B = all 160 KB.  Layout [W0 | X0 | X1 | W1 | W2]: the
+// off-image fragment rows (slab row -1 / 256) then fall into a neighbouring buffer -- a harmless read, zeroed afterwards.
+// Pipeline: K step t = 3 g + kw uses weight buffer kw (static); the DMA of W(t+2) and of slab(g+1) (4 pieces in each of the
+// first two steps of group g, issued BEFORE the weight pieces) is issued during step t, so every piece has a whole K step
+// (> 2000 matrix-pipe cycles) to land: the step ends with s_waitcnt vmcnt(8) -- the 8 youngest pieces, W(t+2), stay in
+// flight -- lgkmcnt(0), s_barrier.  Sub-step 3's MFMAs run after the barrier and cover the first fragment reads of step
+// t+1.  The steps past the end re-stage the last group into idle buffers (no branches in the loop).  r04 first version (two
+// weight buffers, vmcnt(0) per step, padded slabs): 144.5 us in-step against 157.7 us for the 8-phase kernel
+// (profiles/r04/w4_first_look.txt); DMA-only 79.5 us, MFMA-only 103.9 us, no-DMA 118.6 us.
+// Epilogue: as tile_epilogue_lds of conv_gemm.hip for the 32x32 accumulator layout -- bias / ReLU, bf16 tile transposed
 // through the dead operand LDS, whole NHWC pixel rows of 16 B per lane, fused per-(image, channel) statistics (DPP row sums).
 #include "conv_args.h"
 
@@ -38,16 +45,23 @@ __device__ __forceinline__ float w4_row16_sum(float v) {
     return v;
 }
 
-constexpr int W4_XB = 2 * 130 * 128;      // one activation slab: 2 image rows x (pad + 128 + pad) pixels x 64 channels (bytes)
-constexpr int W4_WB = 256 * 128;          // one weight buffer: 256 output channels x 64 K (bytes)
-constexpr int W4_XS = 0, W4_WS = 2 * W4_XB;
-constexpr size_t W4_LOOP_LDS = (size_t)2 * W4_XB + 2 * W4_WB;
+constexpr int W4_BUF = 256 * 128;                     // one weight buffer (256 output channels x 64 K) = one slab (2 x 128 pixels x 64 channels)
+constexpr int W4_X0 = 1 * W4_BUF;                     // slab s at W4_X0 + s * W4_BUF
+__host__ __device__ constexpr int w4_wofs(int b) { return b == 0 ? 0 : (b == 1 ? 3 * W4_BUF : 4 * W4_BUF); }
+constexpr size_t W4_LOOP_LDS = (size_t)5 * W4_BUF;
 constexpr size_t W4_EPI_LDS = (size_t)256 * 512 + 256 * sizeof(int) + (size_t)2 * 2 * 256 * sizeof(float);
 constexpr size_t W4_LDS = W4_LOOP_LDS > W4_EPI_LDS ? W4_LOOP_LDS : W4_EPI_LDS;
+static_assert(W4_LDS <= 160 * 1024, "the whole LDS of a CU");
 
-// ABL != 0: timing-only ablations (results wrong by construction): 1 = no DMA in the loop, 2 = DMA only, 3 = MFMAs only
-template <int ABL, int SCHED>
+// FLIP: kw taps ordered dw = +1, 0, -1 (data gradient) instead of -1, 0, +1.
+// VAR bit 0: DMA pieces and fragment reads in SEPARATE MFMA shadows (2 reads after the even MFMAs, 1 piece after the odd ones) instead of one read
+//            + one piece per shadow;  bit 1: the barrier of a step sits in the MIDDLE of sub-step 3 (after 8 of its MFMAs) instead of in front of it.
+// ABL != 0: timing-only ablations (results wrong by construction): 1 = no DMA in the loop, 2 = DMA only, 3 = MFMAs only, 4 = no K loop (prologue
+//           + epilogue), 5 = DMA issued but never waited for
+template <bool FLIP, int VAR, int ABL>
 __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
+    constexpr bool SEP = (VAR & 1) != 0, LATE = (VAR & 2) != 0;
+    constexpr bool DMA_ON = ABL != 1 && ABL != 3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_char_t *lds = (lds_char_t *)smem_raw;
 
@@ -57,20 +71,12 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
     const int nch = a.Ci >> 6;
-    const int G = 3 * nch;                     // (chunk, kh) groups of three K steps
+    const int G = ABL == 4 ? 0 : 3 * nch;       // (chunk, kh) groups of three K steps
 
-    // taps are ordered (kh, kw); dh is constant per kh, the dw order is the same in every kernel row (w4_eligible)
-    int dhs[3], shs[3];
+    // taps are ordered (kh, kw); dh is constant per kernel row (w4_eligible)
+    int dhs[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        dhs[k] = (int)(int8_t)(a.taps[3 * k] & 0xff);
-        shs[k] = (int)(int8_t)((a.taps[k] >> 8) & 0xff) + 1;
-    }
-
-    if (tid < 64) {          // zero the 2 x 2 pad pixels of both slabs (16 bytes per thread): image columns -1 and 128
-        const int c = tid & 7, r = (tid >> 3) & 1, e = (tid >> 4) & 1, b = tid >> 5;
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(lds + W4_XS + b * W4_XB + (r * 130 + e * 129) * 128 + c * 16) = u32x4_t{0, 0, 0, 0};
-    }
+    for (int k = 0; k < 3; ++k) dhs[k] = (int)(int8_t)(a.taps[3 * k] & 0xff);
 
     // ---- staging geometry.  Weights: instruction i of wave w fills buffer rows (w*8 + i)*8 .. +8 (output channels).  Activations: waves 0,1 stage
     // image row 0 of the tile (columns 0-63 / 64-127), waves 2,3 image row 1; instruction i covers 8 pixels.  LDS rows are 128 B = 8 chunks of 16 B;
@@ -84,7 +90,7 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     uint32_t x_off[8], w_off[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int col = cbase + 8 * i + lrow, xrow = R * 130 + 1 + col;
+        const int col = cbase + 8 * i + lrow, xrow = R * 128 + col;
         x_off[i] = (uint32_t)(((R * a.Wi + col) * a.in_pstride + (lcp ^ ((xrow >> 1) & 7)) * 8) * 2);
         const int s = (wave * 8 + i) * 8 + lrow;
         w_off[i] = (uint32_t)((s * a.w_kstride + (lcp ^ ((s >> 1) & 7)) * 8) * 2);
@@ -92,44 +98,38 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     const char *xg = reinterpret_cast<const char *>(a.in) + ((size_t)(n_img * a.Hi + h0) * a.Wi) * (size_t)a.in_pstride * 2;
     const char *wg = reinterpret_cast<const char *>(a.w_hi) + ((size_t)(tn * 256) * a.w_kstride + a.phase_kbase[0]) * 2;
     const char *zero = reinterpret_cast<const char *>(g_w4_zero_page);
-    const int x_dst0 = W4_XS + (R * 130 + 1 + cbase) * 128;          // + slab * XB + i * 1024
-    const int w_dst0 = W4_WS + wave * 8 * 1024;                      // + buf * WB + i * 1024
+    const int x_dst0 = W4_X0 + (R * 128 + cbase) * 128;              // + slab * BUF + i * 1024
+    const int w_dst0 = wave * 8 * 1024;                              // + w4_wofs(buf) + i * 1024
+    const ptrdiff_t tap_bytes = (ptrdiff_t)a.Ci * 2;                 // one kernel tap further along a packed weight row
 
-    // uniform part of the source addresses of group (chunk c, kernel row kh) / of K step (c, kh, kw)
+    // uniform part of the activation source address of group (chunk c, kernel row kh), and whether that image row exists for this wave
     auto x_group_base = [&](int c, int kh, bool &valid) __attribute__((always_inline)) {
-        const int hr = h0 + R + dhs[kh];
-        valid = (unsigned)hr < (unsigned)a.Hi;
-        return xg + ((ptrdiff_t)dhs[kh] * a.Wi * a.in_pstride + c * 64) * 2;
-    };
-    auto w_step_base = [&](int c, int kh, int kw) __attribute__((always_inline)) {
-        return wg + ((size_t)(kh * 3 + kw) * a.Ci + c * 64) * 2;
+        const int dh = kh == 0 ? dhs[0] : (kh == 1 ? dhs[1] : dhs[2]);
+        valid = (unsigned)(h0 + R + dh) < (unsigned)a.Hi;
+        return xg + ((ptrdiff_t)dh * a.Wi * a.in_pstride + c * 64) * 2;
     };
     auto dma_x = [&](auto I, const char *base, bool valid, int slab) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const char *src = valid ? base + x_off[i] : zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(lds + x_dst0 + slab * W4_XB + i * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(lds + x_dst0 + slab * W4_BUF + i * 1024), 16, 0, 0);
     };
-    auto dma_w = [&](auto I, const char *base, int buf) __attribute__((always_inline)) {
-        constexpr int i = decltype(I)::value;
+    auto dma_w = [&](auto I, const char *base, auto BUF) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, buf = decltype(BUF)::value;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + w_off[i]),
-                                         (__attribute__((address_space(3))) void *)(lds + w_dst0 + buf * W4_WB + i * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(lds + w_dst0 + w4_wofs(buf) + i * 1024), 16, 0, 0);
     };
 
     // ---- fragment addressing (bytes): lane = (row lr of a 32-row block, K half lh of a 16-wide sub-step)
     const int lr = lane & 31, lh = lane >> 5;
-    const int aw = W4_WS + (wn * 128 + lr) * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);
-    int axk[3];                                                         // activation fragment base of kw = 0, 1, 2 (slab row shift dw + 1)
-    {
-        int ax[3];
+    const int aw = (wn * 128 + lr) * 128 + ((lh ^ ((lr >> 1) & 7)) << 4);
+    int axk[3];                                                         // activation fragment base of kw = 0, 1, 2 (slab row shift dw = -1, 0, +1 or reversed)
 #pragma unroll
-        for (int sh = 0; sh < 3; ++sh) {
-            const int row = wm * 130 + sh + lr;
-            ax[sh] = W4_XS + row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) axk[k] = shs[k] == 0 ? ax[0] : (shs[k] == 1 ? ax[1] : ax[2]);
+    for (int k = 0; k < 3; ++k) {
+        const int row = wm * 128 + lr + (FLIP ? 1 - k : k - 1);
+        axk[k] = W4_X0 + row * 128 + ((lh ^ ((row >> 1) & 7)) << 4);
     }
+    const bool edge_lo = lr == 0, edge_hi = lr == 31;                   // the lane whose pixel is column -1 (block 0, dw = -1) / 128 (block 3, dw = +1)
 
     f32x16_t acc[4][4];
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     bf16x8_t FA[8], FB[8];
-    if constexpr (ABL >= 2) {
+    if constexpr (ABL == 2 || ABL == 3) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             FA[f] = bf16x8_t{(short)(0x3f80 + lane), (short)(0x3f00 + f), 0x3e80, 0x3f81, (short)0xbf80, 0x3f10, 0x3e90, 0x3f91};
@@ -149,143 +149,183 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     }
     auto read_one = [&](auto FI, int wp, int xp, bf16x8_t (&F)[8]) __attribute__((always_inline)) {
         constexpr int f = decltype(FI)::value;
-        if constexpr (ABL >= 2) return;
+        if constexpr (ABL == 2 || ABL == 3) return;
         if constexpr (f < 4) F[f] = *reinterpret_cast<lds_frag_t *>(lds + wp + f * 4096);
         else F[f] = *reinterpret_cast<lds_frag_t *>(lds + xp + (f - 4) * 4096);
     };
     auto mma_one = [&](auto MI, const bf16x8_t (&F)[8]) __attribute__((always_inline)) {
-        constexpr int m = decltype(MI)::value, i = m >> 2, j = m & 3;
+        // MFMA 0 of a sub-step multiplies the two fragments that were read LAST (W3, X3): the compiler's wait for them (= for every read of the
+        // previous sub-step: LDS returns in order) then sits in front of the sub-step, before any read of the next one is issued.  With the
+        // natural order hipcc put an s_waitcnt lgkmcnt(0) BEHIND the first two fresh reads of every sub-step (a full LDS round trip, 4 x per step)
+        constexpr int m = decltype(MI)::value, i = 3 - (m >> 2), j = 3 - (m & 3);
         if constexpr (ABL == 2) return;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[4 + j], acc[i][j], 0, 0, 0);
     };
-    // one K=16 sub-step: 16 MFMAs on Fc, the 8 fragment reads of the next sub-step into Fn (bases wp / xp), and `hook(m)` after MFMA m
-    // (DMA issue slots).  SCHED 1: the source order MFMA, read, MFMA, read, ... is pinned with sched_group_barriers.
-    auto substep = [&](const bf16x8_t (&Fc)[8], bf16x8_t (&Fn)[8], int wp, int xp, auto &&hook) __attribute__((always_inline)) {
-        mma_one(W4IC<0>{}, Fc);  read_one(W4IC<0>{}, wp, xp, Fn); hook(W4IC<0>{});
-        mma_one(W4IC<1>{}, Fc);  read_one(W4IC<4>{}, wp, xp, Fn); hook(W4IC<1>{});
-        mma_one(W4IC<2>{}, Fc);  read_one(W4IC<1>{}, wp, xp, Fn); hook(W4IC<2>{});
-        mma_one(W4IC<3>{}, Fc);  read_one(W4IC<5>{}, wp, xp, Fn); hook(W4IC<3>{});
-        mma_one(W4IC<4>{}, Fc);  read_one(W4IC<2>{}, wp, xp, Fn); hook(W4IC<4>{});
-        mma_one(W4IC<5>{}, Fc);  read_one(W4IC<6>{}, wp, xp, Fn); hook(W4IC<5>{});
-        mma_one(W4IC<6>{}, Fc);  read_one(W4IC<3>{}, wp, xp, Fn); hook(W4IC<6>{});
-        mma_one(W4IC<7>{}, Fc);  read_one(W4IC<7>{}, wp, xp, Fn); hook(W4IC<7>{});
-        mma_one(W4IC<8>{}, Fc);  hook(W4IC<8>{});
-        mma_one(W4IC<9>{}, Fc);  hook(W4IC<9>{});
-        mma_one(W4IC<10>{}, Fc); hook(W4IC<10>{});
-        mma_one(W4IC<11>{}, Fc); hook(W4IC<11>{});
-        mma_one(W4IC<12>{}, Fc); hook(W4IC<12>{});
-        mma_one(W4IC<13>{}, Fc); hook(W4IC<13>{});
-        mma_one(W4IC<14>{}, Fc); hook(W4IC<14>{});
-        mma_one(W4IC<15>{}, Fc); hook(W4IC<15>{});
+    // the fragment lane that fell off the image row reads a neighbouring buffer: zero it (SH = slab shift of the step the fragments belong to)
+    auto fix_edge = [&](auto SHc, bf16x8_t (&F)[8]) __attribute__((always_inline)) {
+        constexpr int SH = decltype(SHc)::value;
+        if constexpr (ABL == 2 || ABL == 3) return;
+        if constexpr (SH == 0) { if (edge_lo) F[4] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
+        if constexpr (SH == 2) { if (edge_hi) F[7] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}; }
     };
+    // MFMAs [M0, M1) of a K=16 sub-step on Fc; the fragment reads of the NEXT sub-step (into Fn, bases wp / xp) ride in their shadows when READS;
+    // hook(m) is called after MFMA m (DMA issue slots).  Source order = intended issue order; pinned by the sched_group_barriers that follow.
+    auto mfma_range = [&](auto M0c, auto M1c, auto READSc, const bf16x8_t (&Fc)[8], bf16x8_t (&Fn)[8], int wp, int xp, auto &&hook) __attribute__((always_inline)) {
+        constexpr int M0 = decltype(M0c)::value, M1 = decltype(M1c)::value;
+        constexpr bool READS = decltype(READSc)::value != 0;
+        constexpr int RBASE = decltype(READSc)::value == 2 ? 8 : 0;      // READS == 2: the reads start at MFMA 8 (second half of a sub-step)
+        auto rd = [&](auto K) __attribute__((always_inline)) {           // K-th read of the sub-step: W0 X0 W1 X1 W2 X2 W3 X3
+            constexpr int k = decltype(K)::value;
+            read_one(W4IC<(k & 1) ? 4 + (k >> 1) : (k >> 1)>{}, wp, xp, Fn);
+        };
+        auto one = [&](auto MI) __attribute__((always_inline)) {
+            constexpr int m = decltype(MI)::value;
+            if constexpr (m >= M0 && m < M1) {
+                mma_one(MI, Fc);
+                if constexpr (READS) {
+                    constexpr int q = m - RBASE;
+                    if constexpr (RBASE == 8) {                      // second half of a sub-step: two reads in each of the shadows 8..11
+                        if constexpr (q >= 0 && q < 4) { rd(W4IC<(q >= 0 && q < 4) ? 2 * q : 0>{}); rd(W4IC<(q >= 0 && q < 4) ? 2 * q + 1 : 0>{}); }
+                    } else if constexpr (SEP) {
+                        if constexpr (q >= 0 && q < 8 && (q & 1) == 0) { rd(W4IC<(q >= 0 && q < 8) ? q : 0>{}); rd(W4IC<(q >= 0 && q < 8) ? q + 1 : 0>{}); }
+                    } else {
+                        if constexpr (q >= 0 && q < 8) rd(W4IC<(q >= 0 && q < 8) ? q : 0>{});
+                    }
+                }
+                hook(MI);
+            }
+        };
+        one(W4IC<0>{}); one(W4IC<1>{}); one(W4IC<2>{}); one(W4IC<3>{}); one(W4IC<4>{}); one(W4IC<5>{}); one(W4IC<6>{}); one(W4IC<7>{});
+        one(W4IC<8>{}); one(W4IC<9>{}); one(W4IC<10>{}); one(W4IC<11>{}); one(W4IC<12>{}); one(W4IC<13>{}); one(W4IC<14>{}); one(W4IC<15>{});
+    };
+    // pin the issue order of a range written by mfma_range: per MFMA shadow one MFMA, then its reads / its DMA piece
+    auto pin = [&](auto M0c, auto M1c, auto READSc, auto NDc) __attribute__((always_inline)) {
+        constexpr int M0 = decltype(M0c)::value, M1 = decltype(M1c)::value, ND = decltype(NDc)::value;
+        constexpr bool READS = decltype(READSc)::value != 0;
+        constexpr int RBASE = decltype(READSc)::value == 2 ? 8 : 0;
+#pragma unroll
+        for (int m = M0; m < M1; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            const int q = m - RBASE;
+            if (READS && q >= 0 && q < 8) {
+                if (RBASE == 8) { if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                else if (SEP) { if ((q & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // DMA slots (see dma_slot below): SEP: after MFMAs 1, 3, 5, 7;  else after MFMAs 1, 4, 7, 10
+            const bool slot = SEP ? ((m & 1) == 1 && (m >> 1) < ND) : (m % 3 == 1 && m / 3 < ND);
+            if (slot) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    // index of the DMA piece issued after MFMA m of a sub-step (-1: none)
+    auto dma_slot = [](int m) constexpr { return SEP ? (((m & 1) == 1 && (m >> 1) < 4) ? (m >> 1) : -1) : ((m % 3 == 1 && m / 3 < 4) ? m / 3 : -1); };
     auto nohook = [](auto) __attribute__((always_inline)) {};
 
-    // ---- prologue: slab of group 0, weights of step 0
-    {
-        bool v0;
-        const char *xb0 = x_group_base(0, 0, v0);
-        const char *wb0 = w_step_base(0, 0, 0);
-        dma_w(W4IC<0>{}, wb0, 0); dma_w(W4IC<1>{}, wb0, 0); dma_w(W4IC<2>{}, wb0, 0); dma_w(W4IC<3>{}, wb0, 0);
-        dma_w(W4IC<4>{}, wb0, 0); dma_w(W4IC<5>{}, wb0, 0); dma_w(W4IC<6>{}, wb0, 0); dma_w(W4IC<7>{}, wb0, 0);
-        dma_x(W4IC<0>{}, xb0, v0, 0); dma_x(W4IC<1>{}, xb0, v0, 0); dma_x(W4IC<2>{}, xb0, v0, 0); dma_x(W4IC<3>{}, xb0, v0, 0);
-        dma_x(W4IC<4>{}, xb0, v0, 0); dma_x(W4IC<5>{}, xb0, v0, 0); dma_x(W4IC<6>{}, xb0, v0, 0); dma_x(W4IC<7>{}, xb0, v0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // pad pixels, slab 0, weights 0 visible
-
-    {
-        const int wp = aw, xp = axk[0];
-        read_one(W4IC<0>{}, wp, xp, FA); read_one(W4IC<1>{}, wp, xp, FA); read_one(W4IC<2>{}, wp, xp, FA); read_one(W4IC<3>{}, wp, xp, FA);
-        read_one(W4IC<4>{}, wp, xp, FA); read_one(W4IC<5>{}, wp, xp, FA); read_one(W4IC<6>{}, wp, xp, FA); read_one(W4IC<7>{}, wp, xp, FA);
-    }
-
-    // K step (group g = (chunk c, kernel row kh), kw = KW): see the header comment
-    auto step = [&](auto KWc, int g, int c, int kh, int gn, int cn, int khn) __attribute__((always_inline)) {
-        constexpr int KW = decltype(KWc)::value;
-        const int t = g * 3 + KW;
-        const int wcur = aw + (t & 1) * W4_WB, xcur = axk[KW] + (g & 1) * W4_XB;
-        // next K step: same group (kw + 1) or the first of the next group
-        const int wnext = aw + ((t + 1) & 1) * W4_WB;
-        const int xnext = KW < 2 ? axk[KW < 2 ? KW + 1 : 0] + (g & 1) * W4_XB : axk[0] + ((g + 1) & 1) * W4_XB;
-        const char *wb = KW < 2 ? w_step_base(c, kh, KW + 1) : w_step_base(cn, khn, 0);
-        bool xv;
-        const char *xb = x_group_base(cn, khn, xv);
-        (void)gn;
-        const int wbuf = (t + 1) & 1, xslab = (g + 1) & 1;
-        // DMA issue slots: W(t+1) pieces 0-3 + one slab piece in sub-step 0, pieces 4-7 + up to two slab pieces in sub-step 1; nothing in sub-steps
-        // 2 and 3, so the youngest DMA has ~1000 matrix-pipe cycles to land before the vmcnt(0) in front of the barrier
-        auto hook0 = [&](auto MI) __attribute__((always_inline)) {
-            constexpr int m = decltype(MI)::value;
-            if constexpr (ABL == 1 || ABL == 3) return;
-            if constexpr (m == 1) dma_w(W4IC<0>{}, wb, wbuf);
-            if constexpr (m == 4) dma_w(W4IC<1>{}, wb, wbuf);
-            if constexpr (m == 7) dma_w(W4IC<2>{}, wb, wbuf);
-            if constexpr (m == 10) dma_w(W4IC<3>{}, wb, wbuf);
-            if constexpr (m == 13) {
-                if constexpr (KW == 0) dma_x(W4IC<0>{}, xb, xv, xslab);
-                if constexpr (KW == 1) dma_x(W4IC<3>{}, xb, xv, xslab);
-                if constexpr (KW == 2) dma_x(W4IC<6>{}, xb, xv, xslab);
-            }
-        };
-        auto hook1 = [&](auto MI) __attribute__((always_inline)) {
-            constexpr int m = decltype(MI)::value;
-            if constexpr (ABL == 1 || ABL == 3) return;
-            if constexpr (m == 0) dma_w(W4IC<4>{}, wb, wbuf);
-            if constexpr (m == 3) dma_w(W4IC<5>{}, wb, wbuf);
-            if constexpr (m == 6) dma_w(W4IC<6>{}, wb, wbuf);
-            if constexpr (m == 9) dma_w(W4IC<7>{}, wb, wbuf);
-            if constexpr (m == 11) {
-                if constexpr (KW == 0) dma_x(W4IC<1>{}, xb, xv, xslab);
-                if constexpr (KW == 1) dma_x(W4IC<4>{}, xb, xv, xslab);
-                if constexpr (KW == 2) dma_x(W4IC<7>{}, xb, xv, xslab);
-            }
-            if constexpr (m == 13) {
-                if constexpr (KW == 0) dma_x(W4IC<2>{}, xb, xv, xslab);
-                if constexpr (KW == 1) dma_x(W4IC<5>{}, xb, xv, xslab);
-            }
-        };
-        substep(FA, FB, wcur ^ (1 << 5), xcur ^ (1 << 5), hook0);
-        if constexpr (SCHED == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        }
-        substep(FB, FA, wcur ^ (2 << 5), xcur ^ (2 << 5), hook1);
-        if constexpr (SCHED == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        }
-        substep(FA, FB, wcur ^ (3 << 5), xcur ^ (3 << 5), nohook);
-        if constexpr (SCHED == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-        }
-        // W(t+1) / slab(g+1) have landed (issued >= 1000 cycles ago), this wave's reads of buffer t are complete
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        substep(FB, FA, wnext, xnext, nohook);
-        if constexpr (SCHED == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-        }
-    };
-
+    // ---- running source pointers: group g and group g + 1 (clamped to the last group)
     int c = 0, kh = 0;
-    for (int g = 0; g < G; ++g) {
-        // next group, clamped to the last one (its re-staged copy lands in the idle slab / buffer)
-        int cn = c, khn = kh + 1;
+    const char *wgrp = wg, *wgrp_n = wg;            // weights of (c, kh, kw = 0) of this / the next group
+    const char *xb_n = xg;
+    bool xv_n = false;
+    auto advance = [&](int g, int &cn, int &khn) __attribute__((always_inline)) {
+        cn = c; khn = kh + 1;
         if (khn == 3) { khn = 0; cn = c + 1; }
         if (g + 1 >= G) { cn = c; khn = kh; }
-        step(W4IC<0>{}, g, c, kh, g + 1, cn, khn);
-        step(W4IC<1>{}, g, c, kh, g + 1, cn, khn);
-        step(W4IC<2>{}, g, c, kh, g + 1, cn, khn);
-        c = cn; kh = khn;
+        wgrp_n = wg + ((ptrdiff_t)(khn * 3) * a.Ci + cn * 64) * 2;
+        xb_n = x_group_base(cn, khn, xv_n);
+    };
+
+    // ---- prologue: slab of group 0, weights of steps 0 and 1
+    if (G > 0) {
+        bool v0;
+        const char *xb0 = x_group_base(0, 0, v0);
+        dma_x(W4IC<0>{}, xb0, v0, 0); dma_x(W4IC<1>{}, xb0, v0, 0); dma_x(W4IC<2>{}, xb0, v0, 0); dma_x(W4IC<3>{}, xb0, v0, 0);
+        dma_x(W4IC<4>{}, xb0, v0, 0); dma_x(W4IC<5>{}, xb0, v0, 0); dma_x(W4IC<6>{}, xb0, v0, 0); dma_x(W4IC<7>{}, xb0, v0, 0);
+        dma_w(W4IC<0>{}, wg, W4IC<0>{}); dma_w(W4IC<1>{}, wg, W4IC<0>{}); dma_w(W4IC<2>{}, wg, W4IC<0>{}); dma_w(W4IC<3>{}, wg, W4IC<0>{});
+        dma_w(W4IC<4>{}, wg, W4IC<0>{}); dma_w(W4IC<5>{}, wg, W4IC<0>{}); dma_w(W4IC<6>{}, wg, W4IC<0>{}); dma_w(W4IC<7>{}, wg, W4IC<0>{});
+        const char *w1 = wg + tap_bytes;
+        dma_w(W4IC<0>{}, w1, W4IC<1>{}); dma_w(W4IC<1>{}, w1, W4IC<1>{}); dma_w(W4IC<2>{}, w1, W4IC<1>{}); dma_w(W4IC<3>{}, w1, W4IC<1>{});
+        dma_w(W4IC<4>{}, w1, W4IC<1>{}); dma_w(W4IC<5>{}, w1, W4IC<1>{}); dma_w(W4IC<6>{}, w1, W4IC<1>{}); dma_w(W4IC<7>{}, w1, W4IC<1>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // slab 0, weights 0 visible (weights 1 still in flight: __syncthreads() would drain them)
+
+    if (G > 0) {
+        const int wp = aw + w4_wofs(0), xp = axk[0];
+        read_one(W4IC<0>{}, wp, xp, FA); read_one(W4IC<4>{}, wp, xp, FA); read_one(W4IC<1>{}, wp, xp, FA); read_one(W4IC<5>{}, wp, xp, FA);
+        read_one(W4IC<2>{}, wp, xp, FA); read_one(W4IC<6>{}, wp, xp, FA); read_one(W4IC<3>{}, wp, xp, FA); read_one(W4IC<7>{}, wp, xp, FA);
+    }
+
+    // K step t = 3 g + KW of group g: see the header comment
+    auto step = [&](auto KWc, int g) __attribute__((always_inline)) {
+        constexpr int KW = decltype(KWc)::value;
+        constexpr int SH = FLIP ? 2 - KW : KW, SHN = FLIP ? 2 - (KW + 1) % 3 : (KW + 1) % 3;
+        const int xs = (g & 1) * W4_BUF, xsn = ((g + 1) & 1) * W4_BUF;
+        const int wcur = aw + w4_wofs(KW), xcur = axk[KW] + xs;
+        const int wnext = aw + w4_wofs((KW + 1) % 3);
+        const int xnext = KW < 2 ? axk[(KW + 1) % 3] + xs : axk[0] + xsn;
+        // W(t+2): KW 0 -> (g, kw 2), KW 1 -> (g+1, kw 0), KW 2 -> (g+1, kw 1); it goes to the buffer step t-1 has just released
+        const char *wsrc = KW == 0 ? wgrp + 2 * tap_bytes : (KW == 1 ? wgrp_n : wgrp_n + tap_bytes);
+        const int xslab = (g + 1) & 1;
+        // DMA pieces of this step in issue order: [4 slab pieces (KW 0: 0-3, KW 1: 4-7)] then 8 weight pieces; 4 per sub-step
+        auto piece = [&](auto Pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(Pc)::value;
+            if constexpr (!DMA_ON) return;
+            constexpr int NX = KW < 2 ? 4 : 0;
+            if constexpr (p < NX) dma_x(W4IC<(KW == 1 ? 4 : 0) + (p < NX ? p : 0)>{}, xb_n, xv_n, xslab);
+            else if constexpr (p - NX < 8) dma_w(W4IC<(p - NX >= 0 && p - NX < 8) ? p - NX : 0>{}, wsrc, W4IC<(KW + 2) % 3>{});
+        };
+        auto hook_s = [&](auto Sc) __attribute__((always_inline)) {
+            return [&](auto MI) __attribute__((always_inline)) {
+                constexpr int s = decltype(Sc)::value, m = decltype(MI)::value;
+                constexpr int k = dma_slot(m);
+                if constexpr (k >= 0) piece(W4IC<(k >= 0 ? s * 4 + k : 0)>{});
+            };
+        };
+        constexpr int NP = KW < 2 ? 12 : 8;                               // pieces of this step
+        constexpr int ND0 = 4, ND1 = 4, ND2 = NP - 8;
+        // sched_barrier(0) at every sub-step boundary: without it hipcc hoists the edge fix of the NEXT sub-step's fragment up to the read that
+        // fetches it (an s_waitcnt lgkmcnt(0) on a fresh read in the middle of the MFMA stream)
+        __builtin_amdgcn_sched_barrier(0);
+        fix_edge(W4IC<SH>{}, FA);
+        mfma_range(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, FA, FB, wcur ^ (1 << 5), xcur ^ (1 << 5), hook_s(W4IC<0>{}));
+        pin(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, W4IC<DMA_ON ? ND0 : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fix_edge(W4IC<SH>{}, FB);
+        mfma_range(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, FB, FA, wcur ^ (2 << 5), xcur ^ (2 << 5), hook_s(W4IC<1>{}));
+        pin(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, W4IC<DMA_ON ? ND1 : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fix_edge(W4IC<SH>{}, FA);
+        if constexpr (ND2 > 0) mfma_range(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, FA, FB, wcur ^ (3 << 5), xcur ^ (3 << 5), hook_s(W4IC<2>{}));
+        else mfma_range(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, FA, FB, wcur ^ (3 << 5), xcur ^ (3 << 5), nohook);
+        pin(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, W4IC<DMA_ON ? ND2 : 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fix_edge(W4IC<SH>{}, FB);
+        // everything but the 8 youngest pieces (= W(t+2)) has landed: W(t+1), the slab pieces of this step; this wave's reads of buffer t are complete
+        if constexpr (LATE) {
+            mfma_range(W4IC<0>{}, W4IC<8>{}, W4IC<0>{}, FB, FA, wnext, xnext, nohook);
+            pin(W4IC<0>{}, W4IC<8>{}, W4IC<0>{}, W4IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);          // keeps those 8 MFMAs in front of the barrier (register-only instructions may cross an asm)
+        }
+        if constexpr (ABL == 5) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (DMA_ON) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (LATE) {
+            mfma_range(W4IC<8>{}, W4IC<16>{}, W4IC<2>{}, FB, FA, wnext, xnext, nohook);
+            pin(W4IC<8>{}, W4IC<16>{}, W4IC<2>{}, W4IC<0>{});
+        } else {
+            mfma_range(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, FB, FA, wnext, xnext, nohook);
+            pin(W4IC<0>{}, W4IC<16>{}, W4IC<1>{}, W4IC<0>{});
+        }
+        (void)SHN;
+    };
+
+    for (int g = 0; g < G; ++g) {
+        int cn, khn;
+        advance(g, cn, khn);
+        step(W4IC<0>{}, g);
+        step(W4IC<1>{}, g);
+        step(W4IC<2>{}, g);
+        c = cn; kh = khn; wgrp = wgrp_n;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();             // LDS is dead from here on (the epilogue reuses it)
@@ -377,6 +417,9 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     }
 }
 
+// taps of kernel row 0 ordered dw = +1, 0, -1 (the data gradient's order)?
+static bool w4_flipped(const ConvArgs &a) { return (int8_t)((a.taps[0] >> 8) & 0xff) == 1; }
+
 // The layers this kernel serves: one phase of 9 taps ordered (kh, kw) with dh constant per kernel row and the SAME dw order (-1, 0, +1 or reversed:
 // the data gradient) in every row, stride 1, image rows exactly 128 pixels wide (a 256-pixel tile = two whole image rows), zero padding,
 // Cin a multiple of 64, Co a multiple of 256, epilogue activation none / ReLU, bf16 result (no split-K / raw accumulators / fused norm-backward reductions).
@@ -403,9 +446,9 @@ bool w4_eligible(const ConvArgs &a) {
     return seen == 7;
 }
 
-template <int ABL, int SCHED>
+template <bool FLIP, int VAR, int ABL>
 static int launch_w4(const ConvArgs &a, hipStream_t stream) {
-    auto kern = conv_gemm_w4_kernel<ABL, SCHED>;
+    auto kern = conv_gemm_w4_kernel<FLIP, VAR, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS);
@@ -418,16 +461,35 @@ static int launch_w4(const ConvArgs &a, hipStream_t stream) {
     return 0;
 }
 
+template <int VAR, int ABL>
+static int launch_w4_dir(const ConvArgs &a, hipStream_t stream) {
+    return w4_flipped(a) ? launch_w4<true, VAR, ABL>(a, stream) : launch_w4<false, VAR, ABL>(a, stream);
+}
+
+#ifndef DL_W4_DEFAULT_VAR
+#define DL_W4_DEFAULT_VAR 1
+#endif
+
 int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
-    static const char *abl = getenv("DL_W4_ABLATE");
-    static const char *sched = getenv("DL_W4_SCHED");
-    const bool s1 = sched && sched[0] == '1';
-    if (abl && abl[0] == '1') return launch_w4<1, 0>(a, stream);
-    if (abl && abl[0] == '2') return launch_w4<2, 0>(a, stream);
-    if (abl && abl[0] == '3') return launch_w4<3, 0>(a, stream);
-    if (s1) return launch_w4<0, 1>(a, stream);
-    return launch_w4<0, 0>(a, stream);
+    static const char *abl = getenv("DL_W4_ABLATE");          // timing-only ablations, on the default variant
+    static const char *var = getenv("DL_W4_VAR");             // schedule variant 0..3 (A/B)
+    if (abl && abl[0] >= '1' && abl[0] <= '5') {
+        switch (abl[0]) {
+            case '1': return launch_w4_dir<DL_W4_DEFAULT_VAR, 1>(a, stream);
+            case '2': return launch_w4_dir<DL_W4_DEFAULT_VAR, 2>(a, stream);
+            case '3': return launch_w4_dir<DL_W4_DEFAULT_VAR, 3>(a, stream);
+            case '4': return launch_w4_dir<DL_W4_DEFAULT_VAR, 4>(a, stream);
+            default: return launch_w4_dir<DL_W4_DEFAULT_VAR, 5>(a, stream);
+        }
+    }
+    const int v = var ? var[0] - '0' : DL_W4_DEFAULT_VAR;
+    switch (v) {
+        case 0: return launch_w4_dir<0, 0>(a, stream);
+        case 2: return launch_w4_dir<2, 0>(a, stream);
+        case 3: return launch_w4_dir<3, 0>(a, stream);
+        default: return launch_w4_dir<1, 0>(a, stream);
+    }
 }
