@@ -1518,9 +1518,11 @@ static bool big_tile_fills_gpu(int mtot, int Co, int n_phase, int splitk) {
     return Co >= 256 && (Co % 256) == 0 && (size_t)((mtot + 255) / 256) * (Co / 256) * n_phase * splitk >= 224;
 }
 
+// conv_gemm_w4_kernel (conv_w4.hip) serves the ResnetBlock shape by default since r04; DL_CONV_W4=0 puts it back on the 8-phase kernel (same-box
+// A/B, profiles/r04/w4_v2_variants.txt: 158.9 -> 139.8 us per launch inside the training step, 103.9 -> 100.5 ms per step)
 static bool w4_enabled() {
     static const char *w4 = getenv("DL_CONV_W4");
-    return w4 && w4[0] == '1';
+    return !(w4 && w4[0] == '0');
 }
 
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {

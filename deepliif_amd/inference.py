@@ -152,7 +152,7 @@ def build_generators(opt, device, precision: Optional[str] = None) -> 'OrderedDi
     if model == 'CycleGAN' and _get(opt, 'BtoA', False):       # GB_i: B -> A (CycleGAN_model.py:82-85)
         cin, cout = opt.output_nc, opt.input_nc
     for n, arch in zip(g, net_g):
-        nets[n] = networks.define_G(cin, cout, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids, opt.padding)
+        nets[n] = networks.define_G(cin, cout, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids, opt.padding, _get(opt, 'upsample', 'convtranspose'))
     for n, arch in zip(gs, net_gs):
         nets[n] = networks.define_G(cin_s, opt.output_nc, opt.ngf, arch, opt.norm, False, 'normal', 0.02, ids)
     for net in nets.values():
@@ -211,7 +211,7 @@ def _nets_cache_key(model_dir, phase, eager_mode, opt):
     """the reference's lru_cache keys on (model_dir, eager_mode, opt, phase) (models/__init__.py:157); opt objects here are plain namespaces, so
     the fields that change what gets built / loaded stand in for them"""
     fields = tuple((k, repr(_get(opt, k, None))) for k in ('model', 'precision', 'epoch', 'norm', 'net_g', 'net_gs', 'ngf', 'padding', 'modalities_no', 'seg_gen',
-                                                           'input_no', 'gpu_ids', 'mod_id_seg', 'input_id'))
+                                                           'input_no', 'gpu_ids', 'mod_id_seg', 'input_id', 'BtoA', 'upsample', 'input_nc', 'output_nc'))
     return (os.path.abspath(model_dir), phase, bool(eager_mode), fields)
 
 
@@ -503,9 +503,12 @@ def _result_names(opt, results, seg_only, mod_only, return_seg_intermediate):
 
 
 def inference(img, tile_size, overlap_size, model_path, use_torchserve=False, eager_mode=False, color_dapi=False, color_marker=False, opt=None,
-              return_seg_intermediate=False, seg_only=False, mod_only=False, seg_weights=None, opt_args={}, nets=None, batch_size=8):
+              return_seg_intermediate=False, seg_only=False, mod_only=False, seg_weights=None, opt_args={}, nets=None, batch_size=8, rank=0, world=1):
     """Drop-in for deepliif.models.inference (deepliif/models/__init__.py:464-579): PIL image in, dict name -> PIL image out.
-    The tile loop runs on the GPU in batches (infer_region); `nets` / `batch_size` are extensions (default: init_nets(model_path))."""
+    The tile loop runs on the GPU in batches (infer_region); `nets` / `batch_size` are extensions (default: init_nets(model_path)).
+    rank / world (extension, BASELINE configs[4]): `world` ranks call this with the SAME image; each infers its band of tile rows, rank 0 gathers the
+    bands (gather_bands) and returns the dict, the other ranks return None.  Everything else -- seg_gen guard, input_no / SDG split, result names --
+    is this one code path whatever the world size.  With tile_size != scale_size (PIL resampling on the host) rank 0 does the whole image."""
     from PIL import Image
     if use_torchserve:
         raise NotImplementedError('the TorchServe client route is not part of the MI355X engine (use the in-process engine)')
@@ -527,10 +530,17 @@ def inference(img, tile_size, overlap_size, model_path, use_torchserve=False, ea
         origs = [img]
     scale = _get(opt, 'scale_size', tile_size)
     if tile_size == scale:
-        bands, _ = infer_region([_to_u8_device(o, device) for o in origs], tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights,
-                                batch_size)
+        bands, band = infer_region([_to_u8_device(o, device) for o in origs], tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights,
+                                   batch_size, rank=rank, world=world)
+        if world > 1:
+            keys = sorted(empty_tile_colors(opt, *_wrapper_flags(opt, seg_only, mod_only)))
+            bands = gather_bands(bands, band, origs[0].height, origs[0].width, keys, rank, world)
+            if bands is None:
+                return None
         results = {k: Image.fromarray(v.cpu().numpy()) for k, v in bands.items()}
     else:
+        if rank != 0:
+            return None
         results = _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mod_only, seg_weights, batch_size, scale)
     names = _result_names(opt, results, seg_only, mod_only, return_seg_intermediate)
     return {n: results[k] for n, k in names.items()}
@@ -621,15 +631,17 @@ def postprocess(orig, images, tile_size, model, seg_thresh=120, size_thresh='def
 
 
 def infer_modalities(img, tile_size, model_dir, eager_mode=False, color_dapi=False, color_marker=False, opt=None, return_seg_intermediate=False,
-                     seg_only=False, mod_only=False, seg_weights=None, nets=None, batch_size=8):
+                     seg_only=False, mod_only=False, seg_weights=None, nets=None, batch_size=8, rank=0, world=1):
     """Drop-in for deepliif.models.infer_modalities (deepliif/models/__init__.py:613-660): inference() with overlap tile_size // 16, then
-    postprocess() when the model has a segmentation branch.  -> (images, scoring)"""
+    postprocess() when the model has a segmentation branch.  -> (images, scoring).  rank / world: see inference(); ranks other than 0 get (None, None)."""
     if opt is None:
         opt = get_opt(model_dir)
         opt.use_dp = False
     images = inference(img, tile_size=tile_size, overlap_size=tile_size // 16, model_path=model_dir, eager_mode=eager_mode, color_dapi=color_dapi,
                        color_marker=color_marker, opt=opt, return_seg_intermediate=return_seg_intermediate, seg_only=seg_only, mod_only=mod_only,
-                       seg_weights=seg_weights, nets=nets, batch_size=batch_size)
+                       seg_weights=seg_weights, nets=nets, batch_size=batch_size, rank=rank, world=world)
+    if images is None:
+        return None, None
     if not hasattr(opt, 'seg_gen') or opt.seg_gen:
         if not mod_only:
             post_images, scoring = postprocess(img, images, tile_size, opt.model)

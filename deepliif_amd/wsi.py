@@ -135,26 +135,17 @@ def infer_slide(read_region: Callable[[int, int, int, int], 'object'], size_x: i
             if on_region is not None:
                 on_region(job.xywh, images, scoring)
             continue
-        # bands: every rank infers its tile rows of this region; rank 0 reassembles and post-processes
+        # bands: every rank infers its tile rows of this region; rank 0 reassembles and post-processes -- through the SAME infer_modalities() as the
+        # 'regions' mode (scale_size resampling, input_no / SDG split, seg_gen guard and the seg_only clean-up do not depend on the world size)
         import torch
-        if nets is None:
-            nets = I.init_nets(model_dir, eager_mode, opt)
-        device = next(next(iter(nets.values())).parameters()).device
-        reg_t = region if torch.is_tensor(region) else torch.from_numpy(np.ascontiguousarray(np.asarray(region, dtype=np.uint8)))
-        bands, band = I.infer_region([reg_t.to(device)], tile_size, tile_size // 16, nets, opt, seg_only, False, seg_weights, batch_size, rank=job.rank,
-                                     world=job.world)
-        keys = sorted(I.empty_tile_colors(opt, seg_only, False))
-        full = I.gather_bands(bands, band, h, w, keys, job.rank, job.world)
-        if full is None:
+        if torch.is_tensor(region):
+            region = region.cpu().numpy()
+        img = region if isinstance(region, Image.Image) else Image.fromarray(np.ascontiguousarray(np.asarray(region, dtype=np.uint8)))
+        images, scoring = I.infer_modalities(img, tile_size, model_dir, eager_mode=eager_mode, color_dapi=color_dapi, color_marker=color_marker, opt=opt,
+                                             return_seg_intermediate=return_seg_intermediate, seg_only=seg_only, seg_weights=seg_weights, nets=nets,
+                                             batch_size=batch_size, rank=job.rank, world=job.world)
+        if images is None:
             continue
-        results = {k: Image.fromarray(v.cpu().numpy()) for k, v in full.items()}
-        names = I._result_names(opt, results, seg_only, False, return_seg_intermediate)
-        images = {n: results[k] for n, k in names.items()}
-        scoring = None
-        if getattr(opt, 'seg_gen', True):
-            img = region if isinstance(region, Image.Image) else Image.fromarray(np.asarray(reg_t.cpu().numpy(), dtype=np.uint8))
-            post, scoring = I.postprocess(img, images, tile_size, opt.model)
-            images = {**images, **post}
         total = add_scoring(total, scoring)
         if on_region is not None:
             on_region(job.xywh, images, scoring)

@@ -80,13 +80,13 @@ def _setup():
     return I, opt, nets, slide
 
 
-def _reference_loop(I, opt, nets, slide, region_size):
+def _reference_loop(I, opt, nets, slide, region_size, tile_size=64, **kw):
     """infer_results_for_wsi restated: sequential regions, stand-alone infer_modalities per region, canvas paste, summed counts"""
     from PIL import Image
     h, w = slide.shape[:2]
     canv, total = {}, None
     for (x, y, rw, rh) in W.region_grid(w, h, region_size):
-        images, scoring = I.infer_modalities(Image.fromarray(slide[y:y + rh, x:x + rw]), 64, None, opt=opt, nets=nets, batch_size=3)
+        images, scoring = I.infer_modalities(Image.fromarray(slide[y:y + rh, x:x + rw]), tile_size, None, opt=opt, nets=nets, batch_size=3, **kw)
         total = W.add_scoring(total, scoring)
         W.paste_into(canv, (x, y, rw, rh), images, w, h)
     return canv, W.finish_scoring(total)
@@ -126,7 +126,11 @@ def _free_port():
     return p
 
 
-def _band_worker(rank, world, port, out):
+BAND_VARIANTS = {'plain': (64, {}), 'seg_only': (64, dict(seg_only=True)), 'resampled': (48, {})}      # tile 48 != scale_size 64: the PIL-resampling route
+
+
+def _band_worker(rank, world, port, out, variant='plain'):
+    tile_size, kw = BAND_VARIANTS[variant]
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')):
         sys.path.insert(0, p)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -136,8 +140,8 @@ def _band_worker(rank, world, port, out):
     I, opt, nets, slide = _setup()
     h, w = slide.shape[:2]
     canv = {}
-    plan, total = W.infer_slide(lambda x, y, rw, rh: slide[y:y + rh, x:x + rw], w, h, 64, None, nets=nets, opt=opt, region_size=200, rank=rank, world=world, batch_size=3,
-                                on_region=lambda xywh, images, scoring: W.paste_into(canv, xywh, images, w, h))
+    plan, total = W.infer_slide(lambda x, y, rw, rh: slide[y:y + rh, x:x + rw], w, h, tile_size, None, nets=nets, opt=opt, region_size=200, rank=rank, world=world,
+                                batch_size=3, on_region=lambda xywh, images, scoring: W.paste_into(canv, xywh, images, w, h), **kw)
     assert plan.mode == 'bands' and len(plan.regions) == 2
     if rank == 0:
         torch.save({'canv': canv, 'total': W.finish_scoring(total)}, os.path.join(out, 'bands.pt'))
@@ -147,19 +151,25 @@ def _band_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_fewer_regions_than_ranks_splits_every_region_into_bands(tmp_path):
+@pytest.mark.parametrize('variant', ['plain', 'seg_only', 'resampled'])
+def test_fewer_regions_than_ranks_splits_every_region_into_bands(tmp_path, variant):
+    """the 'bands' mode must give the images, keys and counts of the 'regions' mode / the reference loop also with seg_only
+    (non-Seg images dropped after post-processing) and with tile_size != scale_size (host resampling) -- both go through infer_modalities()"""
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, 'golden')):
         if p not in sys.path:
             sys.path.insert(0, p)
-    mp.spawn(_band_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)          # 2 regions (200 + 30 columns) on 3 ranks
+    tile_size, kw = BAND_VARIANTS[variant]
+    mp.spawn(_band_worker, args=(3, _free_port(), str(tmp_path), variant), nprocs=3, join=True)          # 2 regions (200 + 30 columns) on 3 ranks
     got = torch.load(tmp_path / 'bands.pt', weights_only=False)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         os.environ.pop(k, None)
     I, opt, nets, slide = _setup()
-    ref_canv, ref_total = _reference_loop(I, opt, nets, slide, 200)
+    ref_canv, ref_total = _reference_loop(I, opt, nets, slide, 200, tile_size, **kw)
     import fake_backend
     fake_backend.uninstall()
     assert sorted(got['canv']) == sorted(ref_canv)
+    if variant == 'seg_only':
+        assert all('Seg' in k for k in ref_canv)
     for k in ref_canv:
         assert np.array_equal(got['canv'][k], ref_canv[k]), k
     assert got['total'] == ref_total
