@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=${1:-a}
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/gpu_tests_r04$T.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/gpu_tests_r04$T.log
 cat gpurun_out/gpu_tests_r04$T.log
 cp gpurun_out/parity_errors_fullsize.json gpurun_out/parity_errors_fullsize_r04$T.json 2>/dev/null
 cp gpurun_out/parity_errors.json gpurun_out/parity_errors_r04$T.json 2>/dev/null
