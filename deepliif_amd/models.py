@@ -13,6 +13,7 @@ DeepLIIFExtModel / SDGModel, DeepLIIFKDModel (teacher through inference.init_net
 from __future__ import annotations
 
 import os
+import sys
 from collections import OrderedDict
 from typing import List, Optional
 
@@ -41,6 +42,28 @@ def init_input_and_mod_id(opt, dir_model=None):
     return mod_id_seg, input_id
 
 
+def pick_gpu(gpu_ids, is_train: bool, env=None) -> int:
+    """The GPU this PROCESS trains / infers on.  One id: that one.  Several ids (`--gpu-ids 0 --gpu-ids 1`): the reference wraps every net in
+    nn.DataParallel(net, gpu_ids) (networks.py:136, "Multi-GPU Training.md":20-33) -- ONE process scattering each batch.  This engine is one
+    process per GPU: under torchrun / `deepliif trainlaunch` (LOCAL_RANK set, networks.py:131-134) rank r takes gpu_ids[r]; a single process
+    with several ids re-executes itself as `python -m torch.distributed.run --nproc-per-node <n>` when DEEPLIIF_AMD_AUTO_TORCHRUN=1 and otherwise
+    stops with that command line -- the ONE behaviour change of the CLI.  Inference uses gpu_ids[0]."""
+    env = os.environ if env is None else env
+    if not gpu_ids:
+        raise L.HipLibraryError('deepliif_amd models run on MI355X only: opt.gpu_ids must name a GPU (no CPU fallback)')
+    ids = list(gpu_ids)
+    if len(ids) == 1 or not is_train:
+        return int(ids[0])
+    if 'LOCAL_RANK' in env and int(env.get('WORLD_SIZE', '1')) > 1:
+        return int(ids[int(env['LOCAL_RANK']) % len(ids)])
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1', f'--nproc-per-node={len(ids)}'] + sys.argv
+    if env.get('DEEPLIIF_AMD_AUTO_TORCHRUN') == '1':
+        os.execv(sys.executable, cmd)
+    raise NotImplementedError(f'single-process multi-GPU training (gpu_ids={ids}, nn.DataParallel in the reference) is not supported: this engine runs one '
+                              f'process per GPU.  Launch:  {" ".join(cmd)}   (or set DEEPLIIF_AMD_AUTO_TORCHRUN=1 to have this done for you; every rank '
+                              'then takes gpu_ids[LOCAL_RANK] and the gradients are averaged over RCCL, deepliif_amd.distributed)')
+
+
 class BaseModel:
     """deepliif/models/base_model.py surface."""
 
@@ -59,15 +82,7 @@ class BaseModel:
         self.precision = E.Precision.get(_get(opt, 'precision', networks.DEFAULT_PRECISION))
 
     def _device_from_opt(self, opt) -> torch.device:
-        if not opt.gpu_ids:
-            raise L.HipLibraryError('deepliif_amd models run on MI355X only: opt.gpu_ids must name a GPU (no CPU fallback)')
-        if self.is_train and len(opt.gpu_ids) > 1:
-            # the reference wraps every net in nn.DataParallel(net, gpu_ids) here (networks.py:136): one process scattering each batch.
-            # This engine is one process per GPU (torchrun / `deepliif trainlaunch`, networks.py:131-134) -- refuse rather than silently
-            # train on gpu_ids[0] only
-            raise NotImplementedError(f'single-process multi-GPU training (gpu_ids={list(opt.gpu_ids)}, nn.DataParallel in the reference) is not '
-                                      'supported: launch one process per GPU with torchrun (deepliif_amd.distributed)')
-        dev = torch.device('cuda:{}'.format(opt.gpu_ids[0]))
+        dev = torch.device('cuda:{}'.format(pick_gpu(opt.gpu_ids, self.is_train)))
         torch.cuda.set_device(dev)          # cli.py:250-256 does this before building the model; kernels launch on the tensors' device anyway
         return dev
 
@@ -109,6 +124,7 @@ class BaseModel:
             flat = getattr(o, 'flat', None)
             if flat is None:
                 continue
+            o.dp_tag = next((n[len('optimizer_'):] for n in ('optimizer_G', 'optimizer_D') if getattr(self, n, None) is o), 'opt')      # diagnostics label
             owned = {id(p) for p in flat.params}
             for _, net in self._nets():
                 params = list(net.parameters())

@@ -66,7 +66,16 @@ def _worker(rank, world, port, out, progressive=False):
     flat = model.optimizer_G.flat
     expect = [flat.slice_of(list(getattr(model, 'net' + n).parameters())) for n in reversed(model.model_names_g)]
     if not progressive:
-        assert logs[-1] == expect, (logs[-1], expect)
+        # one message per network -- except the network whose backward ENDS the pass (the first one of the optimizer): as one message it
+        # would only start when nothing is left to hide it behind, so it leaves in two halves, tail first (VERDICT r3 #8a)
+        log = logs[-1]
+        assert log[:len(expect) - 1] == expect[:-1], (log, expect)
+        s, e = expect[-1]
+        last = log[len(expect) - 1:]
+        assert len(last) == 2 and last[0][1] == e and last[0][0] == last[1][1] and last[1][0] == s, (last, (s, e))
+        assert 0.3 * (e - s) <= last[0][1] - last[0][0] <= 0.8 * (e - s), last
+        pl = model.exchange.pass_log[-1]
+        assert pl['tag'] == 'G' and pl['bytes'] == 4 * flat.numel and pl['calls'] == len(log), pl
     else:
         # every generator slice left in several buckets, tail first, and the buckets tile the slice exactly
         log = logs[-1]
