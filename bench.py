@@ -98,6 +98,33 @@ class KernelTimer:
         return v[len(v) // 2] * 1e-3
 
 
+def mfma_sustained(dev, launches=12, iters=240):
+    """What the matrix cores of THIS box sustain on v_mfma_f32_32x32x16_bf16 with nothing else in the way (dl_probe_mfma_sustained: 256 workgroups x 4
+    waves, 16 accumulators + 16 operand fragments per wave, register-resident), on random N(0,1) operand bits and on zeros: the chip clocks to
+    its power budget, so the denominator of `frac` is data-dependent.  -> {'random_tflops', 'zero_tflops'} (event-timed)."""
+    import ctypes as C
+    from deepliif_amd import _lib as L
+    lib = L.load()
+    blocks = 256
+    n = int(lib.dl_probe_mfma_sustained_elems(blocks))
+    sink = torch.zeros(4, device=dev)
+    out = {}
+    for tag in ('random', 'zero'):
+        data = (torch.randn(n, device=dev) if tag == 'random' else torch.zeros(n, device=dev)).to(torch.bfloat16)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            L.check(lib.dl_probe_mfma_sustained(C.c_void_p(data.data_ptr()), blocks, iters, C.c_void_p(sink.data_ptr()), st), 'dl_probe_mfma_sustained')
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            L.check(lib.dl_probe_mfma_sustained(C.c_void_p(data.data_ptr()), blocks, iters, C.c_void_p(sink.data_ptr()), st), 'dl_probe_mfma_sustained')
+        e1.record()
+        torch.cuda.synchronize()
+        out[f'{tag}_tflops'] = round(blocks * 4 * iters * 64 * 32768.0 * launches / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    return out
+
+
 def usable_cores():
     """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (containers)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -434,6 +461,14 @@ def main():
                     'traffic': traffic, 'traffic_note': traffic_note,
                     'kernel': f'{dom_kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload not in ('infer', 'wsi') else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': n_pairs, 'avg_launch_us': round(kt * 1e6, 2), 'median_launch_us': round(kt_median * 1e6, 2)}
+        if not dry and rank == 0 and args.workload == 'train':
+            try:
+                sus = mfma_sustained(dev)
+                roofline['sustained'] = {**sus, 'what': 'register-resident v_mfma_f32_32x32x16_bf16 loop on this box (dl_probe_mfma_sustained), random N(0,1) / zero operand '
+                                                        'bits: the clock the matrix cores hold under their own power draw is data-dependent',
+                                         'frac_of_sustained_random': round(ach / sus['random_tflops'], 4)}
+            except Exception as exc:          # measurement aid only
+                roofline['sustained'] = {'error': str(exc)[:200]}
         if dt_noev is not None:
             roofline['timer_overhead'] = {'ms_per_step_with_events': round(dt / args.steps * 1e3, 3), 'ms_per_step_without_events': round(dt_noev / args.steps * 1e3, 3),
                                           'relative': round(dt / dt_noev - 1.0, 5),

@@ -110,6 +110,8 @@ SIGNATURES = {
     'dl_tile_paste_u8': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i64, _vp]),
     'dl_probe_mfma16': (_i, [_vp, _vp, _vp, _vp]),
     'dl_probe_trread': (_i, [_vp, _vp, _vp]),
+    'dl_probe_mfma_sustained_elems': (C.c_size_t, [_i]),
+    'dl_probe_mfma_sustained': (_i, [_vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None
@@ -133,8 +135,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 108:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 108 (stale build)')
+    if lib.dl_version() != 109:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 109 (stale build)')
     _lib = lib
     return lib
 

@@ -108,14 +108,33 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
         valid = (unsigned)(h0 + R + dh) < (unsigned)a.Hi;
         return xg + ((ptrdiff_t)dh * a.Wi * a.in_pstride + c * 64) * 2;
     };
+    // VAR bit 2 / bit 3: weight / activation pieces by buffer_load ... lds (resource in SGPRs, loop-invariant 32-bit lane offset, the per-step
+    // part of the address in the scalar offset) instead of global_load_lds with a 64-bit VALU address add (and two v_cndmask for the zero
+    // page) per piece: with one wave per SIMD every VALU instruction next to a DMA piece comes out of the MFMA issue stream.  An image row
+    // outside the tensor is fetched through a resource with num_records = 0: out-of-range buffer loads deliver zeros.
+    constexpr bool WBUF = (VAR & 4) != 0, XBUF = (VAR & 8) != 0;
+    const ptrdiff_t row_bytes = (ptrdiff_t)a.Wi * a.in_pstride * 2;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xg - row_bytes), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xg - row_bytes), 0, 0, 0x00020000);
     auto dma_x = [&](auto I, const char *base, bool valid, int slab) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
+        if constexpr (XBUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(valid ? rsrc_x : rsrc_0, (__attribute__((address_space(3))) void *)(lds + x_dst0 + slab * W4_BUF + i * 1024), 16,
+                                                     (int)x_off[i], (int)(base - (xg - row_bytes)), 0, 0);
+            return;
+        }
         const char *src = valid ? base + x_off[i] : zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(lds + x_dst0 + slab * W4_BUF + i * 1024), 16, 0, 0);
     };
     auto dma_w = [&](auto I, const char *base, auto BUF) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value, buf = decltype(BUF)::value;
+        if constexpr (WBUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void *)(lds + w_dst0 + w4_wofs(buf) + i * 1024), 16, (int)w_off[i],
+                                                     (int)(base - wg), 0, 0);
+            return;
+        }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + w_off[i]),
                                          (__attribute__((address_space(3))) void *)(lds + w_dst0 + w4_wofs(buf) + i * 1024), 16, 0, 0);
     };
@@ -475,7 +494,7 @@ int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
     static const char *abl = getenv("DL_W4_ABLATE");          // timing-only ablations, on the default variant
-    static const char *var = getenv("DL_W4_VAR");             // schedule variant 0..3 (A/B)
+    static const char *var = getenv("DL_W4_VAR");             // schedule / DMA variant (A/B): bits as documented at the kernel
     if (abl && abl[0] >= '1' && abl[0] <= '5') {
         switch (abl[0]) {
             case '1': return launch_w4_dir<DL_W4_DEFAULT_VAR, 1>(a, stream);
@@ -485,11 +504,61 @@ int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
             default: return launch_w4_dir<DL_W4_DEFAULT_VAR, 5>(a, stream);
         }
     }
-    const int v = var ? var[0] - '0' : DL_W4_DEFAULT_VAR;
+    const int v = var ? atoi(var) : DL_W4_DEFAULT_VAR;
     switch (v) {
         case 0: return launch_w4_dir<0, 0>(a, stream);
-        case 2: return launch_w4_dir<2, 0>(a, stream);
         case 3: return launch_w4_dir<3, 0>(a, stream);
+        case 5: return launch_w4_dir<5, 0>(a, stream);
+        case 13: return launch_w4_dir<13, 0>(a, stream);
         default: return launch_w4_dir<1, 0>(a, stream);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// dl_probe_mfma_sustained: the denominator of the roofline line measured instead of quoted.  One workgroup per CU slot, four
+// waves, each with the register set of conv_gemm_w4_kernel: 16 accumulators of v_mfma_f32_32x32x16_bf16 and 8 + 8 operand fragments.  The
+// fragments are loaded ONCE from `data` (random bf16 from the caller: the matrix cores' power draw, and with it the clock the chip sustains,
+// depends on the operand bits -- zero-filled operands run ~25 % faster than random ones on this part) and then `iters` x 64 MFMAs run
+// register-resident: no LDS, no DMA, no barrier.  flops = blocks * 4 waves * iters * 64 * 32768; the caller times it with events.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) probe_mfma_sustained_kernel(const bf16_t *data, int iters, float *sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16x8_t F[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+        F[f] = *reinterpret_cast<const bf16x8_t *>(data + ((size_t)((blockIdx.x * 4 + wave) * 16 + f) * 64 + lane) * 8);
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i + 4 * (s & 1)], F[8 + j + 4 * (s >> 1)], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 12345.678f) sink[0] = t;          // keeps the accumulators alive; practically never true
+}
+
+extern "C" size_t dl_probe_mfma_sustained_elems(int blocks) { return (size_t)blocks * 4 * 16 * 64 * 8; }
+
+extern "C" int dl_probe_mfma_sustained(const void *data, int blocks, int iters, float *sink, void *stream_) {
+    if (!data || !sink || blocks <= 0 || iters <= 0) DL_FAIL("dl_probe_mfma_sustained: bad arguments");
+    hipLaunchKernelGGL(probe_mfma_sustained_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, reinterpret_cast<const bf16_t *>(data), iters, sink);
+    DL_CHECK_LAUNCH("dl_probe_mfma_sustained");
+    return 0;
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 108
+#define DL_VERSION 109
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -353,6 +353,11 @@ int dl_tile_paste_u8(int in_dtype, const void *tiles, int in_pstride, int tile, 
 /* hardware probes used by the GPU test-suite (MFMA fragment layouts, ds_read_b64_tr_b16 semantics) */
 int dl_probe_mfma16(const uint16_t *a /*16x32 bf16 row-major*/, const uint16_t *b /*32x16*/, float *d /*16x16*/, void *stream);
 int dl_probe_trread(const uint16_t *src /*64 rows x 16 cols bf16*/, uint16_t *dst /*64 lanes x 4*/, void *stream);
+/* Sustained matrix-core rate of THIS box on caller-supplied operand bits (bench.py: roofline.sustained): `blocks` workgroups of four waves, each
+ * running iters x 64 register-resident v_mfma_f32_32x32x16_bf16 (the register set of conv_gemm_w4_kernel) on 16 fragments read once from `data`
+ * (dl_probe_mfma_sustained_elems(blocks) bf16 values).  flops = blocks * 4 * iters * 64 * 32768.  No reference counterpart: measurement only. */
+size_t dl_probe_mfma_sustained_elems(int blocks);
+int dl_probe_mfma_sustained(const void *data, int blocks, int iters, float *sink, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Segmentation post-processing (deepliif/postprocessing.py: get_cells_info :311-362 = create_posneg_mask :163-190 + mark_background
