@@ -486,7 +486,7 @@ static int launch_w4_dir(const ConvArgs &a, hipStream_t stream) {
 }
 
 #ifndef DL_W4_DEFAULT_VAR
-#define DL_W4_DEFAULT_VAR 1
+#define DL_W4_DEFAULT_VAR 13
 #endif
 
 int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
@@ -505,12 +505,14 @@ int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
         }
     }
     const int v = var ? atoi(var) : DL_W4_DEFAULT_VAR;
+    // default 13 = separated shadows + weights and activations by buffer_load lds (same-box A/B, profiles/r04/w4_dma_variants.txt: 138.3 / 137.4 us per
+    // launch in the training step with global_load_lds (1), 136.9 / 137.1 with the weights on buffer loads (5), 135.2 / 135.7 with both (13))
     switch (v) {
         case 0: return launch_w4_dir<0, 0>(a, stream);
         case 3: return launch_w4_dir<3, 0>(a, stream);
+        case 1: return launch_w4_dir<1, 0>(a, stream);
         case 5: return launch_w4_dir<5, 0>(a, stream);
-        case 13: return launch_w4_dir<13, 0>(a, stream);
-        default: return launch_w4_dir<1, 0>(a, stream);
+        default: return launch_w4_dir<13, 0>(a, stream);
     }
 }
 
