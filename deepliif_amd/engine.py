@@ -126,10 +126,14 @@ def settle_gc():
     took 75 ms on the benched step, during which no kernel is issued (tools/step_jitter.py on MI355X: median 101.75 ms, every 21st step 175-182 ms,
     mean 105.6 ms).  gc.freeze() moves everything that exists NOW (the long-lived model) into the permanent generation, which full collections skip:
     they drop below 1 ms (mean 102.25 ms, max 103.75 ms over 60 steps).  Nothing is ever leaked by this -- frozen objects are still freed by reference
-    counting; only cycles among objects that existed at this moment would stay until exit.  DEEPLIIF_AMD_GC_FREEZE=0 leaves the collector alone."""
+    counting; only cycles among objects that existed at this moment stay until the next call (which unfreezes first) or exit.  It is a process-wide change of the
+    interpreter's collector made by a library constructor: INTEGRATION.md section 1 lists it; DEEPLIIF_AMD_GC_FREEZE=0 leaves the collector alone."""
     if os.environ.get('DEEPLIIF_AMD_GC_FREEZE', '1') == '0':
         return
     import gc
+    # unfreeze first (ADVICE r3): whatever an EARLIER call froze and the host application has dropped since (a previous model of a sweep, a test's
+    # fixture) becomes collectable again -- cycles included -- before the objects alive NOW are moved to the permanent generation
+    gc.unfreeze()
     gc.collect()            # every call: a model built later (a DeepLIIFKD student after its teacher) is settled as well
     gc.freeze()
 

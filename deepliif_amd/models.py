@@ -761,13 +761,15 @@ class DeepLIIFKDModel(DeepLIIFModel):
     FACTOR_KLDIV = 10.0
 
     def __init__(self, opt):
-        opt.seg_gen = True                          # DeepLIIFKD_model.py builds the seg generators unconditionally (:55-60, 95-98)
+        # The caller's option object is left as it came: the base class is built from a shallow copy that carries what
+        # DeepLIIFKD_model.py hard-wires -- seg generators built unconditionally (:55-60, 95-98), criterionGAN_BCE / criterionGAN_lsgan (:130-131)
+        import copy
+        opt = copy.copy(opt)
+        opt.seg_gen = True
         if getattr(opt, 'netG', None) is None and hasattr(opt, 'net_g'):
             opt.netG = opt.net_g
-        gm, gms = _get(opt, 'gan_mode', 'vanilla'), _get(opt, 'gan_mode_s', 'lsgan')
-        opt.gan_mode, opt.gan_mode_s = 'vanilla', 'lsgan'          # criterionGAN_BCE / criterionGAN_lsgan are fixed (:130-131)
+        opt.gan_mode, opt.gan_mode_s = 'vanilla', 'lsgan'
         super().__init__(opt)
-        opt.gan_mode, opt.gan_mode_s = gm, gms
         M, S = opt.modalities_no, self.mod_id_seg
         # ---- names (:33-45): per modality ..., G_KLDiv_i, G_KLDiv_S{i}; then the seg names, G_KLDiv_S and (again) G_KLDiv_S{M}
         self.loss_names = []
@@ -797,6 +799,9 @@ class DeepLIIFKDModel(DeepLIIFModel):
         self.opt_teacher = I.get_opt(tdir, mode='test')
         self.opt_teacher.gpu_ids = opt.gpu_ids                       # use the student's device (:110)
         self.opt_teacher.precision = self.precision.name             # same storage type: the distillation kernel reads both tensors
+        if self.precision.name != 'fp32':
+            print(f'deepliif_amd: the DeepLIIFKD teacher runs on the student\'s precision policy ({self.precision.name}); the reference runs it in fp32 '
+                  '(set opt.precision = "fp32" for a strict-policy teacher and student)')
         self.nets_teacher = I.init_nets(tdir, eager_mode=True, opt=self.opt_teacher, phase='test')
         t_seg, t_in = _get(self.opt_teacher, 'mod_id_seg', 'S'), str(_get(self.opt_teacher, 'input_id', '0'))
         self.opt_teacher.mod_id_seg, self.opt_teacher.input_id = t_seg, t_in

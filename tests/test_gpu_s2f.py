@@ -1,0 +1,39 @@
+"""The fused four-phase tile (csrc/conv_s2f.hip) below its size rule: dl_conv_forward only sends layers with >= 256 phase-grid tiles to it, so the small
+kernel-test shapes (and the fused-statistics case, 2 x 16 x 16) never reach it in the main test process.  The library reads DL_CONV_S2F once per process:
+the same kernel tests run again in a child process with DL_CONV_S2F=2 (size rule lifted) -- forward + data gradient against the emulated reference, fused
+statistics against the stand-alone pass, run-to-run equality."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernel_tests_with_the_fused_stride2_tile_forced():
+    env = dict(os.environ, DL_CONV_S2F='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_kernels.py'), '-m', 'gpu', '-q', '-x', '-k',
+                        'bf16 and (big_tiles or fused_norm_statistics or conv_forward_and_dgrad)'], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]
+
+
+def test_the_dispatch_names_the_fused_tile_for_the_generator_layers():
+    import torch
+    from deepliif_amd import _lib as L, ops
+    from deepliif_amd.engine import Precision
+    from deepliif_amd.geometry import ConvSpec
+    be = ops.impl()
+    prec = Precision.get('bf16')
+    spec = ConvSpec('convT', 128, 64, 3, 2, 1, L.PAD_ZERO, 1)
+    w = torch.randn(128, 64, 3, 3, device='cuda') * 0.02
+    pf = ops.PackedWeights(spec.forward_plan(), 'cuda', False)
+    be.pack_weights(pf, w)
+    x = torch.randn(1, 256, 256, 128, device='cuda').to(prec.dtype)
+    out = torch.empty(1, 512, 512, 64, device='cuda', dtype=prec.dtype)
+    be.conv_forward(pf, x, out, 256, 256, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+    torch.cuda.synchronize()
+    expect = 'conv_gemm_glds_kernel<128,64,64>' if os.environ.get('DL_CONV_S2F') == '0' else 'conv_s2f_kernel'
+    assert be.last_conv_kernel == expect
