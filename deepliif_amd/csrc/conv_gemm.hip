@@ -17,6 +17,9 @@
 // conv_w4.hip: the one-wave-per-SIMD kernel of the ResnetBlock shape
 bool w4_eligible(const ConvArgs &a);
 int launch_conv_w4(const ConvArgs &a0, hipStream_t stream);
+// conv_w4x3.hip: the same tile for the strict policy (split-copy activations, hi / lo weight images, three MFMAs per product)
+bool w4x3_eligible(const ConvArgs &a);
+int launch_conv_w4x3(const ConvArgs &a0, hipStream_t stream);
 // conv_s2f.hip: the fused four-phase tile of the stride-2 layers (transposed conv forward, stride-2 data gradients)
 bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
@@ -1674,7 +1677,16 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
     const int bm = glds_tile_bm(d);
-    if (bm == 0 && x3_glds_applies(d)) return x3_kernel_name(d);
+    if (bm == 0 && x3_glds_applies(d)) {
+        if (w4x3_enabled()) {
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            fill_conv_geometry(a, d);
+            a.w_lo = reinterpret_cast<const bf16_t *>(&a);          // (only its presence is tested)
+            if (w4x3_eligible(a)) return "conv_gemm_w4x3_kernel";
+        }
+        return x3_kernel_name(d);
+    }
     if (bm == 0) return (d->in_dtype == DL_BF16) ? "conv_gemm_kernel<bf16>" : "conv_gemm_kernel<f32>";
     if (d->Co <= 16) return "conv_gemm_glds_kernel<256,16,32>";
     if (d->Co <= 64) return "conv_gemm_glds_kernel<128,64,64>";

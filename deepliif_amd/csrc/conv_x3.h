@@ -811,8 +811,15 @@ static const char *x3_kernel_name(const dl_conv_desc *d) {
     return "conv_gemm_glds_x3_kernel<128,128>";
 }
 
+// conv_gemm_w4x3_kernel (conv_w4x3.hip) serves the ResnetBlock shape with split-copy inputs; DL_CONV_W4X3=0 keeps it on the 8-phase strict kernel (A/B)
+static bool w4x3_enabled() {
+    static const char *e = getenv("DL_CONV_W4X3");
+    return !(e && e[0] == '0');
+}
+
 static int dispatch_tile_x3(const ConvArgs &a, hipStream_t stream) {
     if (x3_big_tile(a.in_act, a.pad_mode, a.Ci, a.Mtot, a.Co, a.n_phase, a.splitk)) {
+        if (w4x3_enabled() && w4x3_eligible(a)) return launch_conv_w4x3(a, stream);
         static const char *abl = getenv("DL_CONV_ABLATE");
         if (abl && abl[0] == '1') return launch_conv_8ph_x3<DL_ACT_NONE, 1>(a, stream);
         if (abl && abl[0] == '2') return launch_conv_8ph_x3<DL_ACT_NONE, 2>(a, stream);

@@ -949,10 +949,16 @@ def test_split_copy_inputs_are_bit_identical_to_the_in_kernel_split(case):
             hq, wq = ((H + 1) // 2, (W_ + 1) // 2) if (kind == 'conv' and s_ == 2) else (H, W_)
         a, b = torch.empty(oshape, device=DEV), torch.empty(oshape, device=DEV)
         real.conv_forward(packed, src, a, hq, wq, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+        k_plain = real.last_conv_kernel
         real.conv_forward(packed, srcs, b, hq, wq, None, L.ACT_NONE, L.ACT_NONE, prec.prec, in_split=True)
         sync()
         assert 'x3' in real.last_conv_kernel, real.last_conv_kernel
-        assert torch.equal(a, b), plan_kind
+        if real.last_conv_kernel == k_plain:
+            assert torch.equal(a, b), plan_kind
+        else:
+            # the ResnetBlock shape: split copies go to conv_gemm_w4x3_kernel (r04), fp32 inputs stay on the 8-phase strict kernel -- same split
+            # formula and products, another summation order (32x32x16 fragments, (chunk, kh, kw) K order)
+            assert real.last_conv_kernel == 'conv_gemm_w4x3_kernel' and rel(b, a) < 2e-6, (plan_kind, real.last_conv_kernel, rel(b, a))
     gshape = wshape
     P, Ps, Q, Qs = (dy, dys, x, xs) if kind == 'conv' else (x, xs, dy, dys)
     g0 = torch.empty(gshape, device=DEV)
@@ -962,3 +968,45 @@ def test_split_copy_inputs_are_bit_identical_to_the_in_kernel_split(case):
         real.conv_wgrad(Ps if ps else P, Qs if qs else Q, g1, k, s_, p, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, prec.prec, False, p_split=ps, q_split=qs)
         sync()
         assert torch.equal(g0, g1), ('wgrad', ps, qs)
+
+
+@pytest.mark.parametrize('case', [(256, 256, 8, 128), (64, 256, 4, 64), (256, 512, 2, 128)], ids=lambda c: f'ci{c[0]}-co{c[1]}-n{c[2]}-h{c[3]}')
+def test_strict_w4_kernel_on_split_copies(case):
+    """conv_gemm_w4x3_kernel (csrc/conv_w4x3.hip): the ResnetBlock conv under the strict policy with a split-copy input -- forward (fused statistics,
+    bias) and data gradient (reversed kw order) against the fp32 reference of the emulation backend at fp32-class tolerance, run-to-run identical,
+    image borders (zero rows through the num_records = 0 resource, zeroed edge lanes) included by construction of the shape."""
+    cin, cout, N, H = case
+    W_ = 128
+    prec = Precision.get('fp32')
+    spec = ConvSpec('conv', cin, cout, 3, 1, 1, L.PAD_ZERO, 0)
+    w = rnd((cout, cin, 3, 3), 1, prec, 0.05)
+    bias = rnd((cout,), 2, prec, 0.1)
+    x = rnd((N, H, W_, cin), 3, prec)
+    dy = rnd((N, H, W_, cout), 4, prec)
+    fake, real = fake_backend.FakeBackend(), hip()
+    exp_f = _run_conv(fake, 'fwd', spec, prec, x, w, bias, L.ACT_NONE, L.ACT_NONE, H, W_)
+    exp_d = _run_conv(fake, 'dgrad', spec, prec, dy, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+    for plan_kind, src, exp, b in (('fwd', x, exp_f, bias), ('dgrad', dy, exp_d, None)):
+        plan = spec.forward_plan() if plan_kind == 'fwd' else spec.dgrad_plan()
+        packed = ops.PackedWeights(plan, DEV, True)
+        real.pack_weights(packed, w.to(DEV))
+        srcs = _split_copy(src.to(DEV))
+        outs = []
+        for rep in range(2):
+            o = torch.empty(exp.shape, device=DEV)
+            nch = real.conv_forward(packed, srcs, o, H, W_, None if b is None else b.to(DEV), L.ACT_NONE, L.ACT_NONE, prec.prec, in_split=True,
+                                    want_stats=(plan_kind == 'fwd'))
+            sync()
+            outs.append(o)
+        if os.environ.get('DL_CONV_W4X3') != '0':
+            assert real.last_conv_kernel == 'conv_gemm_w4x3_kernel', real.last_conv_kernel
+        assert torch.equal(outs[0], outs[1]), 'run-to-run difference'
+        assert rel(outs[0], exp) < 2e-5, (plan_kind, rel(outs[0], exp))
+        if plan_kind == 'fwd':
+            assert nch == H * W_ // 256
+            z1, z2 = torch.empty_like(outs[0]), torch.empty_like(outs[0])
+            st1 = real.norm_forward(outs[0], z1, cout, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, -1.0, None, ext_nchunks=nch)
+            st2 = real.norm_forward(outs[0], z2, cout, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, -1.0, None)
+            sync()
+            assert rel(st1[0], st2[0]) < 1e-5 and rel(st1[1], st2[1]) < 1e-5 and rel(z1, z2) < 1e-5
+

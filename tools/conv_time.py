@@ -22,6 +22,15 @@ if data == 'zero':
 elif data == 'bf16':
     w, x, dy = w.bfloat16().float(), x.bfloat16().to(prec.dtype), dy.bfloat16().to(prec.dtype)
 out = torch.empty_like(x)
+SPLIT = os.environ.get('TIME_SPLIT') == '1' and prec.prec == L.PREC_BF16X3      # strict policy: feed the producer-written split copies (conv_gemm_w4x3_kernel's input)
+if SPLIT:
+    def _split_copy(t):
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        g = torch.stack([hi.reshape(*t.shape[:3], -1, 8), lo.reshape(*t.shape[:3], -1, 8)], dim=4)
+        return g.contiguous().view(torch.int16).reshape(*t.shape[:3], -1).view(torch.float32).reshape(t.shape)
+    x, dy = _split_copy(x), _split_copy(dy)
+KW = {'in_split': True} if SPLIT else {}
 pf = ops.PackedWeights(spec.forward_plan(), DEV, prec.prec == L.PREC_BF16X3); be.pack_weights(pf, w)
 pd = ops.PackedWeights(spec.dgrad_plan(), DEV, prec.prec == L.PREC_BF16X3); be.pack_weights(pd, w)
 grad = torch.zeros(256, 256, 3, 3, device=DEV)
@@ -42,9 +51,9 @@ def timeit(fn, iters=20, warm=3):
 
 res = {}
 if 'fwd' in which:
-    res['fwd_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec)); res['fwd_kernel'] = be.last_conv_kernel
+    res['fwd_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, **KW)); res['fwd_kernel'] = be.last_conv_kernel
 if 'dgrad' in which:
-    res['dgrad_us'] = timeit(lambda: be.conv_forward(pd, dy, out, 128, 128, None, 0, 0, prec.prec))
+    res['dgrad_us'] = timeit(lambda: be.conv_forward(pd, dy, out, 128, 128, None, 0, 0, prec.prec, **KW))
 if 'wgrad' in which:
     res['wgrad_us'] = timeit(lambda: be.conv_wgrad(dy, x, grad, 3, 1, 1, L.PAD_ZERO, 0, 0, prec.prec, False))
 gf = 2 * 8 * 128 * 128 * 256 * 2304 / 1e9
