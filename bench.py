@@ -206,6 +206,7 @@ def main():
     ap.add_argument('--no-timer-check', action='store_true', help='skip the second pass that times the same steps WITHOUT the per-launch events '
                     '(roofline.timer_overhead)')
     ap.add_argument('--no-strict', action='store_true', help='skip the strict-parity (fp32 policy) leg')
+    ap.add_argument('--no-graph', action='store_true', help='skip the hipGraph-replay leg (the same steps replayed from a captured graph, models.StepGraph)')
     ap.add_argument('--strict', action='store_true', help='time the strict-parity leg also when WORLD_SIZE > 1 (by default a multi-GPU run only carries the '
                     'headline policy: the scaling curve should not pay for a second model and 8 more steps per rank)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -262,6 +263,8 @@ def main():
             torch.distributed.barrier()
         sync()
 
+    last_batch = {}
+
     def build(precision):
         """-> (step function, model or None, GF per tile, dominant conv shape, workload description) for args.workload on `precision`"""
         torch.manual_seed(0)
@@ -273,6 +276,7 @@ def main():
             model = M.create_model(opt)
             model.setup(opt)
             batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}
+            last_batch[precision] = batch
             return (lambda: (model.set_input(batch), model.optimize_parameters())), model, GF_PER_TILE_TRAIN_5R5D, dom, \
                 'DeepLIIF train step, 5x Resnet-9block G + 5x NLayerD(n=4), GAN+SmoothL1+Adam (BASELINE configs[2] per GPU)'
         if args.workload == 'ext':
@@ -284,6 +288,7 @@ def main():
             batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(2)], 'BS': [synth(1255 + i) for i in range(2)], 'A_paths': ['synthetic']}
             # per tile: generators forward + 2x backward; every discriminator: 2 forwards + 2x2 backward in backward_D, 1 forward + 1 dgrad
             # in backward_G = 8 forward-equivalents (the accounting SURVEY 8d uses for the 5G+5D figure: 40 x 21.8 for 5 D)
+            last_batch[precision] = batch
             return (lambda: (model.set_input(batch), model.optimize_parameters())), model, 3 * (2 * 396.4 + 2 * 49.2) + 8 * (2 * 21.8 + 2 * 22.6), dom, \
                 ('DeepLIIFExt train step, modalities_no=2: 2x Resnet-9block + 2x UNet-512 (9-ch in) generators, 2x NLayerD (6 ch) + 2x NLayerD '
                  '(12 ch), GAN/LSGAN+SmoothL1+Adam (BASELINE configs[3])')
@@ -292,6 +297,7 @@ def main():
             model = M.create_model(opt)
             model.setup(opt)
             batch = {'A': synth(1234), 'B': [synth(1235 + i) for i in range(5)], 'A_paths': ['synthetic']}      # 4 modalities + seg target
+            last_batch[precision] = batch
             return (lambda: (model.set_input(batch), model.optimize_parameters())), model, GF_PER_TILE_TRAIN_18NETS, dom, \
                 ('real DeepLIIF train step (modalities_no=4, seg_gen=True): 4x Resnet-9block + 5x UNet-512 generators, 4 + 5 NLayerD(n=4), '
                  'GAN/LSGAN+SmoothL1+Adam (SURVEY 8d)')
@@ -413,6 +419,32 @@ def main():
 
     kt = timer.mean_seconds()
     kt_median = timer.median_seconds() if hasattr(timer, 'median_seconds') else kt
+
+    # ---- hipGraph leg: the same steps replayed from ONE captured graph (models.StepGraph): what the step costs when Python is out of it.  The headline
+    # `value` above is the EAGER step (it carries the per-launch events the roofline block needs); this leg runs after it on the same model.
+    graph_report = None
+    if not args.no_graph and not dry and model is not None and world == 1 and args.workload in ('train', 'train18', 'ext') and args.precision in last_batch:
+        sg = M.StepGraph(model, warmup=1)
+        if sg.why_eager is None:
+            gb = last_batch[args.precision]
+            for _ in range(3):                   # one eager step in graph mode, the capture (+ its replay), one replay
+                sg.step(gb)
+            barrier()
+            host = 0.0
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                h0 = time.perf_counter()
+                sg.step(gb)
+                host += time.perf_counter() - h0
+            barrier()
+            gdt = time.perf_counter() - t0
+            graph_report = {'value': round(args.steps * n / gdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(gdt / args.steps * 1e3, 3), 'steps': args.steps,
+                            'host_ms_per_step': round(host / args.steps * 1e3, 3),
+                            'what': 'optimize_parameters() captured once in a hipGraph and replayed (models.StepGraph; bit-identical to the eager step, '
+                                    'tests/test_gpu_graph.py); host_ms_per_step = Python time to issue one step (batch copy into the static tensors, Adam scalars, '
+                                    'one graph launch) -- the eager step issues ~2 400 launches from Python'}
+        else:
+            graph_report = {'skipped': sg.why_eager}
     n_pairs, dom_kernel = len(timer.pairs), timer.kernel
     flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * (4 * args.ngf) * (4 * args.ngf) * 9
 
@@ -491,6 +523,9 @@ def main():
     }
     if exchange_report is not None:
         out['exchange'] = exchange_report
+    if graph_report is not None:
+        out['graph_replay'] = graph_report
+    out['config']['launch_mode'] = 'eager (one HIP launch per kernel from Python; see graph_replay for the captured-graph step)'
     if args.precision == 'bf16' and strict is not None:
         out['dtype_note'] = ('headline dtype bf16 is the throughput policy (BASELINE.json quotes the target on bf16 MFMA); it does NOT meet the 1e-3 parity bar -- '
                              'its measured distance from the strict policy is in strict_parity.headline_vs_strict; the strict policy (asserted at 1e-3 against '

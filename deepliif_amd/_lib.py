@@ -105,6 +105,8 @@ SIGNATURES = {
     'dl_maxpool2_forward': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_maxpool2_backward': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'dl_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    'dl_adam_hyper': (_i, [_f, _f, _f, _f, _i, _f, _vp]),
+    'dl_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'dl_tile_gather_u8': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _i, _vp, _i, _i, _vp]),
     'dl_tile_gray_stats_u8': (_i, [_vp, _i64, _i, _i, _vp, _i, _i, _i, C.c_uint32, _vp, _vp]),
     'dl_tile_paste_u8': (_i, [_i, _vp, _i, _i, _vp, _i, _vp, _i64, _vp]),
@@ -135,8 +137,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 109:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 109 (stale build)')
+    if lib.dl_version() != 110:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 110 (stale build)')
     _lib = lib
     return lib
 

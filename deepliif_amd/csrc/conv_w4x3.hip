@@ -10,7 +10,10 @@
 //     dependent MFMAs 16 issues apart); two sub-steps per K step, fragments double-buffered in registers (128 VGPRs + 256 accumulators);
 //   * epilogue: fp32 results leave through LDS in two 128-channel halves (128 KB each, 16-byte chunks XOR-swizzled by the pixel) as whole 512-byte
 //     pixel rows; bias / ReLU; fused per-(image, channel) statistics of the stored values.
-// 8-phase strict kernel (conv_x3.h) on the same shape: 318 us in the step = 58 % of the MFMA pipe (r03).  Inputs that are NOT split copies stay there.
+// MEASURED (r04, same box, profiles/r04/w4x3_ab.txt): a TIE with the 8-phase strict kernel (conv_x3.h) -- 345.6-347.1 vs 343.7-344.2 us per launch inside the strict
+// step, 204.8 vs 203.8 ms per step -- so this kernel is OPT-IN (DL_CONV_W4X3=1, see w4x3_enabled() in conv_x3.h for the reading).  Timing-only ablations: MFMAs
+// only 267 us (K loop 235 us for 186 us of matrix-pipe time at 2.4 GHz), no DMA 295 us, prologue + epilogue 32 us, full 390 us.  Inputs that are NOT split
+// copies always stay on the 8-phase kernel.
 #include "conv_args.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;

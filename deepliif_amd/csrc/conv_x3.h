@@ -811,10 +811,14 @@ static const char *x3_kernel_name(const dl_conv_desc *d) {
     return "conv_gemm_glds_x3_kernel<128,128>";
 }
 
-// conv_gemm_w4x3_kernel (conv_w4x3.hip) serves the ResnetBlock shape with split-copy inputs; DL_CONV_W4X3=0 keeps it on the 8-phase strict kernel (A/B)
+// conv_gemm_w4x3_kernel (conv_w4x3.hip), the one-wave-per-SIMD tile for the strict policy: OPT-IN (DL_CONV_W4X3=1).  Same-box A/B (r04,
+// profiles/r04/w4x3_ab.txt): isolated forward 390-395 us vs 398-402 us for the 8-phase strict kernel, data gradient 346-350 vs 348-354, inside the strict
+// step 345.6-347.1 vs 343.7-344.2 us per launch and 204.8 vs 203.8 ms per step -- a tie.  Unlike the bf16 pair (conv_w4.hip: -13 %), the strict 8-phase
+// kernel already issues three MFMAs per fragment pair, so halving the LDS bytes per MFMA buys nothing: both run at 1.3-1.35 PF/s executed, 80-90 % of
+// what a bare MFMA loop sustains on random operands on these boxes (1.5-1.7 PF/s, bench.py roofline.sustained) -- the strict conv is power-bound.
 static bool w4x3_enabled() {
     static const char *e = getenv("DL_CONV_W4X3");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }
 
 static int dispatch_tile_x3(const ConvArgs &a, hipStream_t stream) {

@@ -575,6 +575,39 @@ extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, flo
     return 0;
 }
 
+// The same update with its per-step scalars read from DEVICE memory: a captured hipGraph of the training step replays fixed kernel arguments, while
+// the learning rate (schedulers) and Adam's bias corrections change every step.  hyper = {lr, beta1, beta2, eps, 1 - beta1^t, sqrt(1 - beta2^t),
+// grad_scale}, computed by dl_adam_hyper with the expressions of dl_adam_step and copied to the device outside the graph: identical arithmetic,
+// bit-identical parameters.
+__global__ void __launch_bounds__(256) adam_dev_kernel(float *p, const float *g, float *m, float *v, size_t n, const float *hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5], gscale = hyper[6];
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+extern "C" int dl_adam_hyper(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float *hyper_host) {
+    if (!hyper_host || step < 1) DL_FAIL("dl_adam_hyper: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hyper_host[0] = lr; hyper_host[1] = beta1; hyper_host[2] = beta2; hyper_host[3] = eps;
+    hyper_host[4] = bc1; hyper_host[5] = sqrtf(bc2); hyper_host[6] = grad_scale; hyper_host[7] = 0.f;
+    return 0;
+}
+extern "C" int dl_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *hyper_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper_dev || n <= 0) DL_FAIL("dl_adam_step_dev: bad argument");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(EW_BLOCKS(n)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, (size_t)n, hyper_dev);
+    DL_CHECK_LAUNCH("dl_adam_step_dev");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------- dropout
 // nn.Dropout(0.5) of ResnetBlock / UnetSkipConnectionBlock (networks.py:493-494, 604-605): y = x * keep / (1 - p).  The keep mask
 // is a counter-based hash of (seed, element index), so the backward pass regenerates it from the same seed instead of storing it.

@@ -64,6 +64,83 @@ def pick_gpu(gpu_ids, is_train: bool, env=None) -> int:
                               'then takes gpu_ids[LOCAL_RANK] and the gradients are averaged over RCCL, deepliif_amd.distributed)')
 
 
+class StepGraph:
+    """optimize_parameters() captured ONCE in a hipGraph and replayed per step: a training step is ~2 400 kernel launches issued
+    by ~55 ms of Python for ~100 ms of GPU time; a replay is one launch.  The shapes are static, the losses stay on the device, the tape is
+    deterministic, so the captured launch sequence IS the step; what changes per step is data:
+      * the batch: copied into persistent device tensors (`static batch`) before every step; set_input(static batch) -- the NCHW -> engine layout
+        conversions -- is part of the captured region;
+      * Adam's scalars (scheduler learning rate, bias corrections): optim.FusedAdam graph mode, refreshed by prepare_step() outside the graph.
+    step(batch): the first `warmup` calls run eagerly (first-use initialisation: function attributes, pack tables, workspaces), the next one
+    captures, every later one replays.  Results are bit-identical to the eager step (tests/test_gpu_graph.py: reference trajectories).
+    Falls back to eager for good, saying why, when the step cannot be captured: data-parallel exchange active (collectives are launched from tape
+    callbacks on RCCL's own streams), dropout in training mode (the mask seed is a kernel argument), an optimizer other than FusedAdam, a model
+    class with host-side randomness (CycleGAN's ImagePool)."""
+
+    def __init__(self, model, warmup: int = 2):
+        self.model, self.warmup = model, max(1, warmup)
+        self.calls, self.graph, self.static, self.why_eager = 0, None, None, None
+        from . import distributed as D
+        from .optim import FusedAdam
+        if D.active():
+            self.why_eager = 'data-parallel gradient exchange is active'
+        elif not getattr(model, 'graphable', False):
+            self.why_eager = f'{type(model).__name__} has host-side state per step'
+        elif not all(isinstance(o, FusedAdam) for o in model.optimizers):
+            self.why_eager = 'an optimizer other than FusedAdam'
+        elif any(isinstance(m, torch.nn.Dropout) and m.training for _, net in model._nets() for m in net.modules()):
+            self.why_eager = 'dropout is active (its seed is a kernel argument)'
+        if self.why_eager:
+            print(f'deepliif_amd: StepGraph runs eagerly: {self.why_eager}')
+        else:
+            for o in model.optimizers:
+                o.enable_graph_mode()
+
+    def _to_static(self, batch):
+        dev = self.model.device
+
+        def conv(v, ref):
+            if torch.is_tensor(v):
+                if ref is None:
+                    return v.to(dev).clone()
+                ref.copy_(v, non_blocking=True)
+                return ref
+            if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(x) for x in v):
+                return [conv(x, None if ref is None else ref[i]) for i, x in enumerate(v)]
+            return v
+        if self.static is None:
+            self.static = {k: conv(v, None) for k, v in batch.items()}
+        else:
+            for k, v in batch.items():
+                self.static[k] = conv(v, self.static.get(k))
+        return self.static
+
+    def step(self, batch):
+        m = self.model
+        if self.why_eager:
+            m.set_input(batch)
+            m.optimize_parameters()
+            return
+        m._sync_replicas()
+        static = self._to_static(batch)
+        for o in m.optimizers:
+            o.prepare_step()
+        self.calls += 1
+        if self.graph is not None:
+            self.graph.replay()
+        elif self.calls <= self.warmup:
+            m.set_input(static)
+            m.optimize_parameters()
+        else:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                m.set_input(static)
+                m.optimize_parameters()
+            self.graph = g
+            g.replay()                  # capture records, it does not execute: this step's work
+
+
 class BaseModel:
     """deepliif/models/base_model.py surface."""
 
@@ -254,6 +331,7 @@ class BaseModel:
 
 
 class DeepLIIFModel(BaseModel):
+    graphable = True          # may StepGraph capture optimize_parameters()? (no host-side randomness / per-step host state)
     def __init__(self, opt):
         super().__init__(opt)
         if not hasattr(opt, 'net_gs'):
@@ -523,6 +601,7 @@ class DeepLIIFExtModel(BaseModel):
     DS_i(cat(real_A, real_B[0], real_B[i], seg_i)) (12 channels, :97,186).  Networks and losses are list-valued
     (netG[i], loss_G_GAN[i], ...), model names 'G_1', 'GS_1', ...  Quirks kept: the generator-side seg GAN loss uses
     criterionGAN_mod (:236), seg loss weights are 1/M (:27,30), no VGG term."""
+    graphable = True          # may StepGraph capture optimize_parameters()? (no host-side randomness / per-step host state)
 
     _extra_g_loss_names = ()         # subclasses add per-modality generator loss names the reference reports (SDG: G_VGG)
 
@@ -757,6 +836,7 @@ class DeepLIIFKDModel(DeepLIIFModel):
     training batch (run_dask(img=real_A, use_dask=False, output_tensor=True), :203) with its default equal seg weights; BatchNorm there
     normalises with the statistics of the WHOLE batch (the reference's disable_batchnorm_tracking_stats + a batched call), not per sample.
     Quirks kept: loss_names lists G_KLDiv_S{M} twice and never G_KLDiv_S0 (:36-41) although the latter enters loss_G (:342-343)."""
+    graphable = False          # may StepGraph capture optimize_parameters()? (no host-side randomness / per-step host state)
 
     FACTOR_KLDIV = 10.0
 
@@ -872,6 +952,7 @@ class CycleGANModel(BaseModel):
     + 10/M sum_i [L1(rec_A_i, A) + L1(rec_B_i, B_i)], identity terms off (:207-208, 213) -- then the discriminators on the pooled, detached fakes,
     one backward per discriminator of (real + fake) * 0.5 * w_i (:172-205).  Every generator runs TWICE on the generator tape.
     The VGG term carries no lambda here (:232, 238): it needs the weight file like everywhere else (BaseModel._make_vgg rules)."""
+    graphable = False          # may StepGraph capture optimize_parameters()? (no host-side randomness / per-step host state)
 
     LAMBDA_A = LAMBDA_B = 10.0
 

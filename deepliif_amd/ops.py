@@ -515,6 +515,16 @@ class HipBackend:
                                       float(gscale), _stream()), 'dl_adam_step')
 
 
+    def adam_hyper(self, lr, b1, b2, eps, step, gscale, hyper_host: torch.Tensor):
+        """fill the (pinned) host tensor with the scalars dl_adam_step would use at this step (graph mode, optim.FusedAdam.prepare_step)"""
+        assert hyper_host.device.type == 'cpu' and hyper_host.dtype == torch.float32 and hyper_host.numel() >= 8
+        L.check(self.lib.dl_adam_hyper(float(lr), float(b1), float(b2), float(eps), int(step), float(gscale), C.c_void_p(hyper_host.data_ptr())), 'dl_adam_hyper')
+
+    def adam_step_dev(self, p, g, m, v, hyper_dev):
+        _need_cuda(p, g, m, v, hyper_dev)
+        L.check(self.lib.dl_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), 'dl_adam_step_dev')
+
+
 _impl = None
 
 

@@ -78,6 +78,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
         self.dp_scale = 1.0          # set to 1/world_size by the data-parallel driver (sum all-reduce)
         self._pack_batch = None        # engine.PackBatch over this set's conv weights, built at the first step
+        # graph mode (models.StepGraph): the per-step scalars live in device memory -- step() launches dl_adam_step_dev, which a captured hipGraph can
+        # replay, and prepare_step() (outside the graph) advances the step counter and refreshes them
+        self.hyper_dev = None
+        self._hyper_host = None
+        self._prepared = False
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
@@ -125,15 +130,36 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): one fused step counter cannot resume that')
         self.step_count = steps.pop() if steps else 0
 
+    def enable_graph_mode(self):
+        """per-step scalars from device memory (see __init__); idempotent"""
+        if self.hyper_dev is None:
+            self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=self.flat.data.device)
+            self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if self.flat.data.is_cuda else torch.zeros(8, dtype=torch.float32)
+
+    def prepare_step(self):
+        """graph mode, OUTSIDE the captured region, once per step and BEFORE it runs: advance Adam's step counter and put this step's scalars
+        (learning rate of the scheduler, bias corrections, 1 / world size) where the captured dl_adam_step_dev reads them"""
+        assert self.hyper_dev is not None, 'enable_graph_mode() first'
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.impl().adam_hyper(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count, self.dp_scale, self._hyper_host)
+        self.hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        self._prepared = True
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
         if not self.flat.attached():
             raise RuntimeError('parameters were moved after the optimizer was built; rebuild the optimizer (FlatParams lost its views)')
         g = self.param_groups[0]
-        self.step_count += 1
-        ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                             self.step_count, self.dp_scale)
+        if self.hyper_dev is not None:
+            assert self._prepared, 'graph mode: prepare_step() must run before every step (models.StepGraph does)'
+            self._prepared = False
+            ops.impl().adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.hyper_dev)
+        else:
+            self.step_count += 1
+            ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                                 self.step_count, self.dp_scale)
         self.flat.bump_epoch()         # packed bf16 weight images are stale now (engine.ConvLayer.ensure_packed)
         # ... so rebuild the ones that exist in ONE launch instead of one launch per image at their next use (DL_PACK_BATCH=0
         # restores the lazy per-image path).  Measured in round 1 (rocprof, 3 steps x 2 optimizers): 6 batched launches x 302 us

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 109
+#define DL_VERSION 110
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -320,6 +320,11 @@ int dl_maxpool2_backward(int dtype, const void *x, int x_pstride, const void *dy
  * ---------------------------------------------------------------------------------------------------------- */
 int dl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+/* The same step with its per-step scalars in device memory, for a captured hipGraph of optimize_parameters() (kernel arguments are frozen at capture;
+ * learning rate and bias corrections are not): dl_adam_hyper fills hyper_host[8] = {lr, beta1, beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step),
+ * grad_scale, 0} with the expressions dl_adam_step uses; the caller copies it to hyper_dev before every replay.  Bit-identical to dl_adam_step. */
+int dl_adam_hyper(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float *hyper_host);
+int dl_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *hyper_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Tiles: the crop / is_empty / stitch steps either side of the generator DAG, on uint8 RGB images resident in HBM

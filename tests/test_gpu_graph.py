@@ -1,0 +1,86 @@
+"""optimize_parameters() replayed from a captured hipGraph (models.StepGraph) against the eager step: same seeded weights, a DIFFERENT
+batch every step, a learning-rate change in between -- every loss of every step and the final parameters must be bit-identical, for the bf16 and the
+strict policy, DeepLIIF (5 G + 5 D and the 18-net form at fixture width) and DeepLIIFExt."""
+import argparse
+import types
+
+import pytest
+import torch
+
+import bench
+from deepliif_amd import models as M
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _batches(kind, n, size, count, m):
+    g = torch.Generator().manual_seed(77)
+    out = []
+    for _ in range(count):
+        b = {'A': torch.rand(n, 3, size, size, generator=g) * 2 - 1, 'B': [torch.rand(n, 3, size, size, generator=g) * 2 - 1 for _ in range(m)], 'A_paths': ['x']}
+        if kind == 'ext':
+            b['BS'] = [torch.rand(n, 3, size, size, generator=g) * 2 - 1 for _ in range(2)]
+        out.append(b)
+    return out
+
+
+def _build(kind, precision):
+    args = argparse.Namespace(ngf=8, norm='instance', precision=precision, batch=2, size=64)
+    torch.manual_seed(0)
+    if kind == 'train':
+        opt = bench.make_opt(args, 0)
+    elif kind == 'train18':
+        opt = bench.make_opt(args, 0, M=4, seg_gen=True)
+        opt.net_gs, opt.norm = 'unet_64', 'batch'
+    else:
+        opt = bench.make_opt(args, 0, M=2, seg_gen=True)
+        opt.model, opt.net_ds, opt.net_gs = 'DeepLIIFExt', 'n_layers', 'unet_64'
+        opt.loss_G_weights = opt.loss_D_weights = opt.seg_weights = [0.5, 0.5]
+    model = M.create_model(opt)
+    model.setup(opt)
+    return model
+
+
+def _flat(model):
+    return torch.cat([o.flat.data.clone() for o in model.optimizers])
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('kind', ['train', 'train18', 'ext'])
+def test_replayed_step_is_bit_identical_to_the_eager_step(kind, precision):
+    m = {'train': 5, 'train18': 5, 'ext': 2}[kind]
+    batches = _batches(kind, 2, 64, 5, m)
+    eager, graphed = _build(kind, precision), _build(kind, precision)
+    assert torch.equal(_flat(eager), _flat(graphed))
+    sg = M.StepGraph(graphed, warmup=1)
+    assert sg.why_eager is None
+    for i, b in enumerate(batches):
+        if i == 3:                                   # a scheduler step between two replays: the learning rate reaches the graph through device memory
+            for mdl in (eager, graphed):
+                for o in mdl.optimizers:
+                    o.param_groups[0]['lr'] *= 0.5
+        eager.set_input({k: ([t.to(DEV) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else (v.to(DEV) if torch.is_tensor(v) else v)) for k, v in b.items()})
+        eager.optimize_parameters()
+        sg.step(b)
+        torch.cuda.synchronize()
+        le, lg = eager.get_current_losses(), graphed.get_current_losses()
+        assert le.keys() == lg.keys() and all(le[k] == lg[k] for k in le), (i, {k: (le[k], lg[k]) for k in le if le[k] != lg[k]})
+    assert sg.graph is not None and sg.calls == 5
+    assert torch.equal(_flat(eager), _flat(graphed)), 'parameters differ after 1 eager + 1 captured + 3 replayed steps'
+    assert all(o.step_count == 5 for o in graphed.optimizers)
+
+
+def test_step_graph_declines_what_it_cannot_capture():
+    args = argparse.Namespace(ngf=8, norm='instance', precision='bf16', batch=2, size=64)
+    torch.manual_seed(0)
+    opt = bench.make_opt(args, 0)
+    opt.no_dropout = False                           # Dropout(0.5) in the ResnetBlocks, training mode
+    model = M.create_model(opt)
+    model.setup(opt)
+    sg = M.StepGraph(model)
+    assert sg.why_eager and 'dropout' in sg.why_eager
+    b = _batches('train', 2, 64, 1, 5)[0]
+    sg.step(b)                                       # still trains, eagerly
+    torch.cuda.synchronize()
+    assert all(v == v for v in model.get_current_losses().values())

@@ -970,11 +970,11 @@ def test_split_copy_inputs_are_bit_identical_to_the_in_kernel_split(case):
         assert torch.equal(g0, g1), ('wgrad', ps, qs)
 
 
-@pytest.mark.parametrize('case', [(256, 256, 8, 128), (64, 256, 4, 64), (256, 512, 2, 128)], ids=lambda c: f'ci{c[0]}-co{c[1]}-n{c[2]}-h{c[3]}')
+@pytest.mark.parametrize('case', [(256, 256, 8, 128), (64, 256, 8, 128), (256, 512, 4, 128)], ids=lambda c: f'ci{c[0]}-co{c[1]}-n{c[2]}-h{c[3]}')
 def test_strict_w4_kernel_on_split_copies(case):
-    """conv_gemm_w4x3_kernel (csrc/conv_w4x3.hip): the ResnetBlock conv under the strict policy with a split-copy input -- forward (fused statistics,
-    bias) and data gradient (reversed kw order) against the fp32 reference of the emulation backend at fp32-class tolerance, run-to-run identical,
-    image borders (zero rows through the num_records = 0 resource, zeroed edge lanes) included by construction of the shape."""
+    """The ResnetBlock conv under the strict policy with a SPLIT-COPY input -- forward (fused statistics, bias) and data gradient (reversed kw order)
+    against the fp32 reference of the emulation backend at fp32-class tolerance, run-to-run identical, image borders included by construction of the
+    shape.  Default dispatch: conv_gemm_8ph_x3_kernel; with DL_CONV_W4X3=1 (tests/test_gpu_switches.py) conv_gemm_w4x3_kernel (csrc/conv_w4x3.hip)."""
     cin, cout, N, H = case
     W_ = 128
     prec = Precision.get('fp32')
@@ -998,7 +998,7 @@ def test_strict_w4_kernel_on_split_copies(case):
                                     want_stats=(plan_kind == 'fwd'))
             sync()
             outs.append(o)
-        if os.environ.get('DL_CONV_W4X3') != '0':
+        if os.environ.get('DL_CONV_W4X3') == '1' and plan_kind == 'fwd':          # opt-in kernel (tests/test_gpu_switches.py runs this test under the switch)
             assert real.last_conv_kernel == 'conv_gemm_w4x3_kernel', real.last_conv_kernel
         assert torch.equal(outs[0], outs[1]), 'run-to-run difference'
         assert rel(outs[0], exp) < 2e-5, (plan_kind, rel(outs[0], exp))

@@ -1,4 +1,6 @@
-"""The fused four-phase tile (csrc/conv_s2f.hip) below its size rule: dl_conv_forward only sends layers with >= 256 phase-grid tiles to it, so the small
+"""Kernels behind environment switches, tested in child processes (the library reads its switches once per process).
+
+The fused four-phase tile (csrc/conv_s2f.hip) below its size rule: dl_conv_forward only sends layers with >= 256 phase-grid tiles to it, so the small
 kernel-test shapes (and the fused-statistics case, 2 x 16 x 16) never reach it in the main test process.  The library reads DL_CONV_S2F once per process:
 the same kernel tests run again in a child process with DL_CONV_S2F=2 (size rule lifted) -- forward + data gradient against the emulated reference, fused
 statistics against the stand-alone pass, run-to-run equality."""
@@ -37,3 +39,13 @@ def test_the_dispatch_names_the_fused_tile_for_the_generator_layers():
     torch.cuda.synchronize()
     expect = 'conv_gemm_glds_kernel<128,64,64>' if os.environ.get('DL_CONV_S2F') == '0' else 'conv_s2f_kernel'
     assert be.last_conv_kernel == expect
+
+
+def test_strict_w4_kernel_under_its_switch():
+    """conv_gemm_w4x3_kernel (csrc/conv_w4x3.hip) is opt-in (a measured tie with the 8-phase strict kernel): its parity test under DL_CONV_W4X3=1"""
+    env = dict(os.environ, DL_CONV_W4X3='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_kernels.py'), '-m', 'gpu', '-q', '-x', '-k',
+                        'strict_w4_kernel or split_copy_inputs'], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]
+
