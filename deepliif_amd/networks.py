@@ -747,6 +747,9 @@ class GANLoss(nn.Module):
         self.register_buffer('fake_label', torch.tensor(target_fake_label))
         self.gan_mode = gan_mode
         self.label_smoothing = label_smoothing
+        # the labels as host floats: target() runs for every loss term of every step, and float(<device buffer>) is a device-to-host copy that waits
+        # for the whole queue (and is not allowed while a hipGraph is being captured, models.StepGraph)
+        self._labels = (float(target_real_label), float(target_fake_label))
         if gan_mode == 'lsgan':
             self.kind = L.LOSS_MSE
         elif gan_mode == 'vanilla':
@@ -760,8 +763,8 @@ class GANLoss(nn.Module):
         if self.gan_mode == 'wgangp':
             return -1.0 if target_is_real else 1.0       # the sign dl_loss multiplies the prediction with (DL_LOSS_LINEAR)
         if target_is_real:
-            return float(self.real_label) * (1 - self.label_smoothing)
-        return float(self.fake_label) * self.label_smoothing
+            return self._labels[0] * (1 - self.label_smoothing)
+        return self._labels[1] * self.label_smoothing
 
     def __call__(self, prediction, target_is_real):
         prec = E.Precision.get('fp32_bf16mma')
