@@ -456,13 +456,13 @@ def main():
     graph_report = None
     if not args.no_graph and not dry and model is not None and world == 1 and args.workload in ('train', 'train18', 'ext') and args.precision in last_batch:
         try:
-            sg = M.StepGraph(model, warmup=1)
+            sg = M.StepGraph(model, warmup=2)
         except Exception as exc:
             sg = types.SimpleNamespace(why_eager=f'StepGraph: {exc}'[:200])
         if sg.why_eager is None:
             gb = last_batch[args.precision]
             try:
-                for _ in range(3):                   # one eager step in graph mode, the capture (+ its replay), one replay
+                for _ in range(4):                   # two eager steps in graph mode, the capture (+ its replay), one replay
                     sg.step(gb)
                 barrier()
                 host = 0.0

@@ -78,7 +78,7 @@ class StepGraph:
     class with host-side randomness (CycleGAN's ImagePool)."""
 
     def __init__(self, model, warmup: int = 2):
-        self.model, self.warmup = model, max(1, warmup)
+        self.model, self.warmup = model, max(2, warmup)      # two eager steps: the second one still creates state (the repack table sees the data-gradient images)
         self.calls, self.graph, self.static, self.why_eager = 0, None, None, None
         from . import distributed as D
         from .optim import FusedAdam
@@ -134,9 +134,22 @@ class StepGraph:
         else:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                with torch.cuda.graph(g):
+                    m.set_input(static)
+                    m.optimize_parameters()
+            except Exception as exc:
+                # something on the step path still needs the host during the step (e.g. a table that is only complete after another eager step:
+                # the batched weight-repack table grows while data-gradient images appear).  Nothing was executed; run this step -- and all later
+                # ones -- eagerly.  The packed-weight stamps may have been advanced by the aborted pass: force a re-pack.
+                self.why_eager = f'capture failed: {str(exc).splitlines()[0][:160]}'
+                print(f'deepliif_amd: StepGraph runs eagerly: {self.why_eager}')
+                for o in m.optimizers:
+                    o._prepared = True
+                    o.flat.bump_epoch()
                 m.set_input(static)
                 m.optimize_parameters()
+                return
             self.graph = g
             g.replay()                  # capture records, it does not execute: this step's work
 
