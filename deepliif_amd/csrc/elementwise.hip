@@ -550,18 +550,23 @@ extern "C" int dl_maxpool2_backward(int dtype, const void *x, int x_ps, const vo
 }
 
 // ------------------------------------------------------------------------------------------- Adam
+// one element of the update.  Shared by the two kernels below with floating-point contraction OFF: they must round identically (a captured step replays
+// adam_dev_kernel, the eager step runs adam_kernel; with contraction left to the compiler the two differed by one ulp in most parameters -- r04)
+__device__ __forceinline__ void adam_update(float &p, float g, float &m, float &v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+#pragma clang fp contract(off)
+    const float step_size = lr / bc1;
+    const float gi = g * gscale;
+    const float mi = b1 * m + (1.f - b1) * gi;
+    const float vi = b2 * v + (1.f - b2) * gi * gi;
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p = p - step_size * (mi / denom);
+}
 __global__ void __launch_bounds__(256) adam_kernel(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
                                                    float bc1, float bc2_sqrt, float gscale) {
-    const float step_size = lr / bc1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= step_size * (mi / denom);
-    }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
 }
 extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                             float beta2, float eps, int step, float grad_scale, void *stream_) {
@@ -581,16 +586,8 @@ extern "C" int dl_adam_step(float *param, const float *grad, float *exp_avg, flo
 // bit-identical parameters.
 __global__ void __launch_bounds__(256) adam_dev_kernel(float *p, const float *g, float *m, float *v, size_t n, const float *hyper) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5], gscale = hyper[6];
-    const float step_size = lr / bc1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= step_size * (mi / denom);
-    }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        adam_update(p[i], g[i], m[i], v[i], lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
 }
 extern "C" int dl_adam_hyper(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float *hyper_host) {
     if (!hyper_host || step < 1) DL_FAIL("dl_adam_hyper: bad argument");

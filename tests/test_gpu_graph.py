@@ -67,7 +67,13 @@ def test_replayed_step_is_bit_identical_to_the_eager_step(kind, precision):
         le, lg = eager.get_current_losses(), graphed.get_current_losses()
         assert le.keys() == lg.keys() and all(le[k] == lg[k] for k in le), (i, {k: (le[k], lg[k]) for k in le if le[k] != lg[k]})
     assert sg.graph is not None and sg.calls == 6, sg.why_eager
-    assert torch.equal(_flat(eager), _flat(graphed)), 'parameters differ after 2 eager + 1 captured + 3 replayed steps'
+    if not torch.equal(_flat(eager), _flat(graphed)):
+        bad = []
+        for name in eager.model_names:
+            for (k, a), (_, b) in zip(getattr(eager, 'net' + name).named_parameters(), getattr(graphed, 'net' + name).named_parameters()):
+                if not torch.equal(a, b):
+                    bad.append((name, k, float((a - b).abs().max()), float(a.abs().max())))
+        raise AssertionError(f'parameters differ after 2 eager + 1 captured + 3 replayed steps: {bad[:12]} ({len(bad)} tensors)')
     assert all(o.step_count == 6 for o in graphed.optimizers)
 
 
