@@ -142,10 +142,13 @@ class StepGraph:
                 # something on the step path still needs the host during the step (e.g. a table that is only complete after another eager step:
                 # the batched weight-repack table grows while data-gradient images appear).  Nothing was executed; run this step -- and all later
                 # ones -- eagerly.  The packed-weight stamps may have been advanced by the aborted pass: force a re-pack.
-                self.why_eager = f'capture failed: {str(exc).splitlines()[0][:160]}'
+                import traceback
+                where = [l.strip() for l in traceback.format_exc().splitlines() if 'deepliif_amd' in l and 'StepGraph' not in l][-1:]
+                self.why_eager = f'capture failed: {str(exc).splitlines()[0][:160]} {where}'
                 print(f'deepliif_amd: StepGraph runs eagerly: {self.why_eager}')
-                for o in m.optimizers:
-                    o._prepared = True
+                for o in m.optimizers:               # back to the scalar-argument Adam kernel (same arithmetic); prepare_step() had counted this step
+                    o.hyper_dev, o._prepared = None, False
+                    o.step_count -= 1
                     o.flat.bump_epoch()
                 m.set_input(static)
                 m.optimize_parameters()
@@ -767,12 +770,14 @@ class DeepLIIFExtModel(BaseModel):
                 vgg.run(ctx, self._fake[i], self._B[i], self.loss_G_weights[i] * self.lambda_feat, self._slot(f'G_VGG_{i + 1}'))
         tape.backward()
         self._tape_G = None
-        idx = [self._loss_index[n] for n in self.loss_names if '_L1_' in n]
-        self._loss_buf[torch.tensor(idx, dtype=torch.long, device=self.device)] *= self.lambda_L1
-        vidx = [self._loss_index[n] for n in self.loss_names if '_VGG_' in n]
-        if vidx:
+        # index tensors built ONCE: torch.tensor(..., device=cuda) is a host-to-device copy per step (and not capturable, models.StepGraph)
+        if not hasattr(self, '_idx_cache'):
+            self._idx_cache = {k: torch.tensor([self._loss_index[n] for n in self.loss_names if k in n], dtype=torch.long, device=self.device)
+                               for k in ('_L1_', '_VGG_')}
+        self._loss_buf[self._idx_cache['_L1_']] *= self.lambda_L1
+        if self._idx_cache['_VGG_'].numel():
             # reported like the reference does (value * lambda_feat); NaN, not a plausible-looking 0.0, when the term was not evaluated
-            sel = torch.tensor(vidx, dtype=torch.long, device=self.device)
+            sel = self._idx_cache['_VGG_']
             if vgg is not None:
                 self._loss_buf[sel] *= self.lambda_feat
             else:
