@@ -43,6 +43,12 @@ class WgradDesc(C.Structure):
                 ('q_act', i32), ('p_act', i32), ('pad_w', i32), ('stack_kw', i32), ('p_split', i32), ('q_split', i32)]
 
 
+class WgradReduceEntry(C.Structure):
+    _fields_ = [('slab', C.c_void_p), ('grad', C.c_void_p),
+                ('splitk', i32), ('CAp', i32), ('CBp', i32), ('J', i32), ('CA', i32), ('CB', i32), ('KK', i32), ('accumulate', i32), ('stack_kw', i32),
+                ('block0', i32), ('nblocks', i32), ('reserved', i32)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [('A', i32), ('B', i32), ('KH', i32), ('KW', i32), ('row_is_a', i32),
                 ('rows_real', i32), ('rows_pad', i32), ('Cc', i32), ('Cc_pad', i32), ('n_phase', i32),
@@ -73,6 +79,9 @@ SIGNATURES = {
     'dl_conv_forward_bnstats': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvBnStats), _vp]),
     'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
+    'dl_conv_wgrad_deferrable': (_i, [C.POINTER(WgradDesc)]),
+    'dl_conv_wgrad_slabs': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, C.POINTER(WgradReduceEntry), _vp]),
+    'dl_wgrad_reduce_batch': (_i, [_vp, _i, _i, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_pack_job_bytes': (C.c_size_t, []),
     'dl_pack_job_fill': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
@@ -137,8 +146,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 110:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 110 (stale build)')
+    if lib.dl_version() != 111:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 111 (stale build)')
     _lib = lib
     return lib
 

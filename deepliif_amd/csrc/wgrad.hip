@@ -672,12 +672,12 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
 // coalesce; the (small) gradient tensor takes the strided writes.  (A 4-lanes-per-column variant with every load in flight was tried in
 // r02: 22.9 vs 21.6 us on the 66 MB ResnetBlock slab -- the pass is bound by reading partials the previous kernel has just written,
 // not by loads in flight -- so the sequential summation order stayed.)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
-                                                           int KK, float *grad, int accumulate, int stack_kw) {
+__device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB, int KK, float *grad,
+                                                  int accumulate, int stack_kw, int bid, int nb) {
     const int J4 = J / 4;
     const size_t total = (size_t)CA * J4;
     const size_t kstride = (size_t)CAp * J;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x) {
         const int ca = (int)(i / J4), j = (int)(i % J4) * 4;
         const float *src = slab + (size_t)ca * J + j;
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
@@ -695,6 +695,25 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, in
             *g = accumulate ? *g + s[e] : s[e];
         }
     }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
+                                                           int KK, float *grad, int accumulate, int stack_kw) {
+    wgrad_reduce_body(slab, splitk, CAp, CBp, J, CA, CB, KK, grad, accumulate, stack_kw, blockIdx.x, gridDim.x);
+}
+
+// Deferred form (dl_conv_wgrad_slabs + dl_wgrad_reduce_batch): the slabs of MANY layers, each in its own region of a caller-owned arena, are
+// combined by ONE launch at the end of a network's backward pass -- every workgroup looks its layer up in a table sorted by first block.
+// Per element the summation is the loop above, so the result is bit-identical to the immediate reduction.
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dl_wgrad_reduce_entry *tab, int n) {
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const dl_wgrad_reduce_entry e = tab[lo];
+    wgrad_reduce_body(e.slab, e.splitk, e.CAp, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, e.stack_kw, b - e.block0, e.nblocks);
 }
 
 template <typename T, int PREC, int BA, int WA, int WJ>
@@ -726,12 +745,12 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 #include "wgrad_c4.h"
 #include "wgrad_x3.h"
 
-extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// the split-K kernel of the general path: slabs only (the reduction is the caller's: immediate or deferred)
+static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *slab, hipStream_t stream, int *J_out) {
     if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
     if (d->N <= 0 || d->Hp <= 0 || d->Wp <= 0 || d->Hq <= 0 || d->Wq <= 0)
         DL_FAIL("dl_conv_wgrad: empty problem (N=%d, P %dx%d, Q %dx%d): nothing to launch", d->N, d->Hp, d->Wp, d->Hq, d->Wq);
-    if (!P || !Q || !grad || !slab) DL_FAIL("dl_conv_wgrad: null argument");
+    if (!P || !Q || !slab) DL_FAIL("dl_conv_wgrad: null argument");
     const int l2 = ilog2_exact(d->CBp);
     if (l2 < 3) DL_FAIL("dl_conv_wgrad: CBp=%d must be a power of two >= 8", d->CBp);
     if (d->CAp % 8) DL_FAIL("dl_conv_wgrad: CAp=%d must be a multiple of 8", d->CAp);
@@ -739,9 +758,6 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     if (d->splitk < 1) DL_FAIL("dl_conv_wgrad: splitk=%d", d->splitk);
     if (d->stack_kw && d->KW != 1) DL_FAIL("dl_conv_wgrad: stack_kw needs KW == 1");
     if (d->prec == DL_PREC_BF16X3 && d->dtype != DL_F32) DL_FAIL("dl_conv_wgrad: BF16X3 needs fp32 activations");
-
-    if (const int form = wgrad_c4_form(d)) return launch_wgrad_c4(d, form, P, Q, grad, slab, stream);
-    if (const int form = wgrad_c4_x3_form(d)) return launch_wgrad_c4_x3(d, form, P, Q, grad, slab, stream);
 
     WgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -791,13 +807,56 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
     else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<float, 1>(a, stream);
     else DL_FAIL("dl_conv_wgrad: unsupported dtype/precision combination");
-    if (rc) return rc;
+    *J_out = a.J;
+    return rc;
+}
 
-    const int KK = d->KH * d->KW;
-    const size_t total = (size_t)d->CA * (a.J / 4);
-    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, a.J, d->CA, d->CB, KK,
-                       grad, d->accumulate, d->stack_kw);
+static int reduce_blocks(const dl_wgrad_desc *d, int J) {
+    const size_t total = (size_t)d->CA * (J / 4);
+    return (int)min((size_t)4096, (total + 255) / 256);
+}
+
+extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
+    if (!grad) DL_FAIL("dl_conv_wgrad: null argument");
+    if (d->N > 0 && d->Hp > 0 && d->Wp > 0 && P && Q && slab) {
+        if (const int form = wgrad_c4_form(d)) return launch_wgrad_c4(d, form, P, Q, grad, slab, stream);
+        if (const int form = wgrad_c4_x3_form(d)) return launch_wgrad_c4_x3(d, form, P, Q, grad, slab, stream);
+    }
+    int J = 0;
+    if (const int rc = wgrad_slabs(d, P, Q, slab, stream, &J)) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_blocks(d, J)), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, J, d->CA, d->CB,
+                       d->KH * d->KW, grad, d->accumulate, d->stack_kw);
     DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");
+    return 0;
+}
+
+extern "C" int dl_conv_wgrad_deferrable(const dl_wgrad_desc *d) {
+    return d && !wgrad_c4_form(d) && !wgrad_c4_x3_form(d);
+}
+
+extern "C" int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, dl_wgrad_reduce_entry *entry_host,
+                                   void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !entry_host || !grad) DL_FAIL("dl_conv_wgrad_slabs: null argument");
+    if (!dl_conv_wgrad_deferrable(d)) DL_FAIL("dl_conv_wgrad_slabs: the persistent narrow-channel kernels reduce in place; call dl_conv_wgrad");
+    int J = 0;
+    if (const int rc = wgrad_slabs(d, P, Q, slab, stream, &J)) return rc;
+    dl_wgrad_reduce_entry e;
+    memset(&e, 0, sizeof(e));
+    e.slab = slab; e.grad = grad;
+    e.splitk = d->splitk; e.CAp = d->CAp; e.CBp = d->CBp; e.J = J; e.CA = d->CA; e.CB = d->CB; e.KK = d->KH * d->KW;
+    e.accumulate = d->accumulate; e.stack_kw = d->stack_kw;
+    e.block0 = 0; e.nblocks = reduce_blocks(d, J);
+    *entry_host = e;
+    return 0;
+}
+
+extern "C" int dl_wgrad_reduce_batch(const dl_wgrad_reduce_entry *table_dev, int count, int total_blocks, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!table_dev || count <= 0 || total_blocks <= 0) DL_FAIL("dl_wgrad_reduce_batch: empty table");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, table_dev, count);
+    DL_CHECK_LAUNCH("dl_wgrad_reduce_batch");
     return 0;
 }

@@ -165,6 +165,11 @@ class GradExchanger:
             self.launch_log.append((s, e))
 
     def _launch(self, g, s, e):
+        if g.is_cuda:
+            from . import ops
+            flush = getattr(ops.impl(), 'wgrad_flush', None)
+            if flush is not None:
+                flush()                        # pending split-K slabs (ops.HipBackend: deferred reduction) become gradients before anything goes on the wire
         for b in range(s, e, MSG_ELEMS):
             self.handles.append(dist.all_reduce(g[b:min(b + MSG_ELEMS, e)], op=dist.ReduceOp.SUM, async_op=True))
             self._calls = getattr(self, '_calls', 0) + 1

@@ -115,8 +115,17 @@ class Tape:
 
     def backward(self):
         nodes, self.nodes = self.nodes, []
-        for fn in reversed(nodes):
-            fn()
+        # the weight gradients of the pass leave their split-K slabs side by side and are reduced in batches (ops.HipBackend.wgrad_flush)
+        be = ops.impl()
+        begin = getattr(be, 'wgrad_defer_begin', None)
+        if begin is not None:
+            begin()
+        try:
+            for fn in reversed(nodes):
+                fn()
+        finally:
+            if begin is not None:
+                be.wgrad_defer_end()
 
 
 def settle_gc():

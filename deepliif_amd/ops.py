@@ -49,6 +49,8 @@ _NO_X3_GLDS = os.environ.get('DL_NO_X3_GLDS') is not None           # A/B switch
 _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
 _SPLIT_ONLY_GRAD = os.environ.get('DL_NO_SPLIT_ONLY_GRAD', '0') != '1'     # A/B switch: 1 = the norm backward always stores the fp32 gradient next to its split copy
 _NO_C4_X3 = 'DL_NO_C4_X3' in os.environ              # A/B switch: the strict 7x7 stem / head on the general x3 kernels (csrc/conv_x3.h, wgrad_x3.h)
+_WGRAD_DEFER = os.environ.get('DL_WGRAD_DEFER', '1') != '0'            # A/B switch: 0 = every weight gradient reduces its slabs right behind the split-K kernel (rounds 1-3)
+_WGRAD_ARENA_MB = int(os.environ.get('DL_WGRAD_ARENA_MB', '2048'))      # slab arena of the deferred reduction (one Resnet-9 generator's backward pass writes ~1.9 GB of slabs at batch 8)
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
@@ -272,8 +274,75 @@ class HipBackend:
         d.accumulate = 1 if accumulate else 0
         d.p_act, d.q_act = p_act, q_act
         d.p_split, d.q_split = (1 if p_split else 0), (1 if q_split else 0)
-        slab = WS.get('wgrad_slab', d.splitk * d.CAp * j, P.device)
+        nslab = d.splitk * d.CAp * j
+        st = WS._state()
+        if _WGRAD_DEFER and st.get('defer_depth', 0) > 0 and self.lib.dl_conv_wgrad_deferrable(C.byref(d)):
+            self._wgrad_deferred(st, d, P, Q, grad, nslab)
+            return
+        slab = WS.get('wgrad_slab', nslab, P.device)
         L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
+
+    # ---- deferred slab reduction (include/deepliif_hip.h: dl_conv_wgrad_slabs / dl_wgrad_reduce_batch)
+    # Inside Tape.backward() every general-path weight gradient only writes its split-K slabs, each into its own region of a per-thread arena;
+    # ONE batched launch reduces them when (a) the pass ends, (b) a parameter comes up a second time (a discriminator that ran on real and
+    # fake pairs: the second accumulation must see the first), (c) the arena is full, or (d) the data-parallel exchange is about to put
+    # gradients on the wire (distributed.GradExchanger._launch).  Results are bit-identical to the immediate reduction.
+    def wgrad_defer_begin(self):
+        st = WS._state()
+        st['defer_depth'] = st.get('defer_depth', 0) + 1
+
+    def wgrad_defer_end(self):
+        st = WS._state()
+        try:
+            if st.get('defer_depth', 0) == 1:
+                self.wgrad_flush()
+        finally:
+            st['defer_depth'] = max(0, st.get('defer_depth', 0) - 1)
+
+    def _wgrad_deferred(self, st, d, P, Q, grad, nslab):
+        pend = st.setdefault('defer_pending', [])
+        gp = grad.data_ptr()
+        need = (nslab + 63) // 64 * 64
+        arena = st.get('defer_arena')
+        if gp in st.setdefault('defer_grads', set()) or (arena is not None and st.get('defer_off', 0) + need > arena.numel()):
+            self.wgrad_flush()
+        if arena is None or arena.numel() < need or arena.device != P.device:
+            self.wgrad_flush()
+            arena = torch.empty(max(need, _WGRAD_ARENA_MB * (1 << 18)), dtype=torch.float32, device=P.device)
+            st['defer_arena'], st['defer_off'] = arena, 0
+        off = st.get('defer_off', 0)
+        slab = arena[off:off + need]
+        e = L.WgradReduceEntry()
+        L.check(self.lib.dl_conv_wgrad_slabs(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), C.byref(e), _stream()), 'dl_conv_wgrad_slabs')
+        e.block0 = st.get('defer_blocks', 0)
+        st['defer_blocks'] = e.block0 + e.nblocks
+        st['defer_off'] = off + need
+        st['defer_grads'].add(gp)
+        pend.append(e)
+
+    def wgrad_flush(self):
+        """reduce every pending slab set of this thread (no-op when nothing is pending)"""
+        st = WS._state()
+        pend = st.get('defer_pending')
+        if not pend:
+            return
+        arena = st['defer_arena']
+        tab = (L.WgradReduceEntry * len(pend))(*pend)
+        key = bytes(tab)
+        cache = st.setdefault('defer_tables', {})
+        dev_tab = cache.get(key)
+        if dev_tab is None:
+            # static shapes: the same tables come back every step (the arena and the flat gradient buffer do not move), so after the first
+            # step nothing is copied -- which is also what lets models.StepGraph capture the pass
+            if len(cache) >= 512:
+                cache.clear()
+            dev_tab = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(arena.device)
+            cache[key] = dev_tab
+        total = st['defer_blocks']
+        st['defer_pending'], st['defer_blocks'], st['defer_off'] = [], 0, 0
+        st['defer_grads'] = set()
+        _LAUNCH.dev = arena.device
+        L.check(self.lib.dl_wgrad_reduce_batch(_ptr(dev_tab), len(pend), total, _stream()), 'dl_wgrad_reduce_batch')
 
     supports_split = os.environ.get('DL_NO_SPLIT_COPY') is None          # A/B switch: DL_NO_SPLIT_COPY=1 keeps every hi / lo split inside the conv kernels
 

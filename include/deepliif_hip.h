@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 110
+#define DL_VERSION 111
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -140,6 +140,26 @@ typedef struct dl_wgrad_desc {
 } dl_wgrad_desc;
 
 int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
+
+/* Deferred reduction of the split-K slabs (round 4).  A backward pass over one network launches ~30-60 weight gradients; reducing each one's
+ * slabs right behind it costs a ~20 us launch per layer that reads what the previous kernel has just written.  With 288 GB of HBM the slabs of a
+ * whole network fit side by side, so:
+ *   dl_conv_wgrad_slabs     runs ONLY the split-K kernel into `slab` (a region the caller keeps untouched until the batch has run) and fills
+ *                           *entry_host (HOST memory) with the record of the pending reduction (block0 = 0, nblocks = its share of the grid);
+ *   dl_wgrad_reduce_batch   combines `count` pending reductions in ONE launch; table_dev = the records in DEVICE memory, sorted by block0 with
+ *                           block0 = running sum of nblocks (the caller fills it in), total_blocks = the sum.
+ * Two records of one batch must not name the same `grad` (their accumulation would race): the caller flushes before a second use.
+ * Per element the summation order is dl_conv_wgrad's, so results are bit-identical to the immediate form.
+ * dl_conv_wgrad_deferrable: 0 for the persistent narrow-channel forms (7x7 stem / head), which reduce in place -- use dl_conv_wgrad. */
+typedef struct dl_wgrad_reduce_entry {
+    const float *slab;
+    float *grad;
+    int32_t splitk, CAp, CBp, J, CA, CB, KK, accumulate, stack_kw;
+    int32_t block0, nblocks, reserved;
+} dl_wgrad_reduce_entry;
+int dl_conv_wgrad_deferrable(const dl_wgrad_desc *d);
+int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, dl_wgrad_reduce_entry *entry_host, void *stream);
+int dl_wgrad_reduce_batch(const dl_wgrad_reduce_entry *table_dev, int count, int total_blocks, void *stream);
 
 /* Pack an fp32 parameter tensor src[A][B][KH][KW] into the K-contiguous bf16 image(s) dl_conv_forward streams.
  *   row_is_a != 0 : packed row = a, contracted channel = b   (Conv2d forward; ConvTranspose2d data-grad)

@@ -26,18 +26,18 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/deepliif_hip.h but not exported by libdeepliif_hip.so'
         assert n in L.SIGNATURES, f'{n} has no ctypes signature in deepliif_amd/_lib.py'
-    assert lib.dl_version() == 110
+    assert lib.dl_version() == 111
     assert isinstance(lib.dl_last_error(), bytes)
 
 
 def test_ctypes_struct_sizes_match_the_header(tmp_path):
     c = tmp_path / 'sz.c'
-    c.write_text('#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu\\n", sizeof(dl_conv_desc), sizeof(dl_wgrad_desc), '
-                 'sizeof(dl_pack_desc), sizeof(dl_norm_desc));return 0;}\n' % HEADER)
+    c.write_text('#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n", sizeof(dl_conv_desc), sizeof(dl_wgrad_desc), '
+                 'sizeof(dl_pack_desc), sizeof(dl_norm_desc), sizeof(dl_wgrad_reduce_entry));return 0;}\n' % HEADER)
     exe = tmp_path / 'sz'
     subprocess.run(['gcc', str(c), '-o', str(exe)], check=True)
     sizes = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc), ctypes.sizeof(L.PackDesc), ctypes.sizeof(L.NormDesc)]
+    assert sizes == [ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc), ctypes.sizeof(L.PackDesc), ctypes.sizeof(L.NormDesc), ctypes.sizeof(L.WgradReduceEntry)]
 
 
 def test_product_has_no_cpu_fallback():
