@@ -228,6 +228,12 @@ def main():
         os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
                                   f'--nproc-per-node={args.gpus}', os.path.abspath(__file__)] + sys.argv[1:])
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a version banner through C stdio, which is flushed at
+    # exit, i.e. AFTER a Python-level print (seen on the one-rank RCCL run: the last line of stdout was "Librccl path : ...") -- so for the
+    # whole run descriptor 1 points at stderr (every rank) and rank 0 writes the line to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from deepliif_amd import distributed as D
     from deepliif_amd import models as M
     from deepliif_amd import ops
@@ -555,8 +561,8 @@ def main():
                                     'the CPU oracle leg is implemented for the train workload only (oracle optimize_parameters); '
                                     'run the default workload for the CPU baseline')
     if rank == 0:
-        sys.stdout = sys.__stdout__
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
     if world > 1:
         torch.distributed.destroy_process_group()
 

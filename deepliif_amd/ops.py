@@ -300,7 +300,6 @@ class HipBackend:
             st['defer_depth'] = max(0, st.get('defer_depth', 0) - 1)
 
     def _wgrad_deferred(self, st, d, P, Q, grad, nslab):
-        pend = st.setdefault('defer_pending', [])
         gp = grad.data_ptr()
         need = (nslab + 63) // 64 * 64
         arena = st.get('defer_arena')
@@ -318,13 +317,14 @@ class HipBackend:
         st['defer_blocks'] = e.block0 + e.nblocks
         st['defer_off'] = off + need
         st['defer_grads'].add(gp)
-        pend.append(e)
+        st.setdefault('defer_pending', []).append(e)       # (looked up AFTER the flushes above: they start a new list)
 
     def wgrad_flush(self):
         """reduce every pending slab set of this thread (no-op when nothing is pending)"""
         st = WS._state()
         pend = st.get('defer_pending')
         if not pend:
+            st['defer_off'] = 0                  # whatever wrote into the arena has been reduced by a launch earlier in stream order
             return
         arena = st['defer_arena']
         tab = (L.WgradReduceEntry * len(pend))(*pend)

@@ -3,8 +3,8 @@
 # training step over DL_WGRAD_DEFER / DL_WGRAD_ARENA_MB (bf16 + strict), and one DL_DP_FORCE=1 line (one-rank RCCL: the `exchange` block, flush before the wire)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_deferred.py tests/test_gpu_distributed.py -m gpu -q -x 2>&1 | tail -12 > gpurun_out/defer_tests.log
-cat gpurun_out/defer_tests.log
+timeout 900 python -m pytest tests/test_gpu_deferred.py tests/test_gpu_distributed.py -m gpu -q -x > gpurun_out/defer_tests.log 2>&1
+grep -E 'passed|failed|Error|error' gpurun_out/defer_tests.log | tail -12
 timeout 900 python -m pytest tests/test_gpu_graph.py -m gpu -q -x 2>&1 | tail -6 | tee -a gpurun_out/defer_tests.log
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cpu-baseline-n8 --no-graph --no-timer-check"
 run() {   # tag, env...
