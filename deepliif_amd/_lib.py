@@ -102,6 +102,7 @@ SIGNATURES = {
     'dl_nhwc_to_nchw': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'dl_conv_narrow_supported': (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     'dl_conv_narrow_forward': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    'dl_conv_narrow_forward_x3': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'dl_shift_sum': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'dl_shift_stack': (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'dl_reflect_fold': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -24,6 +24,9 @@ int launch_conv_w4x3(const ConvArgs &a0, hipStream_t stream);
 bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
 int launch_conv_s2f(const ConvArgs &a0, hipStream_t stream);
+// conv_s2f_x3.hip: the same tile under the strict policy (split-copy input, three products)
+bool s2f_x3_eligible(const ConvArgs &a);
+int launch_conv_s2f_x3(const ConvArgs &a0, hipStream_t stream);
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -1657,6 +1660,19 @@ static bool s2f_applies(const dl_conv_desc *d) {
     return s2f_eligible(a);
 }
 
+// ... and to its strict twin (conv_s2f_x3.hip)?  Needs the split copy of the input; DL_CONV_S2F=0 or DL_CONV_S2FX3=0: keep the 4-phase strict kernel (A/B)
+static bool s2fx3_applies(const dl_conv_desc *d) {
+    static const char *env = getenv("DL_CONV_S2F");
+    static const char *env3 = getenv("DL_CONV_S2FX3");
+    if ((env && env[0] == '0') || (env3 && env3[0] == '0') || d->in_dtype != DL_F32 || d->prec != DL_PREC_BF16X3 || d->in_act != DL_ACT_NONE || d->n_phase != 4 ||
+        !d->in_split || !x3_glds_applies(d))
+        return false;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_conv_geometry(a, d);
+    return s2f_x3_eligible(a);
+}
+
 // tile height (pixels) the dispatch picks for the bf16 direct-to-LDS path; 0 when that path is not taken
 static int glds_tile_bm(const dl_conv_desc *d) {
     static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
@@ -1676,6 +1692,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (c4_bf16_eligible(d)) return "conv_c4_patch_kernel";
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
+    if (s2fx3_applies(d)) return "conv_s2f_x3_kernel";
     const int bm = glds_tile_bm(d);
     if (bm == 0 && x3_glds_applies(d)) {
         if (w4x3_enabled()) {
@@ -1710,7 +1727,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
     if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
-    if (s2f_applies(d)) {                                            // one chunk per 256-pixel tile of the phase grid (all four phases summed)
+    if (s2f_applies(d) || s2fx3_applies(d)) {                        // one chunk per 256-pixel tile of the phase grid (all four phases summed)
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         fill_conv_geometry(a, d);
@@ -1728,7 +1745,7 @@ extern "C" int dl_conv_bnstats_chunks(const dl_conv_desc *d) {
     // channels per tile, no split-K, tiles that do not straddle images
     static const bool off = getenv("DL_OLD_EPILOGUE") != nullptr;
     static const char *p32 = getenv("DL_CONV_P32");
-    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d)) return 0;
+    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d) || s2fx3_applies(d)) return 0;
     static const int min_bm = getenv("DL_BNSTATS_MIN_BM") ? atoi(getenv("DL_BNSTATS_MIN_BM")) : 0;       // A/B: 256 = only the 256 x 256-tile kernels
     if (glds_tile_bm(d) < min_bm) return 0;
     return dl_conv_stats_chunks(d);
@@ -1807,6 +1824,7 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
     else if (!bn && s2f_applies(d)) rc = launch_conv_s2f(a, stream);
+    else if (!bn && s2fx3_applies(d)) rc = launch_conv_s2f_x3(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = x3_glds_applies(d) ? dispatch_tile_x3(a, stream) : dispatch_tile<float, float, 3>(a, stream);

@@ -324,7 +324,8 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     if spec.kind == 'convT':
         assert (ho, wo) == (2 * hi, 2 * wi)
     assert x.values_stored or not layer.narrow, 'a split-only activation reached the narrow-Cout path'
-    if layer.narrow and in_act == L.ACT_NONE and ctx.prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
+    if layer.narrow and in_act == L.ACT_NONE and ((ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16) or (ctx.prec.prec == L.PREC_BF16X3 and x.t.dtype == torch.float32)) and \
+            be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
         # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
         be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
         nch = 0

@@ -476,6 +476,11 @@ class HipBackend:
     def conv_narrow_forward(self, packed, x, out, cout, k, pad, bias, act):
         _need_cuda(x, out, bias, packed.hi)
         n, h, w, cp = x.shape
+        if x.dtype == torch.float32:            # strict policy: fp32 rows split while the fragments are read, hi weights in registers, lo weights in LDS
+            assert packed.lo is not None and out.dtype == torch.float32
+            L.check(self.lib.dl_conv_narrow_forward_x3(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), _ptr(packed.lo), packed.plan.kstride, cout, k, k, pad,
+                                                       _ptr(bias), act, _ptr(out), pstride(out), out.shape[3], _stream()), 'dl_conv_narrow_forward_x3')
+            return
         L.check(self.lib.dl_conv_narrow_forward(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), packed.plan.kstride, cout, k, k, pad, _ptr(bias), act,
                                                 _ptr(out), pstride(out), out.shape[3], _stream()), 'dl_conv_narrow_forward')
 

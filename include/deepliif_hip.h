@@ -213,6 +213,11 @@ int dl_shift_stack(int dtype, const void *dy, int dy_pstride, int N, int H, int 
 int dl_conv_narrow_supported(int dtype, int Ci, int x_pstride, int Cout, int KH, int KW, int pad, int pad_mode);
 int dl_conv_narrow_forward(const void *x, int N, int H, int W, int Ci, int x_pstride, const void *w_hi, int w_kstride, int Cout, int KH, int KW,
                            int pad, const float *bias, int act, void *out, int out_pstride, int out_Cp, void *stream);
+/* The same layer under the strict policy (fp32 storage, split-bf16 x3 products): x and out are fp32 NHWC, w_hi / w_lo the two images of
+ * dl_pack_weights(stack_kw).  dl_conv_narrow_supported(DL_F32, ...) says whether it applies.  (round 4; the round-3 route was
+ * dl_conv_forward(raw_out) + dl_shift_sum.) */
+int dl_conv_narrow_forward_x3(const void *x, int N, int H, int W, int Ci, int x_pstride, const void *w_hi, const void *w_lo, int w_kstride,
+                              int Cout, int KH, int KW, int pad, const float *bias, int act, void *out, int out_pstride, int out_Cp, void *stream);
 
 /* Backward of nn.ReflectionPad2d(pad) in front of a padding=0 Conv2d (ResnetGenerator with padding_type='reflect':
  * networks.py:386-388 stem, 478-481 / 495-498 ResnetBlock, 438-440 head).  The data gradient of such a layer is computed in two

@@ -623,33 +623,42 @@ def test_narrow_cout_head_conv(precname, pm):
         assert rel(res['real']['db'], res['fake']['db']) < 1e-3
 
 
+@pytest.mark.parametrize('precname', ['bf16', 'fp32'])
 @pytest.mark.parametrize('shape', [(2, 70, 130), (1, 16, 58), (1, 150, 64), (3, 33, 59), (1, 512, 512)])
 @pytest.mark.parametrize('cout,act', [(3, L.ACT_TANH), (1, L.ACT_NONE)])
-def test_narrow_roll_kernel_against_torch(shape, cout, act):
+def test_narrow_roll_kernel_against_torch(shape, cout, act, precname):
     """dl_conv_narrow_forward (rolling input rows, every kernel row at once, kernel-column sum from LDS) vs torch's conv2d on the same
-    bf16-rounded operands: several strips with a ragged last one, row bands with recomputed halo rows, images narrower than a strip."""
+    operands: several strips with a ragged last one, row bands with recomputed halo rows, images narrower than a strip.
+    fp32 = dl_conv_narrow_forward_x3 (strict policy: fp32 rows split into bf16 hi / lo while the fragments are read, lo weights in LDS, eight
+    rolling blocks) against the fp64 convolution of the fp32 operands."""
     from deepliif_amd import engine as E
     n, h, w = shape
-    prec = Precision.get('bf16')
+    prec = Precision.get(precname)
     real = hip()
     spec = ConvSpec('conv', 64, cout, 7, 1, 3, L.PAD_ZERO)
     w0 = rnd((cout, 64, 7, 7), 11, prec, 0.05)
     b0 = rnd((cout,), 12, Precision.get('fp32'), 0.1)
     x0 = rnd((n, h, w, 64), 13, prec)
-    ref = torch.nn.functional.conv2d(x0.permute(0, 3, 1, 2), w0, b0, padding=3)
+    ref = torch.nn.functional.conv2d(x0.double().permute(0, 3, 1, 2), w0.double(), b0.double(), padding=3)
     if act == L.ACT_TANH:
         ref = torch.tanh(ref)
+    ref = ref.float()
     wp = torch.nn.Parameter(w0.clone().to(DEV))
     layer = E.ConvLayer(spec, wp, torch.nn.Parameter(b0.clone().to(DEV)))
     layer.ensure_packed(prec, need_dgrad=False)
-    xd = x0.to(torch.bfloat16).to(DEV)
+    xd = x0.to(prec.dtype).to(DEV)
     assert real.conv_narrow_supported(xd, 64, cout, 7, 3, L.PAD_ZERO)
-    out = torch.full((n, h, w, 8), 5.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((n, h, w, 8), 5.0, dtype=prec.dtype, device=DEV)
     real.conv_narrow_forward(layer.packed_fwd, xd, out, cout, 7, 3, layer.bias.detach(), act)
     sync()
     got = out.float().cpu()
     assert (got[..., cout:] == 0).all(), 'padded channels must be written as zeros'
-    assert rel(got[..., :cout].permute(0, 3, 1, 2), ref) < 6e-3
+    assert rel(got[..., :cout].permute(0, 3, 1, 2), ref) < (6e-3 if precname == 'bf16' else 1e-4)
+    if precname == 'fp32':
+        out2 = torch.empty_like(out)
+        real.conv_narrow_forward(layer.packed_fwd, xd, out2, cout, 7, 3, layer.bias.detach(), act)
+        sync()
+        assert torch.equal(out, out2)              # run to run
 
 
 @pytest.mark.parametrize('precname', ['bf16', 'fp32'])
@@ -958,7 +967,8 @@ def test_split_copy_inputs_are_bit_identical_to_the_in_kernel_split(case):
         else:
             # the ResnetBlock shape: split copies go to conv_gemm_w4x3_kernel (r04), fp32 inputs stay on the 8-phase strict kernel -- same split
             # formula and products, another summation order (32x32x16 fragments, (chunk, kh, kw) K order)
-            assert real.last_conv_kernel == 'conv_gemm_w4x3_kernel' and rel(b, a) < 2e-6, (plan_kind, real.last_conv_kernel, rel(b, a))
+            # likewise the fused four-phase tile: split copies go to conv_s2f_x3_kernel (r04), fp32 inputs stay on the 4-phase strict kernel
+            assert real.last_conv_kernel in ('conv_gemm_w4x3_kernel', 'conv_s2f_x3_kernel') and rel(b, a) < 2e-6, (plan_kind, real.last_conv_kernel, rel(b, a))
     gshape = wshape
     P, Ps, Q, Qs = (dy, dys, x, xs) if kind == 'conv' else (x, xs, dy, dys)
     g0 = torch.empty(gshape, device=DEV)
@@ -1010,3 +1020,54 @@ def test_strict_w4_kernel_on_split_copies(case):
             sync()
             assert rel(st1[0], st2[0]) < 1e-5 and rel(st1[1], st2[1]) < 1e-5 and rel(z1, z2) < 1e-5
 
+
+
+@pytest.mark.parametrize('case', [('convT', 128, 64, 3, 1, 256, 256, 'fwd'), ('convT', 256, 128, 3, 2, 128, 256, 'fwd'), ('conv', 64, 128, 3, 1, 512, 512, 'dgrad'),
+                                  ('conv', 64, 128, 4, 1, 512, 512, 'dgrad'), ('conv', 128, 256, 4, 4, 200, 328, 'dgrad')],
+                         ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}n{c[4]}-{c[5]}x{c[6]}-{c[7]}')
+def test_strict_fused_stride2_tile_on_split_copies(case):
+    """conv_s2f_x3_kernel (csrc/conv_s2f_x3.hip): the stride-2 layers under the strict policy with a SPLIT-COPY input -- ConvTranspose2d(3, 2, 1, 1) forward
+    (bias, fused statistics over pixels and phases) and the data gradients of Conv2d(3 | 4, 2, 1) (4 / 9 distinct input offsets), at sizes that pass the
+    kernel's size rule (>= 256 tiles of 256 phase-grid pixels) incl. a ragged last tile; against the fp32 reference of the emulation backend at fp32-class
+    tolerance, run-to-run identical, and within 2e-6 of the 4-phase strict kernel that fp32 inputs keep."""
+    kind, cin, cout, k, N, H, W_, plan_kind = case
+    prec = Precision.get('fp32')
+    spec = ConvSpec(kind, cin, cout, k, 2, 1, L.PAD_ZERO, 1 if kind == 'convT' else 0)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd(wshape, 1, prec, 0.05)
+    fake, real = fake_backend.FakeBackend(), hip()
+    if plan_kind == 'fwd':
+        src, bias = rnd((N, H, W_, cin), 3, prec), rnd((cout,), 2, prec, 0.1)
+        hq, wq = H, W_
+    else:
+        ho, wo = spec.out_hw(H, W_)
+        src, bias = rnd((N, ho, wo, cout), 4, prec), None
+        hq, wq = (H + 1) // 2, (W_ + 1) // 2
+    exp = _run_conv(fake, plan_kind, spec, prec, src, w, bias, L.ACT_NONE, L.ACT_NONE, H, W_)
+    plan = spec.forward_plan() if plan_kind == 'fwd' else spec.dgrad_plan()
+    packed = ops.PackedWeights(plan, DEV, True)
+    real.pack_weights(packed, w.to(DEV))
+    srcd = src.to(DEV)
+    srcs = _split_copy(srcd)
+    want = plan_kind == 'fwd'
+    outs = []
+    for rep in range(2):
+        o = torch.full(exp.shape, 7.0, device=DEV)
+        nch = real.conv_forward(packed, srcs, o, hq, wq, None if bias is None else bias.to(DEV), L.ACT_NONE, L.ACT_NONE, prec.prec, in_split=True, want_stats=want)
+        sync()
+        outs.append(o)
+    assert (real.last_conv_kernel == 'conv_s2f_x3_kernel') == (os.environ.get('DL_CONV_S2F') != '0' and os.environ.get('DL_CONV_S2FX3') != '0'), real.last_conv_kernel
+    assert torch.equal(outs[0], outs[1]), 'run-to-run difference'
+    assert rel(outs[0], exp) < 2e-5, (plan_kind, rel(outs[0], exp))
+    plain = torch.empty(exp.shape, device=DEV)
+    real.conv_forward(packed, srcd, plain, hq, wq, None if bias is None else bias.to(DEV), L.ACT_NONE, L.ACT_NONE, prec.prec)
+    sync()
+    assert 'x3' in real.last_conv_kernel and rel(outs[0], plain) < 2e-6, (real.last_conv_kernel, rel(outs[0], plain))
+    if want:
+        assert nch == (hq * wq) // 256 if (hq * wq) % 256 == 0 else nch == 0
+        if nch:
+            z1, z2 = torch.empty_like(outs[0]), torch.empty_like(outs[0])
+            st1 = real.norm_forward(outs[0], z1, cout, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, -1.0, None, ext_nchunks=nch)
+            st2 = real.norm_forward(outs[0], z2, cout, L.NORM_INSTANCE, L.ACT_RELU, None, None, None, None, -1.0, None)
+            sync()
+            assert rel(st1[0], st2[0]) < 1e-5 and rel(st1[1], st2[1]) < 1e-5 and rel(z1, z2) < 1e-5

@@ -49,3 +49,13 @@ def test_strict_w4_kernel_under_its_switch():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]
 
+
+
+def test_strict_fused_stride2_tile_below_its_size_rule():
+    """conv_s2f_x3_kernel (csrc/conv_s2f_x3.hip) shares the size rule of the bf16 tile: the small stride-2 cases of the split-copy test reach it only with
+    DL_CONV_S2F=2 -- forward / data gradient within 2e-6 of the 4-phase strict kernel, weight gradients untouched"""
+    env = dict(os.environ, DL_CONV_S2F='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_kernels.py'), '-m', 'gpu', '-q', '-x', '-k',
+                        'split_copy_inputs'], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]

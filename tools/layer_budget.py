@@ -36,6 +36,17 @@ def timeit(fn, iters=12, warm=2):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def split_input(t, prec):
+    """LB_SPLIT=1 (strict policy): hand the convolutions the SPLIT COPY of their input ([8 bf16 hi | 8 bf16 lo] per group of 8 channels), as the norm
+    kernels do inside the training step -- the route conv_gemm_8ph_x3 / conv_s2f_x3 / the split-reading glds kernels take there"""
+    if os.environ.get('LB_SPLIT') != '1' or prec.prec != L.PREC_BF16X3 or t.dtype != torch.float32 or t.shape[3] < 32 or not be.conv_takes_split(t, prec.prec, L.ACT_NONE, L.PAD_ZERO):
+        return t, {}
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    g = torch.stack([hi.reshape(*t.shape[:3], -1, 8), lo.reshape(*t.shape[:3], -1, 8)], dim=4)
+    return g.contiguous().view(torch.int16).reshape(*t.shape[:3], -1).view(torch.float32).reshape(t.shape), {'in_split': True}
+
+
 def conv_case(name, kind, cin, cout, k, s, p, N, H, W, prec, n_fwd, n_dgrad, n_wgrad, op=0, act=L.ACT_NONE, bias=True):
     spec = ConvSpec(kind, cin, cout, k, s, p, L.PAD_ZERO, op)
     ho, wo = spec.out_hw(H, W)
@@ -57,7 +68,7 @@ def conv_case(name, kind, cin, cout, k, s, p, N, H, W, prec, n_fwd, n_dgrad, n_w
             T = torch.empty((N, ho, wo, cpad(cout * k)), dtype=torch.float32, device=DEV)
             out = torch.empty(N, ho, wo, cpad(cout), device=DEV, dtype=prec.dtype)
 
-            roll = prec.prec == L.PREC_BF16 and be.conv_narrow_supported(x, cpad(cin), cout, k, p, L.PAD_ZERO)
+            roll = (prec.prec == L.PREC_BF16 or (prec.prec == L.PREC_BF16X3 and x.dtype == torch.float32)) and be.conv_narrow_supported(x, cpad(cin), cout, k, p, L.PAD_ZERO)
             res['fwd_path'] = 'dl_conv_narrow_forward (rolling rows)' if roll else 'dl_conv_forward(raw) + dl_shift_sum'
 
             def f():
@@ -70,14 +81,17 @@ def conv_case(name, kind, cin, cout, k, s, p, N, H, W, prec, n_fwd, n_dgrad, n_w
             pf = ops.PackedWeights(spec.forward_plan(), DEV, prec.prec == 3); be.pack_weights(pf, w)
             out = torch.empty(N, ho, wo, cpad(cout), device=DEV, dtype=prec.dtype)
 
+            xin, kw = split_input(x, prec)
+
             def f():
-                be.conv_forward(pf, x, out, hq, wq, b, act, L.ACT_NONE, prec.prec, want_stats=(act == L.ACT_NONE))
+                be.conv_forward(pf, xin, out, hq, wq, b, act, L.ACT_NONE, prec.prec, want_stats=(act == L.ACT_NONE), **kw)
         t = timeit(f)
         res['fwd_us'], res['fwd_tf'], res['fwd_kernel'] = t * 1e6, flops / t / 1e12, be.last_conv_kernel
     if n_dgrad:
         pd = ops.PackedWeights(spec.dgrad_plan(), DEV, prec.prec == 3); be.pack_weights(pd, w)
         dx = torch.empty_like(x)
-        t = timeit(lambda: be.conv_forward(pd, dy, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, prec.prec))
+        dyin, kw = split_input(dy, prec)
+        t = timeit(lambda: be.conv_forward(pd, dyin, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, prec.prec, **kw))
         res['dgrad_us'], res['dgrad_tf'], res['dgrad_kernel'] = t * 1e6, flops / t / 1e12, be.last_conv_kernel
     if n_wgrad:
         grad = torch.zeros(wshape, device=DEV)
