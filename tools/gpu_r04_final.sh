@@ -4,7 +4,7 @@
 TAG=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -m gpu -q --timeout=900 2>&1 | tail -12 > gpurun_out/gpu_tests_$TAG.log; echo "tests rc=${PIPESTATUS[0]}"; tail -4 gpurun_out/gpu_tests_$TAG.log
+timeout 1800 python -m pytest tests -m gpu -q --timeout=900 > gpurun_out/gpu_tests_$TAG.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/gpu_tests_$TAG.log | tail -12
 cp gpurun_out/parity_errors.json gpurun_out/parity_errors_main_$TAG.json 2>/dev/null
 cp gpurun_out/parity_errors_fullsize.json gpurun_out/parity_errors_fullsize_$TAG.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
