@@ -46,7 +46,7 @@ class WgradDesc(C.Structure):
 class WgradReduceEntry(C.Structure):
     _fields_ = [('slab', C.c_void_p), ('grad', C.c_void_p),
                 ('splitk', i32), ('CAp', i32), ('CBp', i32), ('J', i32), ('CA', i32), ('CB', i32), ('KK', i32), ('accumulate', i32), ('stack_kw', i32),
-                ('block0', i32), ('nblocks', i32), ('reserved', i32)]
+                ('block0', i32), ('nblocks', i32), ('kstride', i32)]
 
 
 class PackDesc(C.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_wgrad_deferrable': (_i, [C.POINTER(WgradDesc)]),
+    'dl_wgrad_slab_floats': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'dl_conv_wgrad_slabs': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, C.POINTER(WgradReduceEntry), _vp]),
     'dl_wgrad_reduce_batch': (_i, [_vp, _i, _i, _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),

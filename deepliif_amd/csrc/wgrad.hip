@@ -17,6 +17,7 @@ struct WgradArgs {
     const void *P;
     const void *Q;
     float *slab;
+    int kstride;                // floats between the slabs of consecutive pixel ranges: CAp * J + wgrad_slab_pad()
     int N, Hp, Wp, CAp, p_pstride;
     int Hq, Wq, CBp, log2CB, q_pstride;
     int KH, KW, step, pad, pad_w, pad_mode;
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -625,7 +626,7 @@ __global__ void __launch_bounds__(512) wgrad_8ph_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * 128 + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -672,11 +673,11 @@ static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
 // coalesce; the (small) gradient tensor takes the strided writes.  (A 4-lanes-per-column variant with every load in flight was tried in
 // r02: 22.9 vs 21.6 us on the 66 MB ResnetBlock slab -- the pass is bound by reading partials the previous kernel has just written,
 // not by loads in flight -- so the sequential summation order stayed.)
-__device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB, int KK, float *grad,
+__device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk, int kstride_, int CBp, int J, int CA, int CB, int KK, float *grad,
                                                   int accumulate, int stack_kw, int bid, int nb) {
     const int J4 = J / 4;
     const size_t total = (size_t)CA * J4;
-    const size_t kstride = (size_t)CAp * J;
+    const size_t kstride = (size_t)kstride_;
     for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x) {
         const int ca = (int)(i / J4), j = (int)(i % J4) * 4;
         const float *src = slab + (size_t)ca * J + j;
@@ -697,9 +698,9 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk,
     }
 }
 
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int CAp, int CBp, int J, int CA, int CB,
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int kstride, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate, int stack_kw) {
-    wgrad_reduce_body(slab, splitk, CAp, CBp, J, CA, CB, KK, grad, accumulate, stack_kw, blockIdx.x, gridDim.x);
+    wgrad_reduce_body(slab, splitk, kstride, CBp, J, CA, CB, KK, grad, accumulate, stack_kw, blockIdx.x, gridDim.x);
 }
 
 // Deferred form (dl_conv_wgrad_slabs + dl_wgrad_reduce_batch): the slabs of MANY layers, each in its own region of a caller-owned arena, are
@@ -713,7 +714,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dl_wgrad_
         if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
     }
     const dl_wgrad_reduce_entry e = tab[lo];
-    wgrad_reduce_body(e.slab, e.splitk, e.CAp, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, e.stack_kw, b - e.block0, e.nblocks);
+    wgrad_reduce_body(e.slab, e.splitk, e.kstride, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, e.stack_kw, b - e.block0, e.nblocks);
 }
 
 template <typename T, int PREC, int BA, int WA, int WJ>
@@ -745,6 +746,20 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 #include "wgrad_c4.h"
 #include "wgrad_x3.h"
 
+// The slabs of consecutive pixel ranges lie CAp * J + PAD floats apart.  Without the pad the distance is a multiple of a large power of two for every
+// layer of these nets (ResnetBlock: 256 x 2304 floats = 9 x 2^18 bytes): all 28 partials of one gradient element -- written at the same moment by 28
+// workgroups, read back-to-back by one thread of the reduction -- fall on the same HBM channel.  DL_WGRAD_SLAB_PAD (floats, default 1088 = 17 x 256 B;
+// 0 = the unpadded layout of rounds 1-3, for the A/B) moves each slab 17 interleave units further.
+static int wgrad_slab_pad() {
+    static const int pad = [] { const char *e = getenv("DL_WGRAD_SLAB_PAD"); const int v = e ? atoi(e) : 1088; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
+    return pad;
+}
+
+extern "C" size_t dl_wgrad_slab_floats(const dl_wgrad_desc *d) {
+    if (!d || d->splitk < 1) return 0;
+    return (size_t)d->splitk * ((size_t)d->CAp * d->KH * d->KW * d->CBp + wgrad_slab_pad());
+}
+
 // the split-K kernel of the general path: slabs only (the reduction is the caller's: immediate or deferred)
 static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *slab, hipStream_t stream, int *J_out) {
     if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
@@ -766,6 +781,7 @@ static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, flo
     a.Hq = d->Hq; a.Wq = d->Wq; a.CBp = d->CBp; a.log2CB = l2; a.q_pstride = d->q_pstride;
     a.KH = d->KH; a.KW = d->KW; a.step = d->step; a.pad = d->pad; a.pad_w = d->pad_w < 0 ? d->pad : d->pad_w; a.pad_mode = d->pad_mode;
     a.J = d->KH * d->KW * d->CBp;
+    a.kstride = d->CAp * a.J + wgrad_slab_pad();
     a.Ptot = d->N * d->Hp * d->Wp;
     a.splitk = d->splitk;
     a.pchunk = ((a.Ptot + d->splitk - 1) / d->splitk + 31) / 32 * 32;
@@ -826,7 +842,7 @@ extern "C" int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *
     }
     int J = 0;
     if (const int rc = wgrad_slabs(d, P, Q, slab, stream, &J)) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_blocks(d, J)), dim3(256), 0, stream, slab, d->splitk, d->CAp, d->CBp, J, d->CA, d->CB,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_blocks(d, J)), dim3(256), 0, stream, slab, d->splitk, d->CAp * J + wgrad_slab_pad(), d->CBp, J, d->CA, d->CB,
                        d->KH * d->KW, grad, d->accumulate, d->stack_kw);
     DL_CHECK_LAUNCH("dl_conv_wgrad(reduce)");
     return 0;
@@ -848,7 +864,7 @@ extern "C" int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const 
     e.slab = slab; e.grad = grad;
     e.splitk = d->splitk; e.CAp = d->CAp; e.CBp = d->CBp; e.J = J; e.CA = d->CA; e.CB = d->CB; e.KK = d->KH * d->KW;
     e.accumulate = d->accumulate; e.stack_kw = d->stack_kw;
-    e.block0 = 0; e.nblocks = reduce_blocks(d, J);
+    e.block0 = 0; e.nblocks = reduce_blocks(d, J); e.kstride = d->CAp * J + wgrad_slab_pad();
     *entry_host = e;
     return 0;
 }

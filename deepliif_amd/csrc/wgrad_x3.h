@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(512) wgrad_4ph_x3_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * 128 + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[((size_t)ks * a.CAp + ca) * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }

@@ -167,7 +167,7 @@ class GradExchanger:
     def _launch(self, g, s, e):
         if g.is_cuda:
             from . import ops
-            flush = getattr(ops.impl(), 'wgrad_flush', None)
+            flush = getattr(ops.impl(), 'wgrad_flush_all', None)
             if flush is not None:
                 flush()                        # pending split-K slabs (ops.HipBackend: deferred reduction) become gradients before anything goes on the wire
         for b in range(s, e, MSG_ELEMS):

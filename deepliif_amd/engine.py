@@ -90,13 +90,18 @@ class Tape:
     outstanding use of a parameter is done, its gradient is final for this pass and `on_final(param)` fires -- a network that runs
     several times on one tape (a discriminator on real and fake pairs) therefore reports a weight only once, after both passes."""
 
-    def __init__(self):
+    def __init__(self, streams: bool = False):
         self.nodes: List[Callable[[], None]] = []
         self.uses = {}
         self.on_final: Optional[Callable[[torch.nn.Parameter], None]] = None
+        # branch streams (models.BaseModel._branch): every node remembers the HIP stream it was recorded on and runs its backward there -- a
+        # branch's forward, its losses and its backward stay in one in-order stream, different branches overlap on the GPU
+        self.node_streams: Optional[list] = [] if streams else None
 
     def record(self, fn: Callable[[], None]):
         self.nodes.append(fn)
+        if self.node_streams is not None:
+            self.node_streams.append(torch.cuda.current_stream())
 
     def use(self, *params):
         for p in params:
@@ -120,9 +125,22 @@ class Tape:
         begin = getattr(be, 'wgrad_defer_begin', None)
         if begin is not None:
             begin()
+        streams, self.node_streams = self.node_streams, ([] if self.node_streams is not None else None)
         try:
-            for fn in reversed(nodes):
-                fn()
+            if streams is None:
+                for fn in reversed(nodes):
+                    fn()
+            else:
+                home = torch.cuda.current_stream()
+                cur = home
+                try:
+                    for fn, s in zip(reversed(nodes), reversed(streams)):
+                        if s != cur:
+                            torch.cuda.set_stream(s)
+                            cur = s
+                        fn()
+                finally:
+                    torch.cuda.set_stream(home)
         finally:
             if begin is not None:
                 be.wgrad_defer_end()

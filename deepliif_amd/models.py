@@ -12,6 +12,7 @@ DeepLIIFExtModel / SDGModel, DeepLIIFKDModel (teacher through inference.init_net
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import sys
 from collections import OrderedDict
@@ -21,8 +22,13 @@ import torch
 
 from . import _lib as L
 from . import engine as E
+from . import distributed as D
 from . import networks
+from . import ops
 from .distributed import GradExchanger
+
+# DL_STREAMS=N (opt-in, default 1): the independent (G_i, D_i) branches of a DeepLIIF training step on N HIP streams (BaseModel._branch_streams)
+_N_STREAMS = max(1, int(os.environ.get('DL_STREAMS', '1')))
 
 
 def _get(opt, name, default):
@@ -84,6 +90,8 @@ class StepGraph:
         from .optim import FusedAdam
         if D.active():
             self.why_eager = 'data-parallel gradient exchange is active'
+        elif _N_STREAMS > 1 and getattr(model, 'branch_parallel', False):
+            self.why_eager = 'the branches run on several streams (DL_STREAMS)'
         elif not getattr(model, 'graphable', False):
             self.why_eager = f'{type(model).__name__} has host-side state per step'
         elif not all(isinstance(o, FusedAdam) for o in model.optimizers):
@@ -223,6 +231,42 @@ class BaseModel:
                 params = list(net.parameters())
                 if params and id(params[0]) in owned:
                     self.exchange.register_net(o, params)
+
+    # ---- branch streams (DL_STREAMS=N, opt-in): independent (generator, discriminator) branches of a training step on N HIP streams -----------
+    def _branch_streams(self):
+        """the HIP streams the branches of a training step are spread over, or None (the default: everything on torch's current stream).
+        Only where the branches are independent (DeepLIIFModel without the segmentation generators: G_i and D_i of modality i touch nothing
+        of modality j) and no gradient exchange is in flight (its all-reduces are ordered against ONE compute stream)."""
+        if not hasattr(self, '_streams'):
+            n = _N_STREAMS if (self.is_train and self.device.type == 'cuda' and getattr(self, 'branch_parallel', False) and not D.active()) else 1
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else None
+            if self._streams is not None:
+                ops.WS.branch_streams_on()
+        return self._streams
+
+    def _fork(self):
+        """start of a phase: every branch stream waits for what the main stream has issued so far (inputs, zeroed gradients, repacked weights)"""
+        streams = self._branch_streams()
+        if streams:
+            main = torch.cuda.current_stream()
+            for s in streams:
+                s.wait_stream(main)
+
+    def _join(self):
+        """end of a phase: the main stream (optimizer step, loss read-out) waits for every branch"""
+        streams = self._branch_streams()
+        if streams:
+            main = torch.cuda.current_stream()
+            for s in streams:
+                main.wait_stream(s)
+
+    def _branch(self, i):
+        """context: the kernels launched (and the tensors allocated) inside belong to the stream of branch i"""
+        streams = self._branch_streams()
+        return torch.cuda.stream(streams[i % len(streams)]) if streams else contextlib.nullcontext()
+
+    def _new_tape(self):
+        return E.Tape(streams=self._branch_streams() is not None)
 
     def _sync_replicas(self):
         """once, before the first step: broadcast parameters / BatchNorm buffers from rank 0 (what DistributedDataParallel does at
@@ -419,6 +463,9 @@ class DeepLIIFModel(BaseModel):
             self.criterionGAN_seg = networks.GANLoss(opt.gan_mode_s).to(self.device)
             self.lambda_L1 = _get(opt, 'lambda_L1', 100.0)
             self.lambda_feat, self.criterionVGG = self._make_vgg(opt)
+            # branches on several streams only where they are independent: no segmentation generators (they read the other branches' fakes), no VGG term
+            # (evaluated outside the branches), none of the subclasses' extra terms
+            self.branch_parallel = type(self) is DeepLIIFModel and not self.seg_gen and self.criterionVGG is None
             params_g = [p for n in self.model_names_g + self.model_names_gs for p in getattr(self, 'net' + n).parameters()]
             params_d = [p for n in self.model_names_d + self.model_names_ds for p in getattr(self, 'net' + n).parameters()]
             OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
@@ -460,15 +507,19 @@ class DeepLIIFModel(BaseModel):
     def forward(self, record: Optional[bool] = None):
         """DeepLIIF_model.py:175-203."""
         record = self.is_train if record is None else record
-        tape = E.Tape() if record else None
+        tape = self._new_tape() if record else None
         ctx = self._ctx(tape, training=record)
         M, S = self.opt.modalities_no, self.mod_id_seg
         self._fake = []
+        self._fork()
         for i, n in enumerate(self.model_names_g):
-            self._mark_net(tape, getattr(self, 'net' + n))
-            f = getattr(self, 'net' + n).run(ctx, self._A)
-            self._fake.append(f)
-            setattr(self, f'fake_B_{i + 1}', E.from_engine(f))
+            with self._branch(i):
+                self._mark_net(tape, getattr(self, 'net' + n))
+                f = getattr(self, 'net' + n).run(ctx, self._A)
+                self._fake.append(f)
+                setattr(self, f'fake_B_{i + 1}', E.from_engine(f))
+        if not record:
+            self._join()
         if self.seg_gen:
             parts = []
             for i, n in enumerate(self.model_names_gs):
@@ -486,7 +537,10 @@ class DeepLIIFModel(BaseModel):
     def _pairs_real(self, ctx):
         if self._real_pairs is None:
             M = self.opt.modalities_no
-            mod = [E.concat_channels(ctx, [self._A, self._B[i]]) for i in range(M)]
+            mod = []
+            for i in range(M):
+                with self._branch(i):
+                    mod.append(E.concat_channels(ctx, [self._A, self._B[i]]))
             seg = []
             if self.seg_gen:
                 for i in range(M + 1):
@@ -505,29 +559,33 @@ class DeepLIIFModel(BaseModel):
 
     def backward_D(self):
         """DeepLIIF_model.py:205-332: D losses on detached fakes and on real pairs."""
-        tape = E.Tape()
+        tape = self._new_tape()
         ctx = self._ctx(tape)
         M, S = self.opt.modalities_no, self.mod_id_seg
         wD = self.loss_D_weights
         cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
+        self._fork()                             # (the gradients were zeroed on the main stream)
         for net in self._d_nets():               # every discriminator runs twice below (fake, real): mark before the first use
             self._mark_net(tape, net)
         for i, n in enumerate(self.model_names_d):
-            pair = E.concat_channels(ctx, [self._A, self._fake[i].detach()])
-            pred = getattr(self, 'net' + n).run(ctx, pair)
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * wD[i], getattr(self, f'loss_D_fake_{i + 1}').view(1))
+            with self._branch(i):
+                pair = E.concat_channels(ctx, [self._A, self._fake[i].detach()])
+                pred = getattr(self, 'net' + n).run(ctx, pair)
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * wD[i], getattr(self, f'loss_D_fake_{i + 1}').view(1))
         if self.seg_gen:
             pred = self._seg_pred(ctx, self._fake_seg.detach())
             E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * wD[M], getattr(self, f'loss_D_fake_{S}').view(1))
         real_mod, real_seg = self._pairs_real(ctx)
         for i, n in enumerate(self.model_names_d):
-            pred = getattr(self, 'net' + n).run(ctx, real_mod[i])
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * wD[i], getattr(self, f'loss_D_real_{i + 1}').view(1))
+            with self._branch(i):
+                pred = getattr(self, 'net' + n).run(ctx, real_mod[i])
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * wD[i], getattr(self, f'loss_D_real_{i + 1}').view(1))
         if self.seg_gen:
             preds = [getattr(self, 'net' + n).run(ctx, real_seg[i]) for i, n in enumerate(self.model_names_ds)]
             pred = E.weighted_sum(ctx, preds, self.seg_weights[:M + 1])
             E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * wD[M], getattr(self, f'loss_D_real_{S}').view(1))
         tape.backward()
+        self._join()
 
     def backward_G(self):
         """DeepLIIF_model.py:334-429 (VGG term excluded).  The seg term is weighted by loss_G_weights[modalities_no - 1]:
@@ -538,15 +596,18 @@ class DeepLIIFModel(BaseModel):
         M, S = self.opt.modalities_no, self.mod_id_seg
         wG = self.loss_G_weights
         cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
+        self._fork()                             # (D was updated and repacked, the G gradients zeroed, on the main stream)
         for i, n in enumerate(self.model_names_d):
-            pair = E.concat_channels(ctx, [self._A, self._fake[i]])
-            pred = getattr(self, 'net' + n).run(ctx, pair)
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), wG[i], getattr(self, f'loss_G_GAN_{i + 1}').view(1))
+            with self._branch(i):
+                pair = E.concat_channels(ctx, [self._A, self._fake[i]])
+                pred = getattr(self, 'net' + n).run(ctx, pair)
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(True), wG[i], getattr(self, f'loss_G_GAN_{i + 1}').view(1))
         if self.seg_gen:
             pred = self._seg_pred(ctx, self._fake_seg)
             E.loss_op(ctx, cs.kind, pred, None, cs.target(True), wG[M - 1], getattr(self, f'loss_G_GAN_{S}').view(1))
         for i in range(M):
-            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, wG[i] * self.lambda_L1, self._l1_raw(i))
+            with self._branch(i):
+                E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, wG[i] * self.lambda_L1, self._l1_raw(i))
         if self.seg_gen:
             E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_seg, self._Bseg, 0.0, wG[M - 1] * self.lambda_L1, self._l1_raw(M))
         if self.criterionVGG is not None:
@@ -556,6 +617,7 @@ class DeepLIIFModel(BaseModel):
                 self.criterionVGG.run(ctx, self._fake[i], self._B[i], wG[i] * self.lambda_feat, self._vgg_buf[i:i + 1])
         self._extra_g_terms(ctx)
         tape.backward()
+        self._join()
         self._tape_G = None
         # the reference logs loss_G_L1 already multiplied by lambda_L1 (:398-400)
         self._loss_buf[self._l1_slots] *= self.lambda_L1

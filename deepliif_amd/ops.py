@@ -64,13 +64,31 @@ class Workspace:
     def __init__(self):
         self._tls = threading.local()
 
-    def _state(self):
+    def _thread_state(self):
         # DL_SHARED_SCRATCH=1 restores the process-wide buffers: ONLY for demonstrating the hazard (tests/test_gpu_networks.py,
         # test_inference_seam_is_thread_safe fails with it)
-        st = _SHARED_STATE if _SHARED_SCRATCH else self._tls.__dict__
+        return _SHARED_STATE if _SHARED_SCRATCH else self._tls.__dict__
+
+    def _state(self):
+        """scratch state of the calling thread -- and, once a model runs its branches on several HIP streams (branch_streams_on), of the CURRENT
+        stream: two streams of one thread run concurrently on the GPU, so they may not share a slab, a statistics workspace or a slab arena"""
+        st = self._thread_state()
+        if st.get('per_stream') and torch.cuda.is_available():
+            s = torch.cuda.current_stream()
+            sub = st.setdefault('streams', {}).get(s.cuda_stream)
+            if sub is None:
+                sub = st['streams'][s.cuda_stream] = {'stream_obj': s}
+            st = sub
         if 'bufs' not in st:
             st['bufs'], st['norm_ws_token'] = {}, 0
         return st
+
+    def branch_streams_on(self):
+        self._thread_state()['per_stream'] = True
+
+    def stream_states(self):
+        """every per-stream state of this thread (empty unless branch_streams_on() was called)"""
+        return list(self._thread_state().get('streams', {}).values())
 
     def get(self, name: str, nfloats: int, device) -> torch.Tensor:
         bufs = self._state()['bufs']
@@ -274,10 +292,9 @@ class HipBackend:
         d.accumulate = 1 if accumulate else 0
         d.p_act, d.q_act = p_act, q_act
         d.p_split, d.q_split = (1 if p_split else 0), (1 if q_split else 0)
-        nslab = d.splitk * d.CAp * j
-        st = WS._state()
-        if _WGRAD_DEFER and st.get('defer_depth', 0) > 0 and self.lib.dl_conv_wgrad_deferrable(C.byref(d)):
-            self._wgrad_deferred(st, d, P, Q, grad, nslab)
+        nslab = int(self.lib.dl_wgrad_slab_floats(C.byref(d)))
+        if _WGRAD_DEFER and WS._thread_state().get('defer_depth', 0) > 0 and self.lib.dl_conv_wgrad_deferrable(C.byref(d)):
+            self._wgrad_deferred(WS._state(), d, P, Q, grad, nslab)
             return
         slab = WS.get('wgrad_slab', nslab, P.device)
         L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
@@ -288,16 +305,24 @@ class HipBackend:
     # fake pairs: the second accumulation must see the first), (c) the arena is full, or (d) the data-parallel exchange is about to put
     # gradients on the wire (distributed.GradExchanger._launch).  Results are bit-identical to the immediate reduction.
     def wgrad_defer_begin(self):
-        st = WS._state()
+        st = WS._thread_state()
         st['defer_depth'] = st.get('defer_depth', 0) + 1
 
     def wgrad_defer_end(self):
-        st = WS._state()
+        st = WS._thread_state()
         try:
             if st.get('defer_depth', 0) == 1:
-                self.wgrad_flush()
+                self.wgrad_flush_all()
         finally:
             st['defer_depth'] = max(0, st.get('defer_depth', 0) - 1)
+
+    def wgrad_flush_all(self):
+        """wgrad_flush() on every stream of this thread that has slabs pending (each batch is launched on the stream that wrote its slabs)"""
+        self.wgrad_flush()
+        for sub in WS.stream_states():
+            if sub.get('defer_pending'):
+                with torch.cuda.stream(sub['stream_obj']):
+                    self.wgrad_flush()
 
     def _wgrad_deferred(self, st, d, P, Q, grad, nslab):
         gp = grad.data_ptr()

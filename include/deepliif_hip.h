@@ -120,7 +120,7 @@ const char *dl_conv_kernel_name(const dl_conv_desc *d);
  *   ConvTranspose2d  : P = layer input (a = in channel), Q = dL/dy (b = out channel)   -> IOHW
  * (pixel contraction runs on MFMA via ds_read_b64_tr_b16 transposing LDS reads; split-K slabs combined in a fixed order)
  * Replaces ATen conv backward-weight reached from DeepLIIF_model.py:332,429.
- * slab: fp32 scratch, splitk * CAp * (KH*KW*CBp) elements.  reflect padding of Q is supported (pad_mode).
+ * slab: fp32 scratch, dl_wgrad_slab_floats(d) elements (splitk slabs of CAp * (KH*KW*CBp), padded apart).  reflect padding of Q is supported (pad_mode).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct dl_wgrad_desc {
     int32_t N, Hp, Wp, CAp, p_pstride;   /* P: coarse grid                                   */
@@ -139,6 +139,9 @@ typedef struct dl_wgrad_desc {
     int32_t p_split, q_split;            /* 1: P / Q is the split copy of the fp32 tensor (see dl_conv_desc.in_split); strict policy, no staged activation */
 } dl_wgrad_desc;
 
+/* floats the `slab` argument of dl_conv_wgrad / dl_conv_wgrad_slabs must hold for this descriptor: splitk x (CAp x KH*KW*CBp + pad); the pad (round 4)
+ * keeps the slabs of consecutive pixel ranges off one HBM channel -- their unpadded distance is a multiple of 2^18 bytes for every layer of these nets. */
+size_t dl_wgrad_slab_floats(const dl_wgrad_desc *d);
 int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
 
 /* Deferred reduction of the split-K slabs (round 4).  A backward pass over one network launches ~30-60 weight gradients; reducing each one's
@@ -155,7 +158,7 @@ typedef struct dl_wgrad_reduce_entry {
     const float *slab;
     float *grad;
     int32_t splitk, CAp, CBp, J, CA, CB, KK, accumulate, stack_kw;
-    int32_t block0, nblocks, reserved;
+    int32_t block0, nblocks, kstride;    /* kstride: floats between consecutive slabs (see dl_wgrad_slab_floats) */
 } dl_wgrad_reduce_entry;
 int dl_conv_wgrad_deferrable(const dl_wgrad_desc *d);
 int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, dl_wgrad_reduce_entry *entry_host, void *stream);

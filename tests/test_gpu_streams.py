@@ -1,0 +1,62 @@
+"""Branch streams (DL_STREAMS=N, models.BaseModel._branch_streams): the independent (G_i, D_i) branches of a DeepLIIF training step spread over N HIP
+streams -- every branch's forward, losses and backward stay in ONE in-order stream (engine.Tape runs a node's backward on the stream it was recorded on),
+scratch buffers / statistics workspaces / slab arenas are per stream (ops.Workspace), phases fork from and join into the main stream around the
+optimizer steps.  Nothing about a branch's arithmetic or summation order changes, so N streams must be BIT-identical to one: every loss of every step
+and the final parameters, bf16 and strict policy, N = 2, 3 and 5 (one stream per branch); and the models whose branches are NOT independent decline."""
+import pytest
+import torch
+
+from deepliif_amd import models as M
+from deepliif_amd import ops
+from test_gpu_graph import _batches, _build, _flat
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    ops._impl = None
+    yield
+    ops.WS._thread_state().pop('per_stream', None)
+    ops.WS._thread_state().pop('streams', None)
+
+
+def _run(model, batches):
+    losses = []
+    for b in batches:
+        model.set_input({k: ([t.to(DEV) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else (v.to(DEV) if torch.is_tensor(v) else v)) for k, v in b.items()})
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        losses.append(dict(model.get_current_losses()))
+    return losses, _flat(model), [getattr(model, f'fake_B_{i + 1}').clone() for i in range(5)]
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('nstreams', [2, 3, 5])
+def test_branch_streams_are_bit_identical_to_one_stream(nstreams, precision, monkeypatch):
+    batches = _batches('train', 2, 64, 4, 5)
+    monkeypatch.setattr(M, '_N_STREAMS', 1)
+    ref_model = _build('train', precision)
+    assert ref_model._branch_streams() is None
+    ref = _run(ref_model, batches)
+    monkeypatch.setattr(M, '_N_STREAMS', nstreams)
+    model = _build('train', precision)
+    got = _run(model, batches)
+    assert model._streams is not None and len(model._streams) == nstreams
+    used = [s for s in ops.WS.stream_states() if s.get('bufs')]
+    assert len(used) >= nstreams                      # every branch stream worked out of its own scratch state
+    assert got[0] == ref[0]
+    assert torch.equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        assert torch.equal(a, b)
+
+
+def test_models_with_dependent_branches_stay_on_one_stream(monkeypatch):
+    monkeypatch.setattr(M, '_N_STREAMS', 3)
+    seg = _build('train18', 'bf16')                   # segmentation generators read the other branches' outputs
+    assert seg.branch_parallel is False and seg._branch_streams() is None
+    ext = _build('ext', 'bf16')
+    assert not getattr(ext, 'branch_parallel', False) and ext._branch_streams() is None
+    sg = M.StepGraph(_build('train', 'bf16'))
+    assert sg.why_eager and 'streams' in sg.why_eager
