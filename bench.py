@@ -418,11 +418,30 @@ def main():
 
     tiles_total = args.steps * n * world
     value = tiles_total / dt
+
+    def n_streams(m):
+        return len(getattr(m, '_streams', None) or []) if m is not None else 0
+
+    def solo_pass(stepfn, m, tm):
+        """Branch streams (models.BaseModel._branch_streams): launches of different streams share the GPU, so the event-bracketed duration of ONE launch inside
+        the timed region measures contention, not the kernel.  The same steps once more on ONE stream (streams switched off on the same model, per-launch
+        events on) give the launch duration the roofline block is about; the concurrent figure stays in the line next to it."""
+        conc = (tm.mean_seconds(), tm.median_seconds(), len(tm.pairs))
+        saved, m._streams = m._streams, None
+        try:
+            tm.pairs = []
+            sdt_ = timed(stepfn, 1, args.steps, tm)
+        finally:
+            m._streams = saved
+        return conc, sdt_
     # what do the event pairs around the dominant launches cost?  the same K steps once more, events off (same process, same state of the clocks)
     dt_noev = None
     if args.workload != 'wsi' and not dry and timer.pairs and not args.no_timer_check:
         dt_noev = timed(step, 1, args.steps)
 
+    conc_info, dt_solo = None, None
+    if n_streams(model) > 1 and not dry and timer.pairs:
+        conc_info, dt_solo = solo_pass(step, model, timer)
     kt = timer.mean_seconds()
     kt_median = timer.median_seconds() if hasattr(timer, 'median_seconds') else kt
 
@@ -438,6 +457,9 @@ def main():
         sdt = timed(sstep, swarm, ssteps, timer if hasattr(timer, '_orig') else None)
         strict.update({'value': round(ssteps * n * world / sdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(sdt / ssteps * 1e3, 3), 'steps': ssteps, 'warmup': swarm,
                        'model_tflops': round(ssteps * n * world / sdt * gf_per_tile / 1e3, 1)})
+        sconc, sdt_solo = None, None
+        if n_streams(smodel) > 1 and hasattr(timer, '_orig') and timer.pairs:
+            sconc, sdt_solo = solo_pass(sstep, smodel, timer)
         skt = timer.mean_seconds() if hasattr(timer, '_orig') else None
         if skt:
             sach = flops_per_launch / skt / 1e12
@@ -446,6 +468,10 @@ def main():
                                   'kernel': f'{timer.kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv fwd + dgrad (fp32 storage, split-bf16 x3); timed by events around the host call',
                                   'launches_timed': len(timer.pairs), 'avg_launch_us': round(skt * 1e6, 2), 'median_launch_us': round(timer.median_seconds() * 1e6, 2),
                                   'note': 'achieved = algorithmic conv flops per launch / launch time; mfma_pipe_frac counts the 3 MFMA passes the policy issues per product'}
+            if sconc is not None:
+                strict['roofline'].update({'launch_times_from': f'a second pass of the same {ssteps} steps on ONE stream ({round(sdt_solo / ssteps * 1e3, 3)} ms/step)',
+                                           'concurrent_avg_launch_us': round(sconc[0] * 1e6, 2), 'concurrent_median_launch_us': round(sconc[1] * 1e6, 2)})
+            strict['streams'] = n_streams(smodel) or 1
             try:        # HBM-side bytes per launch from the committed --pmc passes over this kernel and shape (not measured in this run)
                 with open(os.path.join(ROOT, 'profiles', STRICT_PMC_FILE)) as f:
                     spmc = json.load(f)
@@ -516,6 +542,13 @@ def main():
                                          'frac_of_sustained_random': round(ach / sus['random_tflops'], 4)}
             except Exception as exc:          # measurement aid only
                 roofline['sustained'] = {'error': str(exc)[:200]}
+        if conc_info is not None:
+            roofline.update({'launch_times_from': f'a second pass of the same {args.steps} steps on ONE stream, per-launch events on ({round(dt_solo / args.steps * 1e3, 3)} ms/step): the timed region '
+                                                  f'runs the independent (G_i, D_i) branches on {n_streams(model)} HIP streams, where the event-bracketed duration of one launch measures the '
+                                                  'share of the GPU it got, not the kernel',
+                             'one_stream_ms_per_step': round(dt_solo / args.steps * 1e3, 3),
+                             'concurrent_avg_launch_us': round(conc_info[0] * 1e6, 2), 'concurrent_median_launch_us': round(conc_info[1] * 1e6, 2),
+                             'concurrent_launches_timed': conc_info[2]})
         if dt_noev is not None:
             roofline['timer_overhead'] = {'ms_per_step_with_events': round(dt / args.steps * 1e3, 3), 'ms_per_step_without_events': round(dt_noev / args.steps * 1e3, 3),
                                           'relative': round(dt / dt_noev - 1.0, 5),

@@ -746,12 +746,13 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 #include "wgrad_c4.h"
 #include "wgrad_x3.h"
 
-// The slabs of consecutive pixel ranges lie CAp * J + PAD floats apart.  Without the pad the distance is a multiple of a large power of two for every
+// The slabs of consecutive pixel ranges lie CAp * J + PAD floats apart.  Without a pad the distance is a multiple of a large power of two for every
 // layer of these nets (ResnetBlock: 256 x 2304 floats = 9 x 2^18 bytes): all 28 partials of one gradient element -- written at the same moment by 28
-// workgroups, read back-to-back by one thread of the reduction -- fall on the same HBM channel.  DL_WGRAD_SLAB_PAD (floats, default 1088 = 17 x 256 B;
-// 0 = the unpadded layout of rounds 1-3, for the A/B) moves each slab 17 interleave units further.
+// workgroups, read back-to-back by one thread of the reduction -- would fall on one HBM channel IF the channel were a plain bit field of the address.
+// Tested r04 (DL_WGRAD_SLAB_PAD = 1088 and 4160 floats vs 0, same box, tools/gpu_r04_streams.sh): 94.75 / 94.69 vs 94.74-94.82 ms per step -- nothing;
+// the memory system hashes the channel.  The pad stays available (floats, default 0) because the slab size is now asked from the library anyway.
 static int wgrad_slab_pad() {
-    static const int pad = [] { const char *e = getenv("DL_WGRAD_SLAB_PAD"); const int v = e ? atoi(e) : 1088; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
+    static const int pad = [] { const char *e = getenv("DL_WGRAD_SLAB_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
     return pad;
 }
 

@@ -139,8 +139,8 @@ typedef struct dl_wgrad_desc {
     int32_t p_split, q_split;            /* 1: P / Q is the split copy of the fp32 tensor (see dl_conv_desc.in_split); strict policy, no staged activation */
 } dl_wgrad_desc;
 
-/* floats the `slab` argument of dl_conv_wgrad / dl_conv_wgrad_slabs must hold for this descriptor: splitk x (CAp x KH*KW*CBp + pad); the pad (round 4)
- * keeps the slabs of consecutive pixel ranges off one HBM channel -- their unpadded distance is a multiple of 2^18 bytes for every layer of these nets. */
+/* floats the `slab` argument of dl_conv_wgrad / dl_conv_wgrad_slabs must hold for this descriptor: splitk x (CAp x KH*KW*CBp + pad); pad = DL_WGRAD_SLAB_PAD
+ * floats (default 0: a padded slab distance was measured to change nothing, see csrc/wgrad.hip). */
 size_t dl_wgrad_slab_floats(const dl_wgrad_desc *d);
 int dl_conv_wgrad(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, void *stream);
 

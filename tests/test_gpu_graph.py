@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
+@pytest.fixture(autouse=True)
+def _one_stream(monkeypatch):
+    """StepGraph captures the single-stream step (with the branches on several streams, DL_STREAMS > 1, it declines: test_gpu_streams.py)"""
+    monkeypatch.setattr(M, '_N_STREAMS', 1)
+
+
 def _batches(kind, n, size, count, m):
     g = torch.Generator().manual_seed(77)
     out = []

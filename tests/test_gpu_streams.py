@@ -2,7 +2,8 @@
 streams -- every branch's forward, losses and backward stay in ONE in-order stream (engine.Tape runs a node's backward on the stream it was recorded on),
 scratch buffers / statistics workspaces / slab arenas are per stream (ops.Workspace), phases fork from and join into the main stream around the
 optimizer steps.  Nothing about a branch's arithmetic or summation order changes, so N streams must be BIT-identical to one: every loss of every step
-and the final parameters, bf16 and strict policy, N = 2, 3 and 5 (one stream per branch); and the models whose branches are NOT independent decline."""
+and the final parameters, bf16 and strict policy, N = 2, 3 and 5 (one stream per branch); the same with the data-parallel exchange in flight (one-rank
+RCCL group: every network's all-reduce is issued from a tape node of its branch, behind THAT stream); and the models whose branches are NOT independent decline."""
 import pytest
 import torch
 
@@ -60,3 +61,29 @@ def test_models_with_dependent_branches_stay_on_one_stream(monkeypatch):
     assert not getattr(ext, 'branch_parallel', False) and ext._branch_streams() is None
     sg = M.StepGraph(_build('train', 'bf16'))
     assert sg.why_eager and 'streams' in sg.why_eager
+
+
+def test_branch_streams_under_the_gradient_exchange(monkeypatch):
+    """DL_STREAMS=3 with a (one-rank, identity) RCCL exchange forced on: the all-reduce of network i must be ordered behind the stream that produced its
+    gradients, finish() behind the join -- a race shows up as a difference from the plain single-stream step"""
+    import torch.distributed as dist
+    from deepliif_amd import distributed as D
+    from test_gpu_distributed import _free_port
+    batches = _batches('train', 2, 64, 3, 5)
+    monkeypatch.setattr(M, '_N_STREAMS', 1)
+    ref = _run(_build('train', 'bf16'), batches)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(D, 'FORCE', True)
+        monkeypatch.setattr(M, '_N_STREAMS', 3)
+        assert D.active()
+        model = _build('train', 'bf16')
+        got = _run(model, batches)
+        assert model._streams is not None and len(model._streams) == 3
+        assert len(model.exchange.launch_log) >= 5          # every generator's slice went out from the tape of the last backward_G
+        assert got[0] == ref[0]
+        assert torch.equal(got[1], ref[1])
+    finally:
+        dist.destroy_process_group()

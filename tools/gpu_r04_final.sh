@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-4 end-of-round verification on ONE box: every GPU test, smoke, the contract line exactly as the driver runs it (cpu_baseline legs included),
-# rocprofv3 --kernel-trace --stats of the bf16 and of the strict step, the bf16 layer budget, the other workloads.  Every command has its own timeout.
+# rocprofv3 --kernel-trace --stats of the bf16 and of the strict step (on ONE stream, DL_STREAMS=1: per-kernel durations that mean the kernel, not its share of the
+# GPU next to another branch), the bf16 layer budget, the other workloads.  Every command has its own timeout.
 TAG=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -18,7 +19,7 @@ print('bench', d['value'], d['ms_per_step'], 'kernel', r['kernel'][:24], r['avg_
       'cpu', (d.get('cpu_baseline') or {}).get('value'))
 PY
 for P in bf16 fp32; do
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$P -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision $P --steps 3 --warmup 1 --no-cpu-baseline --no-cpu-baseline-n8 --no-strict --no-graph --no-timer-check > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/bench_prof_$P.err); echo "rocprof $P rc=$?"
+  (cd /tmp && DL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$P -o bench -- python $GRAFT_REPO_ROOT/bench.py --precision $P --steps 3 --warmup 1 --no-cpu-baseline --no-cpu-baseline-n8 --no-strict --no-graph --no-timer-check > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/bench_prof_$P.err); echo "rocprof $P rc=$?"
   cp gpurun_out/prof_$P/bench_kernel_stats.csv gpurun_out/bench_train_kernel_stats_${P}_$TAG.csv 2>/dev/null
   rm -rf gpurun_out/prof_$P
   python - <<PY
