@@ -50,7 +50,7 @@ _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
 _SPLIT_ONLY_GRAD = os.environ.get('DL_NO_SPLIT_ONLY_GRAD', '0') != '1'     # A/B switch: 1 = the norm backward always stores the fp32 gradient next to its split copy
 _NO_C4_X3 = 'DL_NO_C4_X3' in os.environ              # A/B switch: the strict 7x7 stem / head on the general x3 kernels (csrc/conv_x3.h, wgrad_x3.h)
 _WGRAD_DEFER = os.environ.get('DL_WGRAD_DEFER', '1') != '0'            # A/B switch: 0 = every weight gradient reduces its slabs right behind the split-K kernel (rounds 1-3)
-_WGRAD_ARENA_MB = int(os.environ.get('DL_WGRAD_ARENA_MB', '8192'))      # slab arena of the deferred reduction (one Resnet-9 generator's backward pass writes ~1.9 GB of slabs at batch 8; measured r04: 256 MB = no gain, 2 GB / 12 GB +0.8 %)
+_WGRAD_ARENA_MB = int(os.environ.get('DL_WGRAD_ARENA_MB', '4096'))      # slab arena of the deferred reduction (one Resnet-9 generator's backward pass writes ~1.9 GB of slabs at batch 8; measured r04: 256 MB = no gain, 2 GB / 12 GB +0.8 %)
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
