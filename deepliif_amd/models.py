@@ -244,7 +244,7 @@ class BaseModel:
             n = _N_STREAMS if (self.is_train and self.device.type == 'cuda' and getattr(self, 'branch_parallel', False)) else 1
             self._streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else None
             if self._streams is not None:
-                ops.WS.branch_streams_on()
+                ops.WS.branch_streams_on(self._streams)
         return self._streams
 
     def _fork(self):

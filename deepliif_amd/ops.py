@@ -70,21 +70,24 @@ class Workspace:
         return _SHARED_STATE if _SHARED_SCRATCH else self._tls.__dict__
 
     def _state(self):
-        """scratch state of the calling thread -- and, once a model runs its branches on several HIP streams (branch_streams_on), of the CURRENT
-        stream: two streams of one thread run concurrently on the GPU, so they may not share a slab, a statistics workspace or a slab arena"""
+        """scratch state of the calling thread -- or, while one of a model's BRANCH streams is current (branch_streams_on), of that stream: two
+        streams of one thread run concurrently on the GPU, so they may not share a slab, a statistics workspace or a slab arena"""
         st = self._thread_state()
-        if st.get('per_stream') and torch.cuda.is_available():
+        ids = st.get('branch_ids')
+        if ids:
             s = torch.cuda.current_stream()
-            sub = st.setdefault('streams', {}).get(s.cuda_stream)
-            if sub is None:
-                sub = st['streams'][s.cuda_stream] = {'stream_obj': s}
-            st = sub
+            if s.cuda_stream in ids:           # (any other stream -- torch's default stream, a graph-capture stream -- keeps the thread's own state, as before)
+                sub = st.setdefault('streams', {}).get(s.cuda_stream)
+                if sub is None:
+                    sub = st['streams'][s.cuda_stream] = {'stream_obj': s}
+                st = sub
         if 'bufs' not in st:
             st['bufs'], st['norm_ws_token'] = {}, 0
         return st
 
-    def branch_streams_on(self):
-        self._thread_state()['per_stream'] = True
+    def branch_streams_on(self, streams):
+        """register the branch streams of a model (models.BaseModel._branch_streams): work launched while one of them is current gets its own scratch state"""
+        self._thread_state().setdefault('branch_ids', set()).update(s.cuda_stream for s in streams)
 
     def stream_states(self):
         """every per-stream state of this thread (empty unless branch_streams_on() was called)"""
