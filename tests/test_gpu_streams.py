@@ -18,6 +18,8 @@ DEV = 'cuda'
 @pytest.fixture(autouse=True)
 def _reset():
     ops._impl = None
+    ops.WS._thread_state().pop('branch_ids', None)       # (models of earlier test files leave their branch streams' scratch states behind)
+    ops.WS._thread_state().pop('streams', None)
     yield
     ops.WS._thread_state().pop('branch_ids', None)
     ops.WS._thread_state().pop('streams', None)
