@@ -1,0 +1,135 @@
+"""Host logic of the branch streams (models.BaseModel._branch_streams, engine.Tape(streams=True), ops.Workspace) without a GPU: torch.cuda's stream calls are
+replaced by a recorder, so what is under test is the BOOK-KEEPING -- every tape node runs its backward under the stream it was recorded on, in reverse order,
+and the home stream is restored also when a node raises; scratch state is per REGISTERED branch stream only (torch's default stream and a graph-capture
+stream keep the thread's own state); the deferred slab reduction counts its nesting per thread, not per stream.  The GPU side (bit-identity of N streams
+with one) is tests/test_gpu_streams.py."""
+import pytest
+import torch
+
+from deepliif_amd import engine as E
+from deepliif_amd import ops
+
+
+class FakeStream:
+    def __init__(self, sid):
+        self.cuda_stream = sid
+
+    def __eq__(self, other):
+        return isinstance(other, FakeStream) and other.cuda_stream == self.cuda_stream
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self.cuda_stream)
+
+    def __repr__(self):
+        return f'S{self.cuda_stream}'
+
+
+@pytest.fixture
+def fake_cuda(monkeypatch):
+    state = {'cur': FakeStream(0), 'log': []}
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda device=None: state['cur'])
+
+    def set_stream(s):
+        state['log'].append(s)
+        state['cur'] = s
+    monkeypatch.setattr(torch.cuda, 'set_stream', set_stream)
+    return state
+
+
+class _NoDefer:
+    """a backend without the deferred reduction: Tape.backward() must not need it"""
+
+
+def test_tape_runs_every_node_on_the_stream_it_was_recorded_on(fake_cuda, monkeypatch):
+    monkeypatch.setattr(ops, '_impl', _NoDefer())
+    tape = E.Tape(streams=True)
+    ran = []
+    plan = [0, 1, 1, 2, 0, 2, 2, 1]                   # stream of node k
+    for k, sid in enumerate(plan):
+        fake_cuda['cur'] = FakeStream(sid)
+        tape.record(lambda k=k: ran.append((k, fake_cuda['cur'].cuda_stream)))
+    fake_cuda['cur'] = FakeStream(0)
+    fake_cuda['log'].clear()
+    tape.backward()
+    assert ran == [(k, plan[k]) for k in reversed(range(len(plan)))]
+    assert fake_cuda['cur'] == FakeStream(0)                          # home again
+    # one switch per CHANGE of stream (reverse order: 1, 2, 2, 0, 2, 1, 1, 0), then home
+    assert [s.cuda_stream for s in fake_cuda['log']] == [1, 2, 0, 2, 1, 0, 0]
+    assert tape.nodes == [] and tape.node_streams == []               # the tape is reusable
+
+
+def test_tape_restores_the_home_stream_when_a_node_raises(fake_cuda, monkeypatch):
+    monkeypatch.setattr(ops, '_impl', _NoDefer())
+    tape = E.Tape(streams=True)
+    fake_cuda['cur'] = FakeStream(3)
+    tape.record(lambda: (_ for _ in ()).throw(RuntimeError('boom')))
+    fake_cuda['cur'] = FakeStream(0)
+    with pytest.raises(RuntimeError, match='boom'):
+        tape.backward()
+    assert fake_cuda['cur'] == FakeStream(0)
+
+
+def test_a_plain_tape_never_touches_the_streams(fake_cuda, monkeypatch):
+    monkeypatch.setattr(ops, '_impl', _NoDefer())
+    tape = E.Tape()
+    ran = []
+    tape.record(lambda: ran.append(1))
+    tape.record(lambda: ran.append(2))
+    tape.backward()
+    assert ran == [2, 1] and fake_cuda['log'] == [] and tape.node_streams is None
+
+
+def test_scratch_state_is_per_registered_branch_stream_only(fake_cuda):
+    ws = ops.Workspace()
+    fake_cuda['cur'] = FakeStream(0)
+    base = ws._state()
+    assert base is ws._thread_state()                                 # nothing registered: the thread's own state, no stream lookup needed
+    ws.branch_streams_on([FakeStream(11), FakeStream(12)])
+    assert ws._state() is base                                        # torch's default stream keeps it
+    fake_cuda['cur'] = FakeStream(99)                                 # e.g. the side stream torch.cuda.graph captures on
+    assert ws._state() is base
+    fake_cuda['cur'] = FakeStream(11)
+    a = ws._state()
+    fake_cuda['cur'] = FakeStream(12)
+    b = ws._state()
+    assert a is not base and b is not base and a is not b
+    assert a['stream_obj'] == FakeStream(11) and a['bufs'] == {} and a['norm_ws_token'] == 0
+    fake_cuda['cur'] = FakeStream(11)
+    assert ws._state() is a
+    ws.bump_norm_token()
+    assert a['norm_ws_token'] == 1 and b['norm_ws_token'] == 0 and base['norm_ws_token'] == 0
+    assert sorted(s['stream_obj'].cuda_stream for s in ws.stream_states()) == [11, 12]
+
+
+def test_deferral_nesting_is_counted_per_thread(fake_cuda, monkeypatch):
+    """wgrad_defer_begin() on the main stream must switch the deferral on for the branch streams too, and the end of the OUTER pass flushes every stream"""
+    monkeypatch.setattr(ops, 'WS', ops.Workspace())
+    be = ops.HipBackend.__new__(ops.HipBackend)                       # no library needed for the book-keeping
+    flushed = []
+    monkeypatch.setattr(be, 'wgrad_flush', lambda: flushed.append(fake_cuda['cur'].cuda_stream), raising=False)
+
+    class _Ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            self.prev, fake_cuda['cur'] = fake_cuda['cur'], self.s
+
+        def __exit__(self, *a):
+            fake_cuda['cur'] = self.prev
+    monkeypatch.setattr(torch.cuda, 'stream', lambda s: _Ctx(s))
+    ops.WS.branch_streams_on([FakeStream(21), FakeStream(22)])
+    be.wgrad_defer_begin()
+    be.wgrad_defer_begin()                                            # a nested pass (a tape inside a tape node)
+    fake_cuda['cur'] = FakeStream(21)
+    assert ops.WS._thread_state()['defer_depth'] == 2                 # seen from a branch stream
+    ops.WS._state()['defer_pending'] = ['x']                          # something is pending on stream 21 only
+    fake_cuda['cur'] = FakeStream(0)
+    be.wgrad_defer_end()
+    assert flushed == []                                              # the inner end does not flush
+    be.wgrad_defer_end()
+    assert flushed == [0, 21]                                         # the main state, then every stream with pending slabs -- under THAT stream
+    assert ops.WS._thread_state()['defer_depth'] == 0
