@@ -17,6 +17,7 @@ import torch
 
 from . import engine as E
 from . import networks
+from . import ops
 from .models import _get
 
 
@@ -304,6 +305,9 @@ def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, s
         weights = _seg_weight_map(opt, seg_weights)
         if seg_only:
             seg_map = OrderedDict((k, v) for k, v in seg_map.items() if weights[v] != 0)
+    streams = _infer_streams(x.t.device)
+    if streams and opt.seg_gen and not mod_only and len(seg_map) > 1:
+        return _run_deepliif_dag_on_streams(ctx, x, nets, opt, seg_map, weights, seg_only, streams)
     gens = OrderedDict((k, nets[k].run(ctx, x)) for k in seg_map)
     names = _get(opt, 'modalities_names', [])
     if 'Marker' in names:
@@ -316,6 +320,61 @@ def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, s
     base = f'G{S}{off}'
     if weights[base] != 0:
         segs[base] = nets[base].run(ctx, x)
+    keys = list(segs.keys())
+    seg = E.weighted_sum(ctx, [segs[k] for k in keys], [float(weights[k]) for k in keys])
+    if seg_only and M > 0:
+        last = f'G{M}'
+        res = OrderedDict([(last, gens[last])] if last in gens else [])
+    else:
+        res = OrderedDict(gens)
+        res.update(segs)
+    res[f'G{S}'] = seg
+    return res
+
+
+_INFER_STREAMS = max(1, int(os.environ.get('DL_INFER_STREAMS', '1')))
+
+
+def _infer_streams(device):
+    """DL_INFER_STREAMS=N (opt-in, default 1): the independent chains G_i -> GS_i of the DeepLIIF inference DAG on N HIP streams of the calling thread
+    (the training step's branch streams, models.BaseModel._branch_streams, applied to run_dask's DAG)"""
+    if _INFER_STREAMS <= 1 or device.type != 'cuda':
+        return None
+    st = ops.WS._thread_state()
+    key = ('infer_streams', device.index)
+    if key not in st:
+        st[key] = [torch.cuda.Stream(device) for _ in range(_INFER_STREAMS)]
+        ops.WS.branch_streams_on(st[key])
+    return st[key]
+
+
+def _run_deepliif_dag_on_streams(ctx, x, nets, opt, seg_map, weights, seg_only, streams):
+    """the DeepLIIF branch of run_generators_engine with chain i (G_i(tile) -> GS_i(G_i(tile))) on stream i mod N and GS_0(tile) on the next one; the weighted
+    sum and everything after it on the calling stream, behind a join.  Same kernels on the same operands: results are bit-identical to the one-stream DAG."""
+    M = opt.modalities_no
+    S, off = _get(opt, 'mod_id_seg', 'S'), int(_get(opt, 'input_id', 0))
+    main = torch.cuda.current_stream(x.t.device)
+    for s in streams:
+        s.wait_stream(main)
+    gens, segs = OrderedDict(), OrderedDict()
+    i = -1
+    for i, (k, v) in enumerate(seg_map.items()):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            gens[k] = nets[k].run(ctx, x)
+            segs[v] = nets[v].run(ctx, gens[k])
+    names = _get(opt, 'modalities_names', [])
+    if 'Marker' in names:
+        km = f'G{names.index("Marker")}'
+        if km not in gens and km in nets:
+            with torch.cuda.stream(streams[(i + 1) % len(streams)]):
+                gens[km] = nets[km].run(ctx, x)
+            i += 1
+    base = f'G{S}{off}'
+    if weights[base] != 0:
+        with torch.cuda.stream(streams[(i + 1) % len(streams)]):
+            segs[base] = nets[base].run(ctx, x)
+    for s in streams:
+        main.wait_stream(s)
     keys = list(segs.keys())
     seg = E.weighted_sum(ctx, [segs[k] for k in keys], [float(weights[k]) for k in keys])
     if seg_only and M > 0:
