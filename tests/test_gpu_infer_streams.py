@@ -24,6 +24,7 @@ def _nets(precision, ngf=8):
 @pytest.mark.parametrize('nstreams', [2, 3, 5])
 def test_inference_dag_on_streams_is_bit_identical(nstreams, precision, monkeypatch):
     ops._impl = None
+    ops.WS._thread_state().pop(('infer_streams', 0), None)       # (a process started with DL_INFER_STREAMS set has its own list cached)
     opt, nets = _nets(precision)
     x = (torch.rand(4, 3, 256, 256, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(DEV)
     sw = [0.25, 0.15, 0.25, 0.1, 0.25]
