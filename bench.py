@@ -576,6 +576,9 @@ def main():
     out['config']['launch_mode'] = 'eager (one HIP launch per kernel from Python; see graph_replay for the captured-graph step)'
     ns = len(getattr(model, '_streams', None) or []) if model is not None else 0
     out['config']['streams'] = ns if ns else 1          # DL_STREAMS: HIP streams the independent (G_i, D_i) branches of the step are spread over (models.BaseModel._branch_streams)
+    if args.workload in ('infer', 'wsi') and not dry:
+        from deepliif_amd import inference as I_
+        out['config']['streams'] = I_._INFER_STREAMS      # DL_INFER_STREAMS (opt-in): the chains G_i -> GS_i of the inference DAG on their own streams
     if args.precision == 'bf16' and strict is not None:
         out['dtype_note'] = ('headline dtype bf16 is the throughput policy (BASELINE.json quotes the target on bf16 MFMA); it does NOT meet the 1e-3 parity bar -- '
                              'its measured distance from the strict policy is in strict_parity.headline_vs_strict; the strict policy (asserted at 1e-3 against '
