@@ -31,6 +31,9 @@ from .distributed import GradExchanger
 # (BaseModel._branch_streams).  Measured r04, same box, 5G+5D step at batch 8: 94.8 ms on one stream, 88.6 on two, 83.8 on three, 84.0 on five -- the
 # ~600 launch-latency-bound kernels of a step, every big kernel's ramp and drain and the HBM-bound norm passes overlap with another branch's MFMA work.
 _N_STREAMS = max(1, int(os.environ.get('DL_STREAMS', '3')))
+# DL_STREAMS_SEG=1 (opt-in this round): branch streams also for the model WITH segmentation generators (the reference's default configuration): chain i =
+# G_i -> GS_i on its own stream, the seg discriminators and everything that reads the summed seg image on the main stream (DeepLIIFModel.forward)
+_SEG_STREAMS = os.environ.get('DL_STREAMS_SEG', '0') == '1'
 
 
 def _get(opt, name, default):
@@ -255,13 +258,16 @@ class BaseModel:
             for s in streams:
                 s.wait_stream(main)
 
-    def _join(self):
-        """end of a phase: the main stream (optimizer step, loss read-out) waits for every branch"""
+    def _join(self, tape=None):
+        """end of a phase: the main stream (optimizer step, loss read-out) waits for every branch.  With a tape the join is a point INSIDE a recorded pass
+        (a main-stream op consumes branch results): its mirror image is recorded, so that in backward every branch waits for the main stream there."""
         streams = self._branch_streams()
         if streams:
             main = torch.cuda.current_stream()
             for s in streams:
                 main.wait_stream(s)
+            if tape is not None:
+                tape.record(self._fork)
 
     def _branch(self, i):
         """context: the kernels launched (and the tensors allocated) inside belong to the stream of branch i"""
@@ -468,7 +474,7 @@ class DeepLIIFModel(BaseModel):
             self.lambda_feat, self.criterionVGG = self._make_vgg(opt)
             # branches on several streams only where they are independent: no segmentation generators (they read the other branches' fakes), no VGG term
             # (evaluated outside the branches), none of the subclasses' extra terms
-            self.branch_parallel = type(self) is DeepLIIFModel and not self.seg_gen and self.criterionVGG is None
+            self.branch_parallel = type(self) is DeepLIIFModel and self.criterionVGG is None and (not self.seg_gen or _SEG_STREAMS)
             params_g = [p for n in self.model_names_g + self.model_names_gs for p in getattr(self, 'net' + n).parameters()]
             params_d = [p for n in self.model_names_d + self.model_names_ds for p in getattr(self, 'net' + n).parameters()]
             OptCls = networks.get_optimizer(_get(opt, 'optimizer', 'adam'))
@@ -527,11 +533,16 @@ class DeepLIIFModel(BaseModel):
             parts = []
             for i, n in enumerate(self.model_names_gs):
                 src = self._A if i == 0 else self._fake[i - 1]
-                self._mark_net(tape, getattr(self, 'net' + n))
-                s = getattr(self, 'net' + n).run(ctx, src)
-                parts.append(s)
-                setattr(self, f'fake_B_{S}_{i}', E.from_engine(s))
+                # seg generator i >= 1 reads fake_B_i: it continues the chain of G_i on THAT branch's stream; seg generator 0 (on real_A) gets the next stream
+                with self._branch(i - 1 if i > 0 else M):
+                    self._mark_net(tape, getattr(self, 'net' + n))
+                    s = getattr(self, 'net' + n).run(ctx, src)
+                    parts.append(s)
+                    setattr(self, f'fake_B_{S}_{i}', E.from_engine(s))
             self._fake_seg_parts = parts
+            # the weighted sum reads every chain's result: the main stream waits for the branches here -- and, on the way back, every branch waits for
+            # the main stream at this point of the tape before it takes its part of the seg image's gradient (the tape node below)
+            self._join(tape)
             self._fake_seg = E.weighted_sum(ctx, parts, self.seg_weights[:M + 1])
             setattr(self, f'fake_B_{S}', E.from_engine(self._fake_seg))
         self._tape_G = tape

@@ -32,7 +32,7 @@ def _run(model, batches):
         model.optimize_parameters()
         torch.cuda.synchronize()
         losses.append(dict(model.get_current_losses()))
-    return losses, _flat(model), [getattr(model, f'fake_B_{i + 1}').clone() for i in range(5)]
+    return losses, _flat(model), [getattr(model, k).clone() for k in sorted(vars(model)) if k.startswith('fake_B_') and torch.is_tensor(getattr(model, k))]
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
@@ -89,3 +89,24 @@ def test_branch_streams_under_the_gradient_exchange(monkeypatch):
         assert torch.equal(got[1], ref[1])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('nstreams', [3, 5])
+def test_seg_model_chains_on_streams_are_bit_identical(nstreams, precision, monkeypatch):
+    """DL_STREAMS_SEG=1 (opt-in): the model WITH segmentation generators -- chain i = G_i -> GS_i (+ D_i) on its own stream, GS_0 on the next one, the seg
+    discriminators and the summed seg image on the main stream; the join in front of the weighted sum is a tape node whose backward makes every branch
+    wait for the seg image's gradient.  4 G + 5 GS + 4 D + 5 DS at fixture width, BatchNorm, both policies: bit-identical to one stream."""
+    batches = _batches('train18', 2, 64, 3, 5)
+    monkeypatch.setattr(M, '_N_STREAMS', 1)
+    ref = _run(_build('train18', precision), batches)
+    monkeypatch.setattr(M, '_N_STREAMS', nstreams)
+    monkeypatch.setattr(M, '_SEG_STREAMS', True)
+    model = _build('train18', precision)
+    assert model.seg_gen and model.branch_parallel
+    got = _run(model, batches)
+    assert model._streams is not None and len(model._streams) == nstreams
+    assert got[0] == ref[0]
+    assert torch.equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        assert torch.equal(a, b)
