@@ -133,3 +133,50 @@ def test_deferral_nesting_is_counted_per_thread(fake_cuda, monkeypatch):
     be.wgrad_defer_end()
     assert flushed == [0, 21]                                         # the main state, then every stream with pending slabs -- under THAT stream
     assert ops.WS._thread_state()['defer_depth'] == 0
+
+
+class _NullStream:
+    """stands in for torch.cuda.Stream on a GPU-less machine: waits are no-ops (everything runs in program order on the CPU)"""
+    cuda_stream = -1
+
+    def wait_stream(self, other):
+        self.waited = getattr(self, 'waited', 0) + 1
+
+
+@pytest.mark.parametrize('seg_only', [False, True])
+@pytest.mark.parametrize('names', [['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], []])
+def test_inference_dag_on_streams_keeps_keys_order_and_values(seg_only, names, monkeypatch):
+    """inference._run_deepliif_dag_on_streams restructures run_dask's DAG (chain i = G_i -> GS_i) -- on the emulated backend, with stand-in streams, its result
+    dict must equal the one-stream DAG's: same keys, same ORDER (callers index by position), same values; seg_only drops the same entries."""
+    import contextlib
+    import types
+
+    import fake_backend
+    from deepliif_amd import inference as I
+    fake_backend.install()
+    try:
+        opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8, norm='batch', padding='zero',
+                                    net_g='resnet_9blocks', net_gs='unet_32', input_no=1, scale_size=32, modalities_names=names, gpu_ids=[])
+        torch.manual_seed(3)
+        nets = I.build_generators(opt, torch.device('cpu'), 'fp32')
+        x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(4)) * 2 - 1
+        sw = [0.25, 0.15, 0.25, 0.1, 0.25]
+        ref = I.run_generators(x, nets, opt, seg_only=seg_only, seg_weights=sw)
+        streams = [_NullStream() for _ in range(3)]
+        monkeypatch.setattr(I, '_infer_streams', lambda device: streams)
+        monkeypatch.setattr(torch.cuda, 'current_stream', lambda device=None: _NullStream())
+        monkeypatch.setattr(torch.cuda, 'stream', lambda s: contextlib.nullcontext())
+        got = I.run_generators(x, nets, opt, seg_only=seg_only, seg_weights=sw)
+        assert all(s.waited == 1 for s in streams)                       # forked once; the join is the main stream's wait
+        assert list(got.keys()) == list(ref.keys())
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+        # zero-weight seg branches are skipped on both routes
+        sw0 = [0.5, 0.0, 0.5, 0.0, 0.0]
+        monkeypatch.setattr(I, '_infer_streams', lambda device: None)
+        ref0 = I.run_generators(x, nets, opt, seg_only=True, seg_weights=sw0)
+        monkeypatch.setattr(I, '_infer_streams', lambda device: streams)
+        got0 = I.run_generators(x, nets, opt, seg_only=True, seg_weights=sw0)
+        assert list(got0.keys()) == list(ref0.keys()) and all(torch.equal(got0[k], ref0[k]) for k in ref0)
+    finally:
+        fake_backend.uninstall()
