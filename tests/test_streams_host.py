@@ -180,3 +180,111 @@ def test_inference_dag_on_streams_keeps_keys_order_and_values(seg_only, names, m
         assert list(got0.keys()) == list(ref0.keys()) and all(torch.equal(got0[k], ref0[k]) for k in ref0)
     finally:
         fake_backend.uninstall()
+
+
+class _LogStream:
+    """a stand-in stream that logs who waits for whom; kernels 'run' in program order on the CPU, so results cannot depend on it"""
+
+    def __init__(self, sid, log):
+        self.cuda_stream, self.log = sid, log
+
+    def wait_stream(self, other):
+        self.log.append((self.cuda_stream, 'waits', other.cuda_stream))
+
+    def __eq__(self, other):
+        return isinstance(other, _LogStream) and other.cuda_stream == self.cuda_stream
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self.cuda_stream)
+
+
+@pytest.mark.parametrize('seg_gen,modalities_no', [(False, 2), (True, 2)])
+def test_training_step_on_stand_in_streams_matches_the_plain_step(seg_gen, modalities_no, monkeypatch):
+    """A whole optimize_parameters() on the emulated backend with the branch-stream book-keeping switched on over stand-in streams: (a) losses, images and
+    parameters equal the plain step (the restructured loops compute the same thing in the same order per branch); (b) every phase forks before its first
+    branch op and joins before the optimizer step; (c) with segmentation generators the join in front of the weighted seg sum is ON THE TAPE: in backward
+    every branch waits for the main stream after the weighted sum's backward and before the seg generators' backward."""
+    import contextlib
+    import types
+
+    import fake_backend
+    from deepliif_amd import models as M
+    fake_backend.install()
+    try:
+        n = modalities_no + 1
+        opt = types.SimpleNamespace(
+            model='DeepLIIF', name='t', checkpoints_dir='/tmp/dl_amd_test', gpu_ids=[0], is_train=True, phase='train', continue_train=False, modalities_no=modalities_no,
+            seg_gen=seg_gen, modalities_names=[], input_nc=3, input_no=1, output_nc=3, ngf=8, ndf=8, net_g='resnet_9blocks', net_gs='unet_32', net_d='n_layers', n_layers_D=2,
+            norm='batch', no_dropout=True, init_type='normal', init_gain=0.02, padding='zero', upsample='convtranspose', gan_mode='vanilla', gan_mode_s='lsgan', optimizer='adam',
+            lr_g=2e-4, lr_d=2e-4, beta1=0.5, lr_policy='linear', n_epochs=100, n_epochs_decay=100, epoch_count=0, seg_weights=[1.0 / n] * n, loss_G_weights=[1.0 / n] * n,
+            loss_D_weights=[1.0 / n] * n, lambda_L1=100.0, verbose=False, epoch='latest', load_iter=0, precision='fp32')
+
+        class CpuModel(M.DeepLIIFModel):
+            def _device_from_opt(self, o):
+                return torch.device('cpu')
+
+            def _net_gpu_ids(self):
+                return []
+
+        g = torch.Generator().manual_seed(8)
+        batch = {'A': torch.rand(2, 3, 32, 32, generator=g) * 2 - 1, 'B': [torch.rand(2, 3, 32, 32, generator=g) * 2 - 1 for _ in range(n if seg_gen else modalities_no)], 'A_paths': ['x']}
+
+        def run(with_streams):
+            torch.manual_seed(0)
+            model = CpuModel(opt)
+            model.setup(opt)
+            log = []
+            if with_streams:
+                main = _LogStream(0, log)
+                model._streams = [_LogStream(10 + k, log) for k in range(3)]
+                model.branch_parallel = True
+                state = {'cur': main}
+                monkeypatch.setattr(torch.cuda, 'current_stream', lambda device=None: state['cur'])
+                monkeypatch.setattr(torch.cuda, 'set_stream', lambda s: state.__setitem__('cur', s))
+
+                @contextlib.contextmanager
+                def on(s):
+                    prev, state['cur'] = state['cur'], s
+                    try:
+                        yield
+                    finally:
+                        state['cur'] = prev
+                monkeypatch.setattr(torch.cuda, 'stream', on)
+                orig_ws = M.E.weighted_sum
+
+                def ws(ctx, parts, weights):
+                    log.append(('weighted_sum', 'on', state['cur'].cuda_stream))
+                    out = orig_ws(ctx, parts, weights)
+                    if ctx.tape is not None:
+                        ctx.tape.record(lambda: log.append(('weighted_sum backward', 'on', state['cur'].cuda_stream)))
+                    return out
+                monkeypatch.setattr(M.E, 'weighted_sum', ws)
+            else:
+                model._streams = None
+            for _ in range(2):
+                model.set_input(batch)
+                model.optimize_parameters()
+            return dict(model.get_current_losses()), torch.cat([o.flat.data.clone() for o in model.optimizers]), model.fake_B_1.clone(), log
+
+        ref = run(False)
+        got = run(True)
+        assert got[0] == ref[0] and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        log = got[3]
+        forks = [k for k, e in enumerate(log) if e == (10, 'waits', 0)]
+        joins = [k for k, e in enumerate(log) if e == (0, 'waits', 10)]
+        assert len(forks) >= 6 and len(joins) >= 4                     # forward + backward_D + backward_G, two steps
+        if seg_gen:
+            join3 = [(0, 'waits', 10), (0, 'waits', 11), (0, 'waits', 12)]
+            fork3 = [(10, 'waits', 0), (11, 'waits', 0), (12, 'waits', 0)]
+            # forward (once per step): the main stream joins the branches right before the weighted seg sum, which runs on the main stream
+            fwd = [k for k, e in enumerate(log) if e == ('weighted_sum', 'on', 0) and log[k - 3:k] == join3]
+            assert len(fwd) == 2, fwd
+            # backward of the generator tape (once per step): the weighted sum's backward on the main stream, THEN every branch waits for the main stream
+            bwd = [k for k, e in enumerate(log) if e == ('weighted_sum backward', 'on', 0) and log[k + 1:k + 4] == fork3]
+            assert len(bwd) == 2, bwd
+            assert fwd[0] < bwd[0] < fwd[1] < bwd[1]
+    finally:
+        fake_backend.uninstall()
