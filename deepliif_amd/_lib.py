@@ -15,6 +15,8 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1, LOSS_LINEAR = 0, 1, 2, 3, 4
 MAX_TAPS, MAX_PHASES = 64, 4
+WGRAD_MULTI_MAX = 24
+DL_VERSION = 112
 
 i32 = C.c_int32
 
@@ -83,6 +85,8 @@ SIGNATURES = {
     'dl_wgrad_slab_floats': (C.c_size_t, [C.POINTER(WgradDesc)]),
     'dl_conv_wgrad_slabs': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, C.POINTER(WgradReduceEntry), _vp]),
     'dl_wgrad_reduce_batch': (_i, [_vp, _i, _i, _vp]),
+    'dl_wgrad_plan': (_i, [C.POINTER(WgradDesc), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_char_p)]),
+    'dl_conv_wgrad_multi': (_i, [C.POINTER(WgradDesc), _i, _vp, _vp, _vp, _vp, C.POINTER(WgradReduceEntry), _vp]),
     'dl_pack_weights': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
     'dl_pack_job_bytes': (C.c_size_t, []),
     'dl_pack_job_fill': (_i, [C.POINTER(PackDesc), _vp, _vp, _vp, _vp]),
@@ -148,8 +152,8 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dl_version() != 111:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != 111 (stale build)')
+    if lib.dl_version() != DL_VERSION:
+        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != {DL_VERSION} (stale build)')
     _lib = lib
     return lib
 

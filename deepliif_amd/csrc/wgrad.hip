@@ -29,6 +29,17 @@ struct WgradArgs {
     int p_act, q_act;
     int xcd_group;      // 1: tiles of one pixel range share an XCD (see the kernels)
     int p_split, q_split;   // strict kernels (wgrad_x3.h): the operand is the producer-written split copy
+    int tr_asm;             // 1 (default): transposing LDS reads as inline assembly (no hidden vmcnt(0), see tr_fragment_swz_asm); DL_WGRAD_TR_ASM=0: the builtin (A/B)
+};
+
+// Operands of a BATCH of same-shaped layers (dl_conv_wgrad_multi): the direct-to-LDS kernels take the layer from blockIdx.z (wgrad_w4_kernel: from its
+// flattened grid) and its pointers from this table, which travels in the kernel-argument segment (no device table to build or to keep alive).
+// A single-layer launch fills entry 0.
+constexpr int WGRAD_MULTI_MAX = DL_WGRAD_MULTI_MAX;
+struct WgradLayers {
+    const void *P[WGRAD_MULTI_MAX];
+    const void *Q[WGRAD_MULTI_MAX];
+    float *slab[WGRAD_MULTI_MAX];
 };
 
 __device__ __forceinline__ int reflect_idx_w(int i, int n) {
@@ -281,8 +292,36 @@ __device__ __forceinline__ bf16x8_t tr_fragment_swz(const bf16_t *tile, int prow
     return r;
 }
 
-template <int BA, int WA, int WJ>
-__global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
+// The same fragment fetch as INLINE ASSEMBLY (round 5).  Behind the builtin, hipcc's waitcnt pass puts an s_waitcnt vmcnt(0) in front of every transposing
+// read that follows an LDS-DMA instruction (the builtin's memory operand carries no alias information, so the read "may touch" what the DMA is writing;
+// plain ds_read_b128 loads are not treated this way).  In wgrad_glds_kernel / wgrad_glds_x3_kernel the DMA of tile t+1 is issued in front of the reads of
+// tile t: every K step therefore WAITED for the next tile's DMA before it multiplied the current one -- the prefetch never overlapped anything, and the
+// K step cost DMA latency + MFMA time (ResnetBlock shape: 142 us for 75 us of matrix work; rounds 2-4 read this as "bound by the global->LDS path").
+// The compiler does not count these reads in lgkmcnt: the caller waits explicitly (tr_wait*, tied to the fragment registers so that the MFMAs stay
+// behind the wait).  The "memory" clobber keeps the reads ordered against the barriers and the in-place conversion stores of the strict kernel.
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_fragment_swz_asm(const bf16_t *tile, int prow0, int slot, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const int x = (m >> 2) | ((g & 1) << 2);
+    const char *base = reinterpret_cast<const char *>(tile) + (prow0 + 8 * g + (m >> 2)) * ROWB + ((slot ^ x) << 5) + (m & 3) * 8;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)base;
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * ROWB) : "memory");
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ void tr_wait4(bf16x8_t (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+}
+__device__ __forceinline__ void tr_wait8(bf16x8_t (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory");
+}
+
+template <int BA, int WA, int WJ, bool TRASM>
+__global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a, const WgradLayers lay) {
     constexpr int BJ = 256, BP = 64, NW = 8;
     constexpr int PA = BA / WA, PJ = BJ / WJ, FA = PA / 16, FJ = PJ / 16;
     constexpr int ROWA = BA * 2, ROWJ = BJ * 2;             // row bytes
@@ -299,23 +338,27 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
     const int wa = wave % WA, wj = wave / WA;
     // All (tap, channel) tiles of ONE pixel range read the same P / Q pixels: keep them on one XCD (shared L2) by remapping the
     // flattened workgroup id (hardware deals consecutive ids round-robin over the 8 XCDs); a.xcd_group = 0 keeps the 2-D order.
-    int bid, ks;
+    int bid, ks, layer;
     if (a.xcd_group) {
         const int ntile = gridDim.x;
-        const int logical = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
-        ks = logical / ntile;
-        bid = logical - ks * ntile;
+        const int logical = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * ntile + blockIdx.x, ntile * gridDim.y * gridDim.z);
+        const int grp = logical / ntile;
+        bid = logical - grp * ntile;
+        layer = grp / gridDim.y;
+        ks = grp - layer * gridDim.y;
     } else {
         bid = xcd_remap(blockIdx.x, gridDim.x);
         ks = blockIdx.y;
+        layer = blockIdx.z;
     }
     const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
     const int p_begin = ks * a.pchunk;
     const int p_end = min(a.Ptot, p_begin + a.pchunk);
     const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
 
-    const bf16_t *P = reinterpret_cast<const bf16_t *>(a.P);
-    const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.Q);
+    const bf16_t *P = reinterpret_cast<const bf16_t *>(lay.P[layer]);
+    const bf16_t *Q = reinterpret_cast<const bf16_t *>(lay.Q[layer]);
+    float *slab = lay.slab[layer];
     const bf16_t *zero = reinterpret_cast<const bf16_t *>(g_wzero_page);
 
     // ---- P lanes: instruction i of this wave fills tile rows (wave*A_INS + i)*A_RPI + lane*16/ROWA
@@ -395,10 +438,20 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
 #pragma unroll
         for (int ss = 0; ss < BP / 32; ++ss) {
             bf16x8_t af[FA], bf[FJ];
+            static_assert(FJ == 4 && (FA == 8 || FA == 4), "fragment counts of the explicit waits");
+            if constexpr (TRASM) {
 #pragma unroll
-            for (int i = 0; i < FA; ++i) af[i] = tr_fragment_swz<ROWA>(Ps, ss * 32, (wa * PA) / 16 + i, lane);
+                for (int i = 0; i < FA; ++i) af[i] = tr_fragment_swz_asm<ROWA>(Ps, ss * 32, (wa * PA) / 16 + i, lane);
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) bf[j] = tr_fragment_swz<ROWJ>(Qs, ss * 32, (wj * PJ) / 16 + j, lane);
+                for (int j = 0; j < FJ; ++j) bf[j] = tr_fragment_swz_asm<ROWJ>(Qs, ss * 32, (wj * PJ) / 16 + j, lane);
+                if constexpr (FA == 8) tr_wait8(af); else tr_wait4(*reinterpret_cast<bf16x8_t (*)[4]>(&af[0]));
+                tr_wait4(bf);
+            } else {
+#pragma unroll
+                for (int i = 0; i < FA; ++i) af[i] = tr_fragment_swz<ROWA>(Ps, ss * 32, (wa * PA) / 16 + i, lane);
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) bf[j] = tr_fragment_swz<ROWJ>(Qs, ss * 32, (wj * PJ) / 16 + j, lane);
+            }
 #pragma unroll
             for (int i = 0; i < FA; ++i)
 #pragma unroll
@@ -417,7 +470,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -649,24 +702,29 @@ static int launch_wgrad_8ph(WgradArgs a, hipStream_t stream) {
     return 0;
 }
 
-template <int BA, int WA, int WJ>
-static int launch_wgrad_glds(WgradArgs a, hipStream_t stream) {
+template <int BA, int WA, int WJ, bool TRASM>
+static int launch_wgrad_glds_v(WgradArgs a, const WgradLayers &lay, int n, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 64 * (BA + 256) * sizeof(bf16_t);
     a.tiles_a = a.CAp / BA;
     a.tiles_j = (a.J + 255) / 256;
     a.pchunk = ((a.Ptot + a.splitk - 1) / a.splitk + 63) / 64 * 64;
     const int hw = a.Hp * a.Wp;
     a.dn = 64 / hw; a.dh = (64 % hw) / a.Wp; a.dw = (64 % hw) % a.Wp;
-    auto kern = wgrad_glds_kernel<BA, WA, WJ>;
+    auto kern = wgrad_glds_kernel<BA, WA, WJ, TRASM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) DL_FAIL("dl_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk, n), dim3(512), smem, stream, a, lay);
     DL_CHECK_LAUNCH("dl_conv_wgrad(glds)");
     return 0;
+}
+
+template <int BA, int WA, int WJ>
+static int launch_wgrad_glds(const WgradArgs &a, const WgradLayers &lay, int n, hipStream_t stream) {
+    return a.tr_asm ? launch_wgrad_glds_v<BA, WA, WJ, true>(a, lay, n, stream) : launch_wgrad_glds_v<BA, WA, WJ, false>(a, lay, n, stream);
 }
 
 // grad[a][b][t] (+)= sum_ks slab[ks][a][t*CBp + b].  Threads walk the slab in its own (contiguous) order so the reads
@@ -745,6 +803,7 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 
 #include "wgrad_c4.h"
 #include "wgrad_x3.h"
+#include "wgrad_w4.h"
 
 // The slabs of consecutive pixel ranges lie CAp * J + PAD floats apart.  Without a pad the distance is a multiple of a large power of two for every
 // layer of these nets (ResnetBlock: 256 x 2304 floats = 9 x 2^18 bytes): all 28 partials of one gradient element -- written at the same moment by 28
@@ -761,12 +820,54 @@ extern "C" size_t dl_wgrad_slab_floats(const dl_wgrad_desc *d) {
     return (size_t)d->splitk * ((size_t)d->CAp * d->KH * d->KW * d->CBp + wgrad_slab_pad());
 }
 
-// the split-K kernel of the general path: slabs only (the reduction is the caller's: immediate or deferred)
-static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *slab, hipStream_t stream, int *J_out) {
+// Which kernel of the general path serves a descriptor (one decision for dl_conv_wgrad, dl_conv_wgrad_multi and dl_wgrad_plan)
+enum WgradKernel { WK_GENERIC = 0, WK_GLDS256, WK_GLDS128, WK_X3_256, WK_X3_128, WK_8PH, WK_4PH_X3, WK_4PH_X3_NOPRIO, WK_W4 };
+
+static int wgrad_kernel_of(const dl_wgrad_desc *d, int *err) {
+    *err = 0;
+    const int J = d->KH * d->KW * d->CBp;
+    const long Ptot = (long)d->N * d->Hp * d->Wp;
+    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    const bool fast = d->dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->p_act == DL_ACT_NONE && d->q_act == DL_ACT_NONE &&
+                      d->pad_mode == DL_PAD_ZERO && J >= 256 && Ptot >= 64L * d->splitk && !no_glds;
+    // "1": the four-phase schedule (wgrad_8ph_kernel).  OFF by default -- measured r02, same box, ResnetBlock shape, kernel + reduce:
+    // 217-225 us vs 191-193 us for the one-barrier kernel in all three variants tried (reads retired before the first barrier; restage
+    // two phases later without forced waits; address arithmetic moved into the MFMA shadow).  The one-barrier kernel alone is 172 us,
+    // within 8 % of the forward's 8-phase kernel (155-160 us), so there was little left to win here.
+    static const char *w8 = getenv("DL_WGRAD_8PH");
+    // strict policy on the direct-to-LDS path (wgrad_x3.h); DL_NO_X3_GLDS=1: the round-1 register-staged kernel (A/B)
+    static const bool no_x3 = getenv("DL_NO_X3_GLDS") != nullptr;
+    const bool act_ok3 = (d->p_act == DL_ACT_NONE || d->p_act == DL_ACT_RELU || d->p_act == DL_ACT_LRELU) &&
+                         (d->q_act == DL_ACT_NONE || d->q_act == DL_ACT_RELU || d->q_act == DL_ACT_LRELU);
+    const bool fast3 = d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && act_ok3 && d->pad_mode == DL_PAD_ZERO && J >= 256 &&
+                       Ptot >= 32L * d->splitk && (d->p_pstride % 4) == 0 && (d->q_pstride % 4) == 0 && !no_x3;
+    // DL_WGRAD_X3 = "2": the staggered two-phase schedule (wgrad_4ph_x3_kernel), "3": the same without s_setprio.  OFF by default -- measured r03,
+    // same box, ResnetBlock shape, kernel + reduce: 627 us (604 without s_setprio) vs 577 us for the one-barrier kernel; PMC: the stagger
+    // raises the time waves spend parked at barriers / waitcnt (43 % vs 28 % of wave cycles) more than it overlaps (MFMA-busy 31.6 % vs 35.6 %).
+    static const char *w3 = getenv("DL_WGRAD_X3");
+    if ((d->p_split || d->q_split) && !(fast3 && (d->CAp % 128) == 0 && (!d->p_split || d->p_act == DL_ACT_NONE) && (!d->q_split || d->q_act == DL_ACT_NONE))) {
+        *err = 1;
+        return WK_GENERIC;
+    }
+    if (w4w_eligible(d)) return WK_W4;
+    if (fast3 && (d->CAp % 256) == 0 && w3 && (w3[0] == '2' || w3[0] == '3') && !d->p_split && !d->q_split) return w3[0] == '3' ? WK_4PH_X3_NOPRIO : WK_4PH_X3;
+    if (fast3 && (d->CAp % 256) == 0) return WK_X3_256;
+    if (fast3 && (d->CAp % 128) == 0) return WK_X3_128;
+    if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') return WK_8PH;
+    if (fast && (d->CAp % 256) == 0) return WK_GLDS256;
+    if (fast && (d->CAp % 128) == 0) return WK_GLDS128;
+    return WK_GENERIC;
+}
+
+// the split-K kernel of the general path for n same-shaped layers (n > 1: the direct-to-LDS kernels only): slabs only (the reduction is the
+// caller's: immediate or deferred)
+static int wgrad_slabs(const dl_wgrad_desc *d, const WgradLayers &lay, int n, hipStream_t stream, int *J_out) {
     if (!d) DL_FAIL("dl_conv_wgrad: null descriptor");
     if (d->N <= 0 || d->Hp <= 0 || d->Wp <= 0 || d->Hq <= 0 || d->Wq <= 0)
         DL_FAIL("dl_conv_wgrad: empty problem (N=%d, P %dx%d, Q %dx%d): nothing to launch", d->N, d->Hp, d->Wp, d->Hq, d->Wq);
-    if (!P || !Q || !slab) DL_FAIL("dl_conv_wgrad: null argument");
+    if (n < 1 || n > WGRAD_MULTI_MAX) DL_FAIL("dl_conv_wgrad: %d layers in one launch (1 .. %d)", n, WGRAD_MULTI_MAX);
+    for (int l = 0; l < n; ++l)
+        if (!lay.P[l] || !lay.Q[l] || !lay.slab[l]) DL_FAIL("dl_conv_wgrad: null argument");
     const int l2 = ilog2_exact(d->CBp);
     if (l2 < 3) DL_FAIL("dl_conv_wgrad: CBp=%d must be a power of two >= 8", d->CBp);
     if (d->CAp % 8) DL_FAIL("dl_conv_wgrad: CAp=%d must be a multiple of 8", d->CAp);
@@ -777,7 +878,7 @@ static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, flo
 
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.P = P; a.Q = Q; a.slab = slab;
+    a.P = lay.P[0]; a.Q = lay.Q[0]; a.slab = lay.slab[0];
     a.N = d->N; a.Hp = d->Hp; a.Wp = d->Wp; a.CAp = d->CAp; a.p_pstride = d->p_pstride;
     a.Hq = d->Hq; a.Wq = d->Wq; a.CBp = d->CBp; a.log2CB = l2; a.q_pstride = d->q_pstride;
     a.KH = d->KH; a.KW = d->KW; a.step = d->step; a.pad = d->pad; a.pad_w = d->pad_w < 0 ? d->pad : d->pad_w; a.pad_mode = d->pad_mode;
@@ -790,42 +891,76 @@ static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, flo
     a.dn = 32 / hw; a.dh = (32 % hw) / d->Wp; a.dw = (32 % hw) % d->Wp;
     a.p_act = d->p_act; a.q_act = d->q_act;
     a.p_split = d->p_split; a.q_split = d->q_split;
+    static const char *tr_env = getenv("DL_WGRAD_TR_ASM");            // A/B switch: "0" = the transposing reads through the builtin (rounds 2-4)
+    a.tr_asm = (tr_env && tr_env[0] == '0') ? 0 : 1;
     static const char *xg_env = getenv("DL_WGRAD_XCDGROUP");          // A/B switch: "0" keeps the plain 2-D block order
     a.xcd_group = (xg_env && xg_env[0] == '0') ? 0 : 1;
 
-    int rc;
-    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
-    const bool fast = d->dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->p_act == DL_ACT_NONE && d->q_act == DL_ACT_NONE &&
-                      d->pad_mode == DL_PAD_ZERO && a.J >= 256 && a.Ptot >= 64 * d->splitk && !no_glds;
-    // "1": the four-phase schedule (wgrad_8ph_kernel).  OFF by default -- measured r02, same box, ResnetBlock shape, kernel + reduce:
-    // 217-225 us vs 191-193 us for the one-barrier kernel in all three variants tried (reads retired before the first barrier; restage
-    // two phases later without forced waits; address arithmetic moved into the MFMA shadow).  The one-barrier kernel alone is 172 us,
-    // within 8 % of the forward's 8-phase kernel (155-160 us), so there was little left to win here.
-    static const char *w8 = getenv("DL_WGRAD_8PH");
-    // strict policy on the direct-to-LDS path (wgrad_x3.h); DL_NO_X3_GLDS=1: the round-1 register-staged kernel (A/B)
-    static const bool no_x3 = getenv("DL_NO_X3_GLDS") != nullptr;
-    const bool act_ok3 = (d->p_act == DL_ACT_NONE || d->p_act == DL_ACT_RELU || d->p_act == DL_ACT_LRELU) &&
-                         (d->q_act == DL_ACT_NONE || d->q_act == DL_ACT_RELU || d->q_act == DL_ACT_LRELU);
-    const bool fast3 = d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && act_ok3 && d->pad_mode == DL_PAD_ZERO && a.J >= 256 &&
-                       a.Ptot >= 32 * d->splitk && (d->p_pstride % 4) == 0 && (d->q_pstride % 4) == 0 && !no_x3;
-    // DL_WGRAD_X3 = "2": the staggered two-phase schedule (wgrad_4ph_x3_kernel), "3": the same without s_setprio.  OFF by default -- measured r03,
-    // same box, ResnetBlock shape, kernel + reduce: 627 us (604 without s_setprio) vs 577 us for the one-barrier kernel; PMC: the stagger
-    // raises the time waves spend parked at barriers / waitcnt (43 % vs 28 % of wave cycles) more than it overlaps (MFMA-busy 31.6 % vs 35.6 %).
-    static const char *w3 = getenv("DL_WGRAD_X3");
-    if ((d->p_split || d->q_split) && !(fast3 && (d->CAp % 128) == 0 && (!d->p_split || d->p_act == DL_ACT_NONE) && (!d->q_split || d->q_act == DL_ACT_NONE)))
+    int err = 0;
+    const int k = wgrad_kernel_of(d, &err);
+    if (err)
         DL_FAIL("dl_conv_wgrad: split-copy operands need the strict direct-to-LDS kernel (fp32 + BF16X3, zero padding, CAp %% 128 == 0, J >= 256) and no staged activation on them");
-    if (fast3 && (d->CAp % 256) == 0 && w3 && (w3[0] == '2' || w3[0] == '3') && !d->p_split && !d->q_split) rc = (w3[0] == '3') ? launch_wgrad_4ph_x3<1>(a, stream) : launch_wgrad_4ph_x3<0>(a, stream);
-    else if (fast3 && (d->CAp % 256) == 0) rc = launch_wgrad_glds_x3<256>(a, stream);
-    else if (fast3 && (d->CAp % 128) == 0) rc = launch_wgrad_glds_x3<128>(a, stream);
-    else if (fast && (d->CAp % 256) == 0 && w8 && w8[0] == '1') rc = launch_wgrad_8ph(a, stream);
-    else if (fast && (d->CAp % 256) == 0) rc = launch_wgrad_glds<256, 2, 4>(a, stream);
-    else if (fast && (d->CAp % 128) == 0) rc = launch_wgrad_glds<128, 2, 4>(a, stream);
-    else if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
-    else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
-    else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<float, 1>(a, stream);
-    else DL_FAIL("dl_conv_wgrad: unsupported dtype/precision combination");
+    if (n > 1 && !(k == WK_W4 || k == WK_GLDS256 || k == WK_GLDS128 || k == WK_X3_256 || k == WK_X3_128))
+        DL_FAIL("dl_conv_wgrad_multi: this descriptor takes a kernel without a batched form (ask dl_wgrad_plan first)");
+    int rc;
+    switch (k) {
+        case WK_W4: rc = launch_wgrad_w4(d, lay, n, a.kstride, stream); break;
+        case WK_4PH_X3: rc = launch_wgrad_4ph_x3<0>(a, stream); break;
+        case WK_4PH_X3_NOPRIO: rc = launch_wgrad_4ph_x3<1>(a, stream); break;
+        case WK_X3_256: rc = launch_wgrad_glds_x3<256>(a, lay, n, stream); break;
+        case WK_X3_128: rc = launch_wgrad_glds_x3<128>(a, lay, n, stream); break;
+        case WK_8PH: rc = launch_wgrad_8ph(a, stream); break;
+        case WK_GLDS256: rc = launch_wgrad_glds<256, 2, 4>(a, lay, n, stream); break;
+        case WK_GLDS128: rc = launch_wgrad_glds<128, 2, 4>(a, lay, n, stream); break;
+        default:
+            if (d->dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<bf16_t, 1>(a, stream);
+            else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = dispatch_wgrad<float, 3>(a, stream);
+            else if (d->dtype == DL_F32 && d->prec == DL_PREC_BF16) rc = dispatch_wgrad<float, 1>(a, stream);
+            else DL_FAIL("dl_conv_wgrad: unsupported dtype/precision combination");
+    }
     *J_out = a.J;
     return rc;
+}
+
+static int wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *slab, hipStream_t stream, int *J_out) {
+    if (!P || !Q || !slab) DL_FAIL("dl_conv_wgrad: null argument");
+    WgradLayers lay;
+    lay.P[0] = P; lay.Q[0] = Q; lay.slab[0] = slab;
+    return wgrad_slabs(d, lay, 1, stream, J_out);
+}
+
+// What dl_conv_wgrad / dl_conv_wgrad_multi would run for `d` (d->splitk is ignored except where a kernel's eligibility depends on it: pass 1):
+// the kernel class, its output tiles per layer and the K steps one tile runs with split-K 1 -- what a caller needs to size split-K for one
+// layer or for a batch.  Returns 1 when the kernel has a batched form (dl_conv_wgrad_multi), 0 when not, < 0 on error.
+extern "C" int dl_wgrad_plan(const dl_wgrad_desc *d, int32_t *tiles, int32_t *ksteps, const char **name) {
+    if (!d) DL_FAIL("dl_wgrad_plan: null descriptor");
+    if (wgrad_c4_form(d) || wgrad_c4_x3_form(d)) {
+        if (tiles) *tiles = 0;
+        if (ksteps) *ksteps = 0;
+        if (name) *name = "wgrad_c4";
+        return 0;
+    }
+    int err = 0;
+    const int k = wgrad_kernel_of(d, &err);
+    const int J = d->KH * d->KW * d->CBp;
+    const long Ptot = (long)d->N * d->Hp * d->Wp;
+    int t = 0, ks = 0, multi = 0;
+    const char *nm = "wgrad_kernel";
+    switch (k) {
+        case WK_W4: t = (d->CAp / 128) * (d->CBp / 128) * 3; ks = d->N * d->Hp; multi = 1; nm = "wgrad_w4_kernel"; break;
+        case WK_X3_256: case WK_4PH_X3: case WK_4PH_X3_NOPRIO: t = (d->CAp / 256) * ((J + 255) / 256); ks = (int)((Ptot + 31) / 32); multi = k == WK_X3_256; nm = "wgrad_glds_x3_kernel<256>"; break;
+        case WK_X3_128: t = (d->CAp / 128) * ((J + 255) / 256); ks = (int)((Ptot + 31) / 32); multi = 1; nm = "wgrad_glds_x3_kernel<128>"; break;
+        case WK_GLDS256: case WK_8PH: t = (d->CAp / 256) * ((J + 255) / 256); ks = (int)((Ptot + 63) / 64); multi = k == WK_GLDS256; nm = "wgrad_glds_kernel<256>"; break;
+        case WK_GLDS128: t = (d->CAp / 128) * ((J + 255) / 256); ks = (int)((Ptot + 63) / 64); multi = 1; nm = "wgrad_glds_kernel<128>"; break;
+        default: {
+            const int ba = d->CAp <= 16 ? 16 : (d->CAp <= 32 ? 32 : (d->CAp <= 64 ? 64 : 128));
+            t = ((d->CAp + ba - 1) / ba) * ((J + 127) / 128); ks = (int)((Ptot + 31) / 32);
+        }
+    }
+    if (tiles) *tiles = t;
+    if (ksteps) *ksteps = ks;
+    if (name) *name = nm;
+    return err ? -1 : multi;
 }
 
 static int reduce_blocks(const dl_wgrad_desc *d, int J) {
@@ -867,6 +1002,34 @@ extern "C" int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const 
     e.accumulate = d->accumulate; e.stack_kw = d->stack_kw;
     e.block0 = 0; e.nblocks = reduce_blocks(d, J); e.kstride = d->CAp * J + wgrad_slab_pad();
     *entry_host = e;
+    return 0;
+}
+
+// n same-shaped layers (one descriptor, d->splitk row / pixel ranges each) in ONE split-K launch; the slabs of layer l start at
+// slab + l * dl_wgrad_slab_floats(d); entries_host[l] = its pending reduction (as dl_conv_wgrad_slabs)
+extern "C" int dl_conv_wgrad_multi(const dl_wgrad_desc *d, int n, const void *const *P, const void *const *Q, float *const *grad, float *slab,
+                                   dl_wgrad_reduce_entry *entries_host, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !P || !Q || !grad || !slab || !entries_host) DL_FAIL("dl_conv_wgrad_multi: null argument");
+    if (n < 1 || n > WGRAD_MULTI_MAX) DL_FAIL("dl_conv_wgrad_multi: n=%d (1 .. %d)", n, WGRAD_MULTI_MAX);
+    if (!dl_conv_wgrad_deferrable(d)) DL_FAIL("dl_conv_wgrad_multi: the persistent narrow-channel kernels reduce in place; call dl_conv_wgrad");
+    const size_t per_layer = dl_wgrad_slab_floats(d);
+    WgradLayers lay;
+    for (int l = 0; l < n; ++l) {
+        if (!grad[l]) DL_FAIL("dl_conv_wgrad_multi: null gradient");
+        lay.P[l] = P[l]; lay.Q[l] = Q[l]; lay.slab[l] = slab + (size_t)l * per_layer;
+    }
+    int J = 0;
+    if (const int rc = wgrad_slabs(d, lay, n, stream, &J)) return rc;
+    for (int l = 0; l < n; ++l) {
+        dl_wgrad_reduce_entry e;
+        memset(&e, 0, sizeof(e));
+        e.slab = lay.slab[l]; e.grad = grad[l];
+        e.splitk = d->splitk; e.CAp = d->CAp; e.CBp = d->CBp; e.J = J; e.CA = d->CA; e.CB = d->CB; e.KK = d->KH * d->KW;
+        e.accumulate = d->accumulate; e.stack_kw = d->stack_kw;
+        e.block0 = 0; e.nblocks = reduce_blocks(d, J); e.kstride = d->CAp * J + wgrad_slab_pad();
+        entries_host[l] = e;
+    }
     return 0;
 }
 

@@ -1,0 +1,262 @@
+// wgrad_w4.h -- included by wgrad.hip.  Weight gradient of the ResnetBlock conv (networks.py:467-513: 3x3, stride 1, zero padding 1, image rows of
+// exactly 128 pixels, both channel counts multiples of 128, bf16) on a one-wave-per-SIMD tile, for ONE layer or for a BATCH of same-shaped layers
+// in one launch (dl_conv_wgrad_multi).  VERDICT r4 #1 / #3: the 256 x 256 x 64 tile of wgrad_glds_kernel stages 1 KB per pixel for 131 kflop
+// (128 flop/B through the global->LDS path that bounds every big-tile kernel here at ~18 B/clk/CU), fills the chip with 9 tiles x split-K 28 and
+// so writes 28 fp32 partial copies of the gradient (66 MB for a 2.4 MB result) that a second kernel reads back.
+//
+// Tile: 128 dL/dy channels (ca) x [3 kernel columns kw] x 128 input channels (cb) of ONE kernel row kh -- 12 tiles for 256 -> 256.  A K step is
+// one image row: the workgroup stages the dy row (128 px x 128 ch, 32 KB) and the x row h + kh - 1 (32 KB) ONCE and the three kw taps read the
+// x row at pixel offsets -1 / 0 / +1 (LDS rows 0 and 129 of the x buffer are zero: the padding columns; image rows above / below the tensor are
+// not staged at all -- the step is skipped): 512 B per pixel for 98 kflop = 192 flop/B (+50 %), the x tile resident across the kernel row.
+// Four waves; wave w owns input channels 32 w .. 32 w + 31 for all three kw and all four 32-channel blocks of ca: 12 accumulators of
+// v_mfma_f32_32x32x16_bf16 (192 registers), 7 fragments (4 dy + 3 x) per 16-pixel sub-step for 12 MFMAs.  Both operands are pixel-major in memory and
+// the contraction index IS the pixel, so the fragments come from ds_read_b64_tr_b16 (two per fragment; 64-byte channel groups of a 256-byte LDS
+// row XOR-swizzled by (row & 3): the four pixel rows a half-wave touches fall into different bank groups; the permutation is applied on the
+// SOURCE side of the DMA, whose LDS image is lane-linear).  buffer_load ... lds for both operands (resource in SGPRs, lane-constant voffset,
+// per-piece scalar offset).  Two LDS buffers per operand (129 KB): row t+1 lands while row t is multiplied; one barrier per row; the last
+// sub-step's MFMAs run behind the barrier and cover the first fragment reads of the next row (conv_w4.hip's pipeline).
+// Grid: (layer, pixel-row range ks, tile) flattened, XCD-remapped so that the 12 tiles of one (layer, ks) share an L2: dy / x rows leave HBM once.
+// Slabs: slab[ks][ca][(kh*3 + kw) * CBp + cb] as every other kernel here -> wgrad_reduce_kernel / wgrad_reduce_batch_kernel unchanged (fixed order).
+#pragma once
+
+typedef __attribute__((ext_vector_type(16))) float w4w_f32x16_t;
+typedef __attribute__((address_space(3))) char w4w_lds_t;
+typedef __attribute__((address_space(3))) s16x4_t w4w_lds_s16x4_t;
+
+struct WgradW4Args {
+    int NH, H;                   // image rows in total (N * Hp), image rows per image
+    int CBp, J, kstride;         // J = 9 * CBp; kstride = floats between the slabs of consecutive row ranges
+    int p_pstride, q_pstride;    // elements between pixels
+    int splitk, rps;             // row ranges per layer, rows per range
+    int tiles_a, tiles_b;        // CAp / 128, CBp / 128
+};
+
+template <int V> struct W4WIC { static constexpr int value = V; };
+
+constexpr int W4W_DY = 128 * 256;                    // bytes of a dy buffer
+constexpr int W4W_X = 130 * 256;                     // bytes of an x buffer (pixel rows -1 .. 128)
+constexpr int W4W_X0 = 2 * W4W_DY;
+constexpr size_t W4W_LDS = (size_t)2 * W4W_DY + 2 * W4W_X;
+static_assert(W4W_LDS <= 160 * 1024, "LDS of a CU");
+
+__global__ void __launch_bounds__(256) wgrad_w4_kernel(const WgradW4Args a, const WgradLayers lay) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    w4w_lds_t *lds = (w4w_lds_t *)smem_raw;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = a.tiles_a * a.tiles_b * 3;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = logical % ntile, grp = logical / ntile;
+    const int ks = grp % a.splitk, layer = grp / a.splitk;
+    const int kh = tile % 3, tb = (tile / 3) % a.tiles_b, ta = tile / (3 * a.tiles_b);
+    const int dh = kh - 1;
+
+    const char *Pg = reinterpret_cast<const char *>(lay.P[layer]) + ta * 256;
+    const char *Qg = reinterpret_cast<const char *>(lay.Q[layer]) + tb * 256;
+    float *slab = lay.slab[layer] + (size_t)ks * a.kstride;
+
+    const int r_begin = ks * a.rps, r_end = min(a.NH, r_begin + a.rps);
+    // smallest row >= r of this range whose x row h + dh lies inside its image (-1: none).  H >= 2: never two invalid rows in a row
+    auto next_valid = [&](int r) __attribute__((always_inline)) {
+        if (r < r_end) {
+            const int h = r % a.H;
+            if ((unsigned)(h + dh) >= (unsigned)a.H) ++r;
+        }
+        return r < r_end ? r : -1;
+    };
+
+    // ---- staging.  Piece j (0..7) of wave w fills pixel rows 4 (8 w + j) .. + 3 of the dy buffer (x buffer: + 1); lane l <- pixel + (l >> 4),
+    // 16-byte position l & 15 of the LDS row, which holds channel chunk (l & 15) ^ (key << 2), key = LDS row & 3
+    const int lq = lane >> 4, lc = lane & 15;
+    const int vp = lq * a.p_pstride * 2 + ((lc ^ (lq << 2)) << 4);
+    const int vq = lq * a.q_pstride * 2 + ((lc ^ (((lq + 1) & 3) << 2)) << 4);
+    const int p_piece = 4 * a.p_pstride * 2, q_piece = 4 * a.q_pstride * 2;          // bytes between pieces
+    const int p_row = 128 * a.p_pstride * 2, q_row = 128 * a.q_pstride * 2;          // bytes between image rows
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Pg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Qg), 0, 0x7fffffff, 0x00020000);
+    int sp = 0, sq = 0;                                                              // scalar offsets of the row being staged (+ this wave's share)
+    auto set_row = [&](int r) __attribute__((always_inline)) {
+        sp = r * p_row + wave * 8 * p_piece;
+        sq = (r + dh) * q_row + wave * 8 * q_piece;
+    };
+    // LDS byte offsets of the buffers: `nb_*` = the buffer being staged (scalar, toggles every row); the fragment addresses below point into the
+    // buffer being multiplied and are moved by +-W4W_DY / +-W4W_X at every row (no second copy of the loop body for the other buffer parity: with the
+    // body unrolled by two and an exit in the middle the register allocator shuffled all 192 accumulators at the loop head)
+    int nb_dy = 0, nb_x = 0;
+    auto dma_p = [&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void *)(lds + nb_dy + (wave * 8 + j) * 1024), 16, vp, sp + j * p_piece, 0, 0);
+    };
+    auto dma_q = [&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_q, (__attribute__((address_space(3))) void *)(lds + W4W_X0 + nb_x + 256 + (wave * 8 + j) * 1024), 16, vq, sq + j * q_piece,
+                                                 0, 0);
+    };
+    // piece k (0..15) of a row: dy pieces and x pieces alternate
+    auto piece = [&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        if constexpr ((k & 1) == 0) dma_p(W4WIC<(k >> 1)>{});
+        else dma_q(W4WIC<(k >> 1)>{});
+    };
+
+    // ---- fragment addressing (bytes).  lane = 16 g + m: channel 16 (g & 1) + m of a 32-channel block, pixels 8 (g >> 1) + {0..3 | 4..7}; the
+    // transposing read takes per lane the address of pixel row (m >> 2), 4-channel piece (m & 3)
+    const int m = lane & 15, g = lane >> 4;
+    const int mr = m >> 2;
+    const int lane_b = (g & 1) * 32 + (m & 3) * 8;
+    int a_addr[4], x_addr[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_addr[i] = (8 * (g >> 1) + mr) * 256 + ((i ^ mr) << 6) + lane_b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x_addr[k] = W4W_X0 + (8 * (g >> 1) + mr + k) * 256 + ((wave ^ ((mr + k) & 3)) << 6) + lane_b;
+    int da = W4W_DY, dx = W4W_X;            // to the other buffer
+
+    w4w_f32x16_t acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    bf16x8_t FA[7], FB[7];              // [0..3] dy blocks, [4..6] x at kw = 0, 1, 2
+    // The transposing reads are INLINE ASSEMBLY: behind the builtin (__builtin_amdgcn_ds_read_tr16_b64_*) hipcc puts an s_waitcnt vmcnt(0) in front
+    // of every read that follows an LDS-DMA instruction -- its memory operand carries no alias information, so the waitcnt pass assumes the read
+    // may touch what the DMA is writing (plain ds_read_b128 loads are not treated this way: conv_w4.hip) -- and the next row's DMA latency would sit
+    // exposed in every sub-step (that is what bounds wgrad_glds_kernel's K step, csrc/wgrad.hip).  The compiler neither counts these reads in
+    // lgkmcnt nor knows they touch LDS: the wait is explicit (frag_wait, tied to the fragment registers so the MFMAs stay behind it), and the
+    // issue order is pinned with sched_barrier(0) after every MFMA shadow instead of sched_group_barrier classes.
+    // K-th fragment read of a sub-step (order A0 X0 A1 X1 A2 X2 A3): OFS = sub-step offset (compile-time: the instruction's offset field)
+    auto read_frag = [&](auto Kc, auto OFS, bf16x8_t (&F)[7]) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr int f = (k & 1) ? 4 + (k >> 1) : (k >> 1);
+        constexpr int ofs = decltype(OFS)::value;
+        int addr;
+        if constexpr (k & 1) addr = x_addr[k >> 1];
+        else addr = a_addr[k >> 1];
+        s16x4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(ofs));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(ofs + 1024));
+        F[f][0] = lo[0]; F[f][1] = lo[1]; F[f][2] = lo[2]; F[f][3] = lo[3];
+        F[f][4] = hi[0]; F[f][5] = hi[1]; F[f][6] = hi[2]; F[f][7] = hi[3];
+    };
+    auto frag_wait = [&](bf16x8_t (&F)[7]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]));
+    };
+    auto mma_one = [&](auto Qc, const bf16x8_t (&F)[7]) __attribute__((always_inline)) {
+        constexpr int q = decltype(Qc)::value, i = 3 - q / 3, k = 2 - q % 3;
+        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[4 + k], acc[i][k], 0, 0, 0);
+    };
+    // one 16-pixel sub-step: wait for Fc (read during the previous sub-step), then 12 MFMAs on it; in the shadows of MFMAs 0..6 the fragment reads
+    // of the next sub-step (into Fn), in the shadows of MFMAs 7..10 DMA pieces D0 .. D0+3 of the NEXT row (when D0 >= 0)
+    auto substep = [&](bf16x8_t (&Fc)[7], bf16x8_t (&Fn)[7], auto OFS, auto D0c) __attribute__((always_inline)) {
+        constexpr int D0 = decltype(D0c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        frag_wait(Fc);
+        auto one = [&](auto Qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(Qc)::value;
+            mma_one(Qc, Fc);
+            if constexpr (q < 7) read_frag(Qc, OFS, Fn);
+            if constexpr (D0 >= 0 && q >= 7 && q < 11) piece(W4WIC<(D0 >= 0 && q >= 7 && q < 11) ? D0 + q - 7 : 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        one(W4WIC<0>{}); one(W4WIC<1>{}); one(W4WIC<2>{}); one(W4WIC<3>{}); one(W4WIC<4>{}); one(W4WIC<5>{});
+        one(W4WIC<6>{}); one(W4WIC<7>{}); one(W4WIC<8>{}); one(W4WIC<9>{}); one(W4WIC<10>{}); one(W4WIC<11>{});
+    };
+    // one K step = one image row (fragments of its sub-step 0 are in FA); the row set_row() named is staged into the other buffer meanwhile
+    auto step = [&]() __attribute__((always_inline)) {
+        substep(FA, FB, W4WIC<1 * 4096>{}, W4WIC<0>{});
+        substep(FB, FA, W4WIC<2 * 4096>{}, W4WIC<4>{});
+        substep(FA, FB, W4WIC<3 * 4096>{}, W4WIC<8>{});
+        substep(FB, FA, W4WIC<4 * 4096>{}, W4WIC<12>{});
+        substep(FA, FB, W4WIC<5 * 4096>{}, W4WIC<-1>{});
+        substep(FB, FA, W4WIC<6 * 4096>{}, W4WIC<-1>{});
+        substep(FA, FB, W4WIC<7 * 4096>{}, W4WIC<-1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // the next row has landed (this wave's pieces; the barrier collects the others') and this wave's reads of the current buffer are complete
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_addr[i] += da;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x_addr[k] += dx;
+        da = -da; dx = -dx;
+        nb_dy = W4W_DY - nb_dy; nb_x = W4W_X - nb_x;
+        substep(FB, FA, W4WIC<0>{}, W4WIC<-1>{});
+    };
+
+    // ---- prologue: padding columns of both x buffers, first row into buffer 0
+    {
+        const int which = tid >> 6;                                   // (buffer, pixel row -1 | 128)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(lds + W4W_X0 + (which >> 1) * W4W_X + (which & 1) * 129 * 256 + (tid & 63) * 4) = 0u;
+    }
+    // valid rows of this range: every row but, for kh = 0 / 2, the first / last row of an image
+    int nrows = max(0, r_end - r_begin);
+    if (dh != 0 && nrows > 0) {
+        const int hbad = dh < 0 ? 0 : a.H - 1;                       // rows q with q % H == hbad have no x row
+        nrows -= (r_end + a.H - 1 - hbad) / a.H - (r_begin + a.H - 1 - hbad) / a.H;
+    }
+    int r = next_valid(r_begin);
+    if (nrows > 0) {
+        set_row(r);
+        piece(W4WIC<0>{}); piece(W4WIC<1>{}); piece(W4WIC<2>{}); piece(W4WIC<3>{}); piece(W4WIC<4>{}); piece(W4WIC<5>{}); piece(W4WIC<6>{}); piece(W4WIC<7>{});
+        piece(W4WIC<8>{}); piece(W4WIC<9>{}); piece(W4WIC<10>{}); piece(W4WIC<11>{}); piece(W4WIC<12>{}); piece(W4WIC<13>{}); piece(W4WIC<14>{}); piece(W4WIC<15>{});
+    }
+    nb_dy = W4W_DY; nb_x = W4W_X;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nrows > 0) {
+        read_frag(W4WIC<0>{}, W4WIC<0>{}, FA); read_frag(W4WIC<1>{}, W4WIC<0>{}, FA); read_frag(W4WIC<2>{}, W4WIC<0>{}, FA); read_frag(W4WIC<3>{}, W4WIC<0>{}, FA);
+        read_frag(W4WIC<4>{}, W4WIC<0>{}, FA); read_frag(W4WIC<5>{}, W4WIC<0>{}, FA); read_frag(W4WIC<6>{}, W4WIC<0>{}, FA);
+        // past the end the last row is staged once more into the idle buffer (no branch around the DMA)
+        for (int t = 0; t < nrows; ++t) {
+            const int rn = next_valid(r + 1);
+            r = rn < 0 ? r : rn;
+            set_row(r);
+            step();
+        }
+    }
+
+    // ---- epilogue: acc[i][k][e] = dW[ca = ta*128 + 32 i + 8 (e >> 2) + 4 lh + (e & 3)][kh][kw = k][cb = tb*128 + 32 wave + lr]
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float *o = slab + (size_t)(ta * 128 + 32 * i + 4 * lh) * a.J + (kh * 3 + k) * a.CBp + tb * 128 + 32 * wave + lr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[(size_t)(8 * (e >> 2) + (e & 3)) * a.J] = acc[i][k][e];
+        }
+}
+
+// the layers this kernel serves (see the header comment)
+static bool w4w_eligible(const dl_wgrad_desc *d) {
+    static const bool off = getenv("DL_NO_WGRAD_W4") != nullptr;
+    if (off) return false;
+    if (d->dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->p_act != DL_ACT_NONE || d->q_act != DL_ACT_NONE || d->pad_mode != DL_PAD_ZERO) return false;
+    if (d->KH != 3 || d->KW != 3 || d->step != 1 || d->pad != 1 || (d->pad_w >= 0 && d->pad_w != 1) || d->stack_kw || d->p_split || d->q_split) return false;
+    if (d->Wp != 128 || d->Wq != 128 || d->Hp != d->Hq || d->Hp < 2 || d->N < 1) return false;
+    if ((d->CAp % 128) || (d->CBp % 128) || (d->p_pstride % 8) || (d->q_pstride % 8)) return false;
+    const size_t rows = (size_t)d->N * d->Hp;
+    if (rows * 128 * (size_t)d->p_pstride * 2 >= ((size_t)1 << 31) || rows * 128 * (size_t)d->q_pstride * 2 >= ((size_t)1 << 31)) return false;   // 32-bit offsets
+    return d->splitk >= 1 && (size_t)d->splitk <= rows;
+}
+
+static int launch_wgrad_w4(const dl_wgrad_desc *d, const WgradLayers &lay, int n, int kstride, hipStream_t stream) {
+    WgradW4Args a;
+    memset(&a, 0, sizeof(a));
+    a.NH = d->N * d->Hp; a.H = d->Hp;
+    a.CBp = d->CBp; a.J = 9 * d->CBp; a.kstride = kstride;
+    a.p_pstride = d->p_pstride; a.q_pstride = d->q_pstride;
+    a.splitk = d->splitk; a.rps = (a.NH + d->splitk - 1) / d->splitk;
+    a.tiles_a = d->CAp / 128; a.tiles_b = d->CBp / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4W_LDS);
+        if (e != hipSuccess) DL_FAIL("dl_conv_wgrad(w4): hipFuncSetAttribute(%zu): %s", W4W_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int grid = a.tiles_a * a.tiles_b * 3 * a.splitk * n;
+    hipLaunchKernelGGL(wgrad_w4_kernel, dim3(grid), dim3(256), W4W_LDS, stream, a, lay);
+    DL_CHECK_LAUNCH("dl_conv_wgrad(w4)");
+    return 0;
+}

@@ -32,6 +32,22 @@ __device__ __forceinline__ bf16x8_t tr_fragment_plane(const char *plane, int pro
     return r;
 }
 
+// the same through inline assembly: see tr_fragment_swz_asm (wgrad.hip) -- the caller waits (tr_wait4)
+template <int ROWB>
+__device__ __forceinline__ bf16x8_t tr_fragment_plane_asm(const char *plane, int prow0, int slot, int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const int x = (m >> 2) | ((g & 1) << 2);
+    const char *base = plane + (prow0 + 8 * g + (m >> 2)) * ROWB + ((slot ^ x) << 5) + (m & 3) * 8;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)base;
+    s16x4_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * ROWB) : "memory");
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
 // 4 fp32 values -> 4 bf16 hi (8 bytes) + 4 bf16 lo
 __device__ __forceinline__ void x3w_split4(f32x4_t v, int act, u32x2_t &hi, u32x2_t &lo) {
     if (act == DL_ACT_RELU) {
@@ -49,8 +65,8 @@ __device__ __forceinline__ void x3w_split4(f32x4_t v, int act, u32x2_t &hi, u32x
     }
 }
 
-template <int BA>
-__global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
+template <int BA, bool TRASM>
+__global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a, const WgradLayers lay) {
     constexpr int BJ = 256, BP = 32, NW = 8, WA = 2, WJ = 4;
     constexpr int PA = BA / WA, PJ = BJ / WJ, FA = PA / 16, FJ = PJ / 16;     // FJ = 4; FA = 8 (BA 256) or 4 (BA 128)
     constexpr int ROWA = BA * 4, ROWJ = BJ * 4;                               // bytes of one pixel row (fp32, later hi plane | lo plane)
@@ -64,23 +80,27 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave % WA, wj = wave / WA;
-    int bid, ks;
+    int bid, ks, layer;
     if (a.xcd_group) {
         const int ntile = gridDim.x;
-        const int logical = xcd_remap(blockIdx.y * ntile + blockIdx.x, ntile * gridDim.y);
-        ks = logical / ntile;
-        bid = logical - ks * ntile;
+        const int logical = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * ntile + blockIdx.x, ntile * gridDim.y * gridDim.z);
+        const int grp = logical / ntile;
+        bid = logical - grp * ntile;
+        layer = grp / gridDim.y;
+        ks = grp - layer * gridDim.y;
     } else {
         bid = xcd_remap(blockIdx.x, gridDim.x);
         ks = blockIdx.y;
+        layer = blockIdx.z;
     }
     const int tj = bid % a.tiles_j, ta = bid / a.tiles_j;
     const int p_begin = ks * a.pchunk;
     const int p_end = min(a.Ptot, p_begin + a.pchunk);
     const int nk = (p_end > p_begin) ? (p_end - p_begin + BP - 1) / BP : 0;
 
-    const float *P = reinterpret_cast<const float *>(a.P);
-    const float *Q = reinterpret_cast<const float *>(a.Q);
+    const float *P = reinterpret_cast<const float *>(lay.P[layer]);
+    const float *Q = reinterpret_cast<const float *>(lay.Q[layer]);
+    float *slab = lay.slab[layer];
     const float *zero = reinterpret_cast<const float *>(g_wzero_page);
 
     // ---- P: instruction i of this wave fills tile rows (wave*A_INS + i)*A_RPI + lane / A_LPR; this lane owns channels 4*(lane % A_LPR) .. +3
@@ -213,18 +233,37 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
         if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
         const char *Ps = smem_raw + cur * BUFB, *Qs = Ps + TAB;
         bf16x8_t bh[FJ], bl[FJ];
+        static_assert(FJ == 4, "fragment count of the explicit waits");
+        if constexpr (TRASM) {
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            bh[j] = tr_fragment_plane<ROWJ>(Qs, 0, (wj * PJ) / 16 + j, lane);
-            bl[j] = tr_fragment_plane<ROWJ>(Qs + ROWJ / 2, 0, (wj * PJ) / 16 + j, lane);
+            for (int j = 0; j < FJ; ++j) {
+                bh[j] = tr_fragment_plane_asm<ROWJ>(Qs, 0, (wj * PJ) / 16 + j, lane);
+                bl[j] = tr_fragment_plane_asm<ROWJ>(Qs + ROWJ / 2, 0, (wj * PJ) / 16 + j, lane);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                bh[j] = tr_fragment_plane<ROWJ>(Qs, 0, (wj * PJ) / 16 + j, lane);
+                bl[j] = tr_fragment_plane<ROWJ>(Qs + ROWJ / 2, 0, (wj * PJ) / 16 + j, lane);
+            }
         }
 #pragma unroll
         for (int half = 0; half < FA / 4; ++half) {
             bf16x8_t ah[4], al[4];
+            if constexpr (TRASM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = tr_fragment_plane<ROWA>(Ps, 0, (wa * PA) / 16 + half * 4 + i, lane);
-                al[i] = tr_fragment_plane<ROWA>(Ps + ROWA / 2, 0, (wa * PA) / 16 + half * 4 + i, lane);
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = tr_fragment_plane_asm<ROWA>(Ps, 0, (wa * PA) / 16 + half * 4 + i, lane);
+                    al[i] = tr_fragment_plane_asm<ROWA>(Ps + ROWA / 2, 0, (wa * PA) / 16 + half * 4 + i, lane);
+                }
+                tr_wait4(ah); tr_wait4(al);
+                if (half == 0) { tr_wait4(bh); tr_wait4(bl); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = tr_fragment_plane<ROWA>(Ps, 0, (wa * PA) / 16 + half * 4 + i, lane);
+                    al[i] = tr_fragment_plane<ROWA>(Ps + ROWA / 2, 0, (wa * PA) / 16 + half * 4 + i, lane);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -256,7 +295,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ta * BA + wa * PA + i * 16 + fg * 4 + r;
-                if (ca < a.CAp) a.slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
+                if (ca < a.CAp) slab[(size_t)ks * a.kstride + (size_t)ca * a.J + jj] = acc[i][j][r];
             }
         }
 }
@@ -485,24 +524,29 @@ static int launch_wgrad_4ph_x3(WgradArgs a, hipStream_t stream) {
     return 0;
 }
 
-template <int BA>
-static int launch_wgrad_glds_x3(WgradArgs a, hipStream_t stream) {
+template <int BA, bool TRASM>
+static int launch_wgrad_glds_x3_v(WgradArgs a, const WgradLayers &lay, int n, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 32 * (BA + 256) * sizeof(float);
     a.tiles_a = a.CAp / BA;
     a.tiles_j = (a.J + 255) / 256;
     a.pchunk = ((a.Ptot + a.splitk - 1) / a.splitk + 31) / 32 * 32;
     const int hw = a.Hp * a.Wp;
     a.dn = 32 / hw; a.dh = (32 % hw) / a.Wp; a.dw = (32 % hw) % a.Wp;
-    auto kern = wgrad_glds_x3_kernel<BA>;
+    auto kern = wgrad_glds_x3_kernel<BA, TRASM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) DL_FAIL("dl_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_a * a.tiles_j, a.splitk, n), dim3(512), smem, stream, a, lay);
     DL_CHECK_LAUNCH("dl_conv_wgrad(glds x3)");
     return 0;
+}
+
+template <int BA>
+static int launch_wgrad_glds_x3(const WgradArgs &a, const WgradLayers &lay, int n, hipStream_t stream) {
+    return a.tr_asm ? launch_wgrad_glds_x3_v<BA, true>(a, lay, n, stream) : launch_wgrad_glds_x3_v<BA, false>(a, lay, n, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -236,6 +236,21 @@ def choose_wgrad_splitk(cap: int, j: int, ptot: int, fast: bool = False, target_
     return max(1, sk)
 
 
+def wgrad_batch_shape(kh: int, kw: int, step: int, wp: int, hp: int, hq: int, cap: int, cbp: int) -> bool:
+    """the layers ops.HipBackend queues for the batched weight gradient: the ResnetBlock conv (networks.py:467-513) -- 3x3, stride 1, image rows of 128 pixels --
+    i.e. the one shape a network repeats (18 times in a Resnet-9).  Every other layer occurs once per network and pass: a batch of one would only
+    under-fill the chip with the batch's small split-K."""
+    return kh == 3 and kw == 3 and step == 1 and wp == 128 and hp == hq and cap % 128 == 0 and cbp % 128 == 0
+
+
+def choose_wgrad_batch_splitk(tiles: int, ksteps: int) -> int:
+    """split-K of a layer inside a batch: its tiles x splitk workgroups take about a THIRD of the chip, whatever the batch size -- the result of a layer
+    then does not depend on how many layers share its launch (a flush in the middle of a network, branch streams or not, leaves every gradient
+    bit-identical), three layers fill the chip, and 18 make ~6 rounds of it, so every workgroup's slab store hides behind the next round's main loops.
+    ResnetBlock conv at batch 8: 12 tiles x 7 row ranges (w4 kernel; r04: 9 tiles x 28 pixel ranges, four times the slab bytes)."""
+    return max(1, min((NUM_CUS // 3 + tiles // 2) // tiles, max(1, ksteps // 16)))
+
+
 WGRAD_C4_PARTS = 512
 
 

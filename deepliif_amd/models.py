@@ -128,6 +128,16 @@ class StepGraph:
                 self.static[k] = conv(v, self.static.get(k))
         return self.static
 
+    def _same_layout(self, batch) -> bool:
+        """same keys, list lengths, shapes and dtypes as the batch the static tensors were made from"""
+        def sig(v):
+            if torch.is_tensor(v):
+                return (tuple(v.shape), v.dtype)
+            if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(x) for x in v):
+                return tuple(sig(x) for x in v)
+            return None
+        return batch.keys() == self.static.keys() and all(sig(v) == sig(self.static[k]) for k, v in batch.items())
+
     def step(self, batch):
         m = self.model
         if self.why_eager:
@@ -135,6 +145,16 @@ class StepGraph:
             m.optimize_parameters()
             return
         m._sync_replicas()
+        if self.static is not None and not self._same_layout(batch):
+            # a batch the captured step was not recorded for (the reference's loaders keep the last, smaller batch of an epoch; copy_() would broadcast a
+            # remainder of 1 into every slot without a word): this step runs eagerly on the scalar-argument Adam kernel (same arithmetic),
+            # the graph stays valid for the batches that fit
+            self.eager_steps = getattr(self, 'eager_steps', 0) + 1
+            for o in m.optimizers:
+                o.step_eager_once = True
+            m.set_input(batch)
+            m.optimize_parameters()
+            return
         static = self._to_static(batch)
         for o in m.optimizers:
             o.prepare_step()
@@ -216,7 +236,15 @@ class BaseModel:
         if tape is None or not self.is_train:
             return
         params = [p for p in net.parameters()]
-        tape.record(lambda: self.exchange.ready(params))
+
+        def net_done():
+            # the network's queued weight gradients (ops.HipBackend: batched launch of its ResnetBlock layers) run now, on this branch's stream: the
+            # batches are per network whatever the number of branch streams or ranks, and dL/dy / x of one network at a time are kept alive
+            flush = getattr(ops.impl(), 'wgrad_flush', None)
+            if flush is not None and params and params[0].is_cuda:
+                flush()
+            self.exchange.ready(params)
+        tape.record(net_done)
 
     def _hook_tape(self, tape):
         """a training tape reports every parameter whose gradient has become final to the gradient exchange (progressive buckets of the

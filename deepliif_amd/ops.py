@@ -20,8 +20,8 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from .geometry import (GatherPlan, WGRAD_C4_PARTS, choose_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc, wgrad_c4_ok,
-                       wgrad_fast_path)
+from .geometry import (GatherPlan, NUM_CUS, WGRAD_C4_PARTS, choose_splitk, choose_wgrad_batch_splitk, choose_wgrad_splitk, fill_conv_desc, fill_pack_desc,
+                       wgrad_batch_shape, wgrad_c4_ok, wgrad_fast_path)
 
 
 def dl_dtype(t: torch.Tensor) -> int:
@@ -50,7 +50,14 @@ _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
 _SPLIT_ONLY_GRAD = os.environ.get('DL_NO_SPLIT_ONLY_GRAD', '0') != '1'     # A/B switch: 1 = the norm backward always stores the fp32 gradient next to its split copy
 _NO_C4_X3 = 'DL_NO_C4_X3' in os.environ              # A/B switch: the strict 7x7 stem / head on the general x3 kernels (csrc/conv_x3.h, wgrad_x3.h)
 _WGRAD_DEFER = os.environ.get('DL_WGRAD_DEFER', '1') != '0'            # A/B switch: 0 = every weight gradient reduces its slabs right behind the split-K kernel (rounds 1-3)
-_WGRAD_ARENA_MB = int(os.environ.get('DL_WGRAD_ARENA_MB', '4096'))      # slab arena of the deferred reduction (one Resnet-9 generator's backward pass writes ~1.9 GB of slabs at batch 8; measured r04: 256 MB = no gain, 2 GB / 12 GB +0.8 %)
+# slab arena of the deferred reduction, per scratch state (thread / branch stream): grown on demand, never below this.  r04 reserved 4 GB per state whatever the
+# model (~16 GB with three branch streams, also for an ngf = 8 fixture); since the batched weight gradient (below) a Resnet-9 pass at batch 8 writes
+# ~0.9 GB of slabs (r04: 1.9 GB), and an arena that is too small only costs an extra reduction launch
+_WGRAD_ARENA_MB = int(os.environ.get('DL_WGRAD_ARENA_MB', '256'))
+# DL_WGRAD_BATCH=0: A/B switch -- every weight gradient launches its own split-K kernel as in round 4.  Default: inside a backward pass the layers of the
+# ResnetBlock shape (the only shape a network repeats: 18 of a Resnet-9's 23 convolutions) are QUEUED with their operands and computed by one launch per
+# network (dl_conv_wgrad_multi) at the network's tape marker / the end of the pass
+_WGRAD_BATCH = os.environ.get('DL_WGRAD_BATCH', '1') != '0'
 _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B switch: 1 = head forward through dl_conv_forward(raw) + dl_shift_sum (round 1)
 _SHARED_STATE: dict = {}
 
@@ -63,6 +70,11 @@ class Workspace:
 
     def __init__(self):
         self._tls = threading.local()
+        # HIP streams registered as a model's BRANCH streams -- process-wide: a model caches its streams once, so a thread other than the
+        # one that ran the first forward (a worker-thread trainer, validation then training) must recognise them too, or its three concurrently
+        # running branches would share one slab arena and one statistics workspace
+        self._branch_ids = set()
+        self._branch_lock = threading.Lock()
 
     def _thread_state(self):
         # DL_SHARED_SCRATCH=1 restores the process-wide buffers: ONLY for demonstrating the hazard (tests/test_gpu_networks.py,
@@ -73,7 +85,7 @@ class Workspace:
         """scratch state of the calling thread -- or, while one of a model's BRANCH streams is current (branch_streams_on), of that stream: two
         streams of one thread run concurrently on the GPU, so they may not share a slab, a statistics workspace or a slab arena"""
         st = self._thread_state()
-        ids = st.get('branch_ids')
+        ids = self._branch_ids
         if ids:
             s = torch.cuda.current_stream()
             if s.cuda_stream in ids:           # (any other stream -- torch's default stream, a graph-capture stream -- keeps the thread's own state, as before)
@@ -87,7 +99,14 @@ class Workspace:
 
     def branch_streams_on(self, streams):
         """register the branch streams of a model (models.BaseModel._branch_streams): work launched while one of them is current gets its own scratch state"""
-        self._thread_state().setdefault('branch_ids', set()).update(s.cuda_stream for s in streams)
+        with self._branch_lock:
+            self._branch_ids = self._branch_ids | {s.cuda_stream for s in streams}          # (replaced, never mutated: readers need no lock)
+
+    def forget_branch_streams(self):
+        """drop every registration and this thread's per-stream scratch states (tests; a model that is gone leaves its streams' states behind)"""
+        with self._branch_lock:
+            self._branch_ids = set()
+        self._thread_state().pop('streams', None)
 
     def stream_states(self):
         """every per-stream state of this thread (empty unless branch_streams_on() was called)"""
@@ -285,18 +304,36 @@ class HipBackend:
         if stack_kw:
             d.KW, d.pad_w, d.stack_kw, d.CA = 1, 0, stack_kw, grad.shape[0] * stack_kw
         d.dtype, d.prec = dl_dtype(P), prec
+        d.accumulate = 1 if accumulate else 0
+        d.p_act, d.q_act = p_act, q_act
+        d.p_split, d.q_split = (1 if p_split else 0), (1 if q_split else 0)
         j = d.KH * d.KW * d.CBp
         strict = d.dtype == L.DL_F32 and prec == L.PREC_BF16X3 and not _NO_X3_GLDS
         fast = wgrad_fast_path(d.CAp, j, d.dtype == L.DL_BF16 and prec == L.PREC_BF16, p_act == L.ACT_NONE and q_act == L.ACT_NONE,
                                pad_mode == L.PAD_ZERO, strict, p_act in _X3_ACTS and q_act in _X3_ACTS)
-        d.splitk = splitk if splitk is not None else choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
+        # which kernel will run (the library decides: csrc/wgrad.hip wgrad_kernel_of), with its tile count -- split-K is sized from that
+        d.splitk = 1
+        tiles, ksteps, kname = L.i32(), L.i32(), C.c_char_p()
+        multi = int(self.lib.dl_wgrad_plan(C.byref(d), C.byref(tiles), C.byref(ksteps), C.byref(kname)))
+        if multi < 0:
+            L.check(multi, 'dl_wgrad_plan')
+        w4 = kname.value == b'wgrad_w4_kernel'
+        deferring = _WGRAD_DEFER and WS._thread_state().get('defer_depth', 0) > 0
+        # batched: the w4 kernel's layers only.  Measured r05 (profiles/r05/wgrad_first_look.txt, 18 layers): bf16 w4 129.6 -> 114.3 us per layer; the strict
+        # glds_x3 kernel 465.5 -> 473.2 (its 3 x MFMA work already hides the slab store; split-K 9 instead of 28 only lengthens the tail)
+        if deferring and _WGRAD_BATCH and splitk is None and multi == 1 and w4 and wgrad_batch_shape(d.KH, d.KW, d.step, d.Wp, d.Hp, d.Hq, d.CAp, d.CBp):
+            self._wgrad_queued(WS._state(), d, P, Q, grad, tiles.value, ksteps.value)
+            return
+        if splitk is not None:
+            d.splitk = splitk
+        elif w4:
+            d.splitk = max(1, min(NUM_CUS // tiles.value, ksteps.value))       # 12 tiles x 21 row ranges = 252 workgroups: one round of the chip
+        else:
+            d.splitk = choose_wgrad_splitk(d.CAp, j, d.N * d.Hp * d.Wp, fast)
         if splitk is None and not _NO_WGRAD_C4 and self.wgrad_c4_applies(P, Q, grad, k, step, pad, pad_mode, p_act, q_act, prec, stack_kw):
             d.splitk = WGRAD_C4_PARTS          # one partial result per persistent workgroup (csrc/wgrad_c4.h)
-        d.accumulate = 1 if accumulate else 0
-        d.p_act, d.q_act = p_act, q_act
-        d.p_split, d.q_split = (1 if p_split else 0), (1 if q_split else 0)
         nslab = int(self.lib.dl_wgrad_slab_floats(C.byref(d)))
-        if _WGRAD_DEFER and WS._thread_state().get('defer_depth', 0) > 0 and self.lib.dl_conv_wgrad_deferrable(C.byref(d)):
+        if deferring and self.lib.dl_conv_wgrad_deferrable(C.byref(d)):
             self._wgrad_deferred(WS._state(), d, P, Q, grad, nslab)
             return
         slab = WS.get('wgrad_slab', nslab, P.device)
@@ -323,33 +360,81 @@ class HipBackend:
         """wgrad_flush() on every stream of this thread that has slabs pending (each batch is launched on the stream that wrote its slabs)"""
         self.wgrad_flush()
         for sub in WS.stream_states():
-            if sub.get('defer_pending'):
+            if sub.get('defer_pending') or sub.get('defer_queue'):
                 with torch.cuda.stream(sub['stream_obj']):
                     self.wgrad_flush()
+
+    def _arena_region(self, st, need: int, device):
+        """`need` floats of this state's slab arena (flushes what is pending when it is full; grows it when it is too small)"""
+        arena = st.get('defer_arena')
+        if arena is not None and st.get('defer_off', 0) + need > arena.numel():
+            self._reduce_pending(st)
+        if arena is None or arena.numel() < need or arena.device != device:
+            self._reduce_pending(st)
+            arena = torch.empty(max(need, _WGRAD_ARENA_MB * (1 << 18)), dtype=torch.float32, device=device)
+            st['defer_arena'], st['defer_off'] = arena, 0
+        off = st.get('defer_off', 0)
+        st['defer_off'] = off + need
+        return arena[off:off + need]
+
+    def _wgrad_queued(self, st, d, P, Q, grad, tiles, ksteps):
+        """batched weight gradient: keep the operands (the references keep dL/dy and x alive until the launch) and compute at the next flush"""
+        gp = grad.data_ptr()
+        if gp in st.setdefault('defer_grads', set()):
+            self.wgrad_flush()
+        st['defer_grads'].add(gp)
+        d.splitk = choose_wgrad_batch_splitk(tiles, ksteps)
+        st.setdefault('defer_queue', []).append((bytes(d), d, P, Q, grad))
+
+    def _launch_queued(self, st):
+        """one dl_conv_wgrad_multi per group of same-descriptor layers (<= WGRAD_MULTI_MAX each); their reductions join the pending list"""
+        queue = st.get('defer_queue')
+        if not queue:
+            return
+        st['defer_queue'] = []
+        groups = {}
+        for item in queue:
+            groups.setdefault(item[0], []).append(item)
+        for items in groups.values():
+            d = items[0][1]
+            per_layer = int(self.lib.dl_wgrad_slab_floats(C.byref(d)))           # the library places layer l's slabs at slab + l * per_layer
+            for i0 in range(0, len(items), L.WGRAD_MULTI_MAX):
+                chunk = items[i0:i0 + L.WGRAD_MULTI_MAX]
+                n = len(chunk)
+                slab = self._arena_region(st, (n * per_layer + 63) // 64 * 64, chunk[0][2].device)
+                arr = C.c_void_p * n
+                Ps, Qs, Gs = arr(*[it[2].data_ptr() for it in chunk]), arr(*[it[3].data_ptr() for it in chunk]), arr(*[it[4].data_ptr() for it in chunk])
+                ents = (L.WgradReduceEntry * n)()
+                _LAUNCH.dev = chunk[0][2].device
+                L.check(self.lib.dl_conv_wgrad_multi(C.byref(d), n, Ps, Qs, Gs, _ptr(slab), ents, _stream()), 'dl_conv_wgrad_multi')
+                pend = st.setdefault('defer_pending', [])
+                for l in range(n):
+                    e = L.WgradReduceEntry.from_buffer_copy(ents[l])
+                    e.block0 = st.get('defer_blocks', 0)
+                    st['defer_blocks'] = e.block0 + e.nblocks
+                    pend.append(e)
 
     def _wgrad_deferred(self, st, d, P, Q, grad, nslab):
         gp = grad.data_ptr()
         need = (nslab + 63) // 64 * 64
-        arena = st.get('defer_arena')
-        if gp in st.setdefault('defer_grads', set()) or (arena is not None and st.get('defer_off', 0) + need > arena.numel()):
+        if gp in st.setdefault('defer_grads', set()):
             self.wgrad_flush()
-        if arena is None or arena.numel() < need or arena.device != P.device:
-            self.wgrad_flush()
-            arena = torch.empty(max(need, _WGRAD_ARENA_MB * (1 << 18)), dtype=torch.float32, device=P.device)
-            st['defer_arena'], st['defer_off'] = arena, 0
-        off = st.get('defer_off', 0)
-        slab = arena[off:off + need]
+        slab = self._arena_region(st, need, P.device)
         e = L.WgradReduceEntry()
         L.check(self.lib.dl_conv_wgrad_slabs(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), C.byref(e), _stream()), 'dl_conv_wgrad_slabs')
         e.block0 = st.get('defer_blocks', 0)
         st['defer_blocks'] = e.block0 + e.nblocks
-        st['defer_off'] = off + need
         st['defer_grads'].add(gp)
         st.setdefault('defer_pending', []).append(e)       # (looked up AFTER the flushes above: they start a new list)
 
     def wgrad_flush(self):
-        """reduce every pending slab set of this thread (no-op when nothing is pending)"""
+        """compute every queued weight gradient and reduce every pending slab set of this thread / branch stream (no-op when there is nothing)"""
         st = WS._state()
+        self._launch_queued(st)
+        self._reduce_pending(st)
+        st['defer_grads'] = set()
+
+    def _reduce_pending(self, st):
         pend = st.get('defer_pending')
         if not pend:
             st['defer_off'] = 0                  # whatever wrote into the arena has been reduced by a launch earlier in stream order
@@ -368,7 +453,6 @@ class HipBackend:
             cache[key] = dev_tab
         total = st['defer_blocks']
         st['defer_pending'], st['defer_blocks'], st['defer_off'] = [], 0, 0
-        st['defer_grads'] = set()
         _LAUNCH.dev = arena.device
         L.check(self.lib.dl_wgrad_reduce_batch(_ptr(dev_tab), len(pend), total, _stream()), 'dl_wgrad_reduce_batch')
 

@@ -63,6 +63,7 @@ class FlatParams:
 
 
 _PACK_BATCH = os.environ.get('DL_PACK_BATCH', '1') != '0'
+_HYPER_RING = 4            # pinned staging slots of the graph-mode Adam scalars (FusedAdam.enable_graph_mode)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -81,7 +82,7 @@ class FusedAdam(torch.optim.Optimizer):
         # graph mode (models.StepGraph): the per-step scalars live in device memory -- step() launches dl_adam_step_dev, which a captured hipGraph can
         # replay, and prepare_step() (outside the graph) advances the step counter and refreshes them
         self.hyper_dev = None
-        self._hyper_host = None
+        self._hyper_ring = None
         self._prepared = False
 
     def zero_grad(self, set_to_none: bool = False):
@@ -134,7 +135,14 @@ class FusedAdam(torch.optim.Optimizer):
         """per-step scalars from device memory (see __init__); idempotent"""
         if self.hyper_dev is None:
             self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=self.flat.data.device)
-            self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if self.flat.data.is_cuda else torch.zeros(8, dtype=torch.float32)
+            # A RING of pinned staging buffers, each with the event of its last copy (ADVICE r4): the asynchronous H2D copy reads the pinned memory when
+            # the copy EXECUTES on the stream, not when it is enqueued, and a replayed step never synchronises -- with one buffer the host, running
+            # a step or more ahead, overwrote step N's scalars with step N+1's before step N's copy had run (a scheduler's new learning rate and
+            # the bias corrections landed a step early, nondeterministically).  A slot is rewritten only after its previous copy has completed.
+            cuda = self.flat.data.is_cuda
+            self._hyper_ring = [(torch.zeros(8, dtype=torch.float32).pin_memory() if cuda else torch.zeros(8, dtype=torch.float32),
+                                 torch.cuda.Event() if cuda else None) for _ in range(_HYPER_RING)]
+            self._hyper_slot, self._hyper_used = 0, [False] * _HYPER_RING
 
     def prepare_step(self):
         """graph mode, OUTSIDE the captured region, once per step and BEFORE it runs: advance Adam's step counter and put this step's scalars
@@ -142,8 +150,16 @@ class FusedAdam(torch.optim.Optimizer):
         assert self.hyper_dev is not None, 'enable_graph_mode() first'
         g = self.param_groups[0]
         self.step_count += 1
-        ops.impl().adam_hyper(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count, self.dp_scale, self._hyper_host)
-        self.hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        slot = self._hyper_slot
+        host, ev = self._hyper_ring[slot]
+        if ev is not None and self._hyper_used[slot]:
+            ev.synchronize()                   # the copy that last read this slot has executed (a no-op unless the host is _HYPER_RING steps ahead)
+        ops.impl().adam_hyper(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count, self.dp_scale, host)
+        self.hyper_dev.copy_(host, non_blocking=True)
+        if ev is not None:
+            ev.record()
+            self._hyper_used[slot] = True
+        self._hyper_slot = (slot + 1) % _HYPER_RING
         self._prepared = True
 
     @torch.no_grad()
@@ -152,7 +168,13 @@ class FusedAdam(torch.optim.Optimizer):
         if not self.flat.attached():
             raise RuntimeError('parameters were moved after the optimizer was built; rebuild the optimizer (FlatParams lost its views)')
         g = self.param_groups[0]
-        if self.hyper_dev is not None:
+        if self.hyper_dev is not None and getattr(self, 'step_eager_once', False):
+            # graph mode, but THIS step runs outside the captured graph (models.StepGraph: a batch of another shape): scalar-argument kernel
+            self.step_eager_once = False
+            self.step_count += 1
+            ops.impl().adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                                 self.step_count, self.dp_scale)
+        elif self.hyper_dev is not None:
             assert self._prepared, 'graph mode: prepare_step() must run before every step (models.StepGraph does)'
             self._prepared = False
             ops.impl().adam_step_dev(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.hyper_dev)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 111
+#define DL_VERSION 112
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -41,6 +41,7 @@ enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L
 
 #define DL_MAX_TAPS 64
 #define DL_MAX_PHASES 4
+#define DL_WGRAD_MULTI_MAX 24       /* layers per dl_conv_wgrad_multi launch (their pointers travel as kernel arguments) */
 
 int dl_version(void);
 const char *dl_last_error(void);
@@ -163,6 +164,24 @@ typedef struct dl_wgrad_reduce_entry {
 int dl_conv_wgrad_deferrable(const dl_wgrad_desc *d);
 int dl_conv_wgrad_slabs(const dl_wgrad_desc *d, const void *P, const void *Q, float *grad, float *slab, dl_wgrad_reduce_entry *entry_host, void *stream);
 int dl_wgrad_reduce_batch(const dl_wgrad_reduce_entry *table_dev, int count, int total_blocks, void *stream);
+
+/* Batched weight gradient (round 5).  With one launch per layer the split-K factor must fill 256 CUs by itself (ResnetBlock conv: 9 tiles x 28
+ * pixel ranges -> 28 fp32 partial copies of every gradient, 66 MB written and read back for a 2.4 MB result; every workgroup's prologue and slab
+ * store sit exposed).  The weight gradients of a backward pass do not depend on each other, and with 288 GB of HBM the operands (dL/dy, x) of a
+ * whole network stay alive until its pass ends, so same-shaped layers are computed by ONE launch: n layers x tiles x splitk workgroups, several
+ * rounds of the chip, split-K 3-7 instead of 28, the slab stores of one round hidden behind the next round's main loops.
+ *   dl_wgrad_plan        which kernel dl_conv_wgrad would run for `d` (pass splitk = 1): *tiles = its output tiles per layer, *ksteps = K steps of one
+ *                        tile at split-K 1, *name = kernel name (static string, diagnostic); returns 1 when that kernel has a batched form, 0 when
+ *                        not, < 0 on error.  Callers size split-K from it: one layer: tiles x splitk ~ one round of 256 CUs; a batch: see
+ *                        deepliif_amd/geometry.py choose_wgrad_multi_splitk.
+ *   dl_conv_wgrad_multi  n <= DL_WGRAD_MULTI_MAX layers sharing the descriptor `d` (HOST arrays P[n], Q[n], grad[n]) in one split-K launch; layer
+ *                        l's slabs start at slab + l * dl_wgrad_slab_floats(d); entries_host[l] = its pending reduction for dl_wgrad_reduce_batch
+ *                        (as dl_conv_wgrad_slabs).  Per element the result is the fixed-order sum of d->splitk partials: deterministic, and
+ *                        bit-identical to dl_conv_wgrad with the same splitk.
+ * Replaces the per-layer ATen conv backward-weight calls reached from DeepLIIF_model.py:332,429 (networks.py:467-513 for the dominant shape). */
+int dl_wgrad_plan(const dl_wgrad_desc *d, int32_t *tiles, int32_t *ksteps, const char **name);
+int dl_conv_wgrad_multi(const dl_wgrad_desc *d, int n, const void *const *P, const void *const *Q, float *const *grad, float *slab,
+                        dl_wgrad_reduce_entry *entries_host, void *stream);
 
 /* Pack an fp32 parameter tensor src[A][B][KH][KW] into the K-contiguous bf16 image(s) dl_conv_forward streams.
  *   row_is_a != 0 : packed row = a, contracted channel = b   (Conv2d forward; ConvTranspose2d data-grad)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/deepliif_hip.h but not exported by libdeepliif_hip.so'
         assert n in L.SIGNATURES, f'{n} has no ctypes signature in deepliif_amd/_lib.py'
-    assert lib.dl_version() == 111
+    assert lib.dl_version() == L.DL_VERSION
     assert isinstance(lib.dl_last_error(), bytes)
 
 

@@ -39,6 +39,28 @@ class StubLib:
         self.batches.append((table.value, count, total))
         return 0
 
+    # round 5: the kernel plan and the batched launch.  The stub calls a layer "batchable" when it has 128-pixel rows and 128-multiple channel counts,
+    # i.e. when geometry.wgrad_batch_shape() also says yes
+    def dl_wgrad_plan(self, d, tiles, ksteps, name):
+        d = d._obj
+        big = d.Wp == 128 and d.CAp % 128 == 0 and d.CBp % 128 == 0
+        tiles._obj.value = 12 if big else 1
+        ksteps._obj.value = d.N * d.Hp if big else max(1, d.N * d.Hp * d.Wp // 32)
+        name._obj.value = b'wgrad_w4_kernel' if big else b'wgrad_kernel'
+        return 1 if big else 0
+
+    def dl_conv_wgrad_multi(self, d, n, P, Q, grad, slab, entries, stream):
+        d = d._obj
+        per = self.dl_wgrad_slab_floats(C.byref(d))
+        self.multi = getattr(self, 'multi', [])
+        self.multi.append((d.splitk, n, [P[i] for i in range(n)], [grad[i] for i in range(n)], slab.value))
+        for l in range(n):
+            e = entries[l]
+            e.slab, e.grad = slab.value + 4 * l * per, grad[l]
+            e.splitk, e.CAp, e.CBp, e.J = d.splitk, d.CAp, d.CBp, d.KH * d.KW * d.CBp
+            e.nblocks = 5
+        return 0
+
 
 @pytest.fixture
 def be(monkeypatch):
@@ -130,3 +152,68 @@ def _desc_of(P, Q, grad):
     d.KH = d.KW = 3
     d.splitk = 2
     return d
+
+
+# ---- round 5: the batched weight gradient (ops.HipBackend._wgrad_queued / _launch_queued) ---------------------------------------------------------
+def _big_layer(n=1, h=4):
+    P = torch.zeros(n, h, 128, 128, dtype=torch.bfloat16)
+    Q = torch.zeros(n, h, 128, 128, dtype=torch.bfloat16)
+    return P, Q, torch.zeros(128, 128, 3, 3)
+
+
+def _wgrad_auto(be, P, Q, g):
+    be.conv_wgrad(P, Q, g, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, L.PREC_BF16, True)
+
+
+def test_repeated_shape_is_queued_and_computed_by_one_launch(be, monkeypatch):
+    monkeypatch.setattr(ops, '_WGRAD_BATCH', True)
+    big = [_big_layer() for _ in range(5)]
+    small = _layer(16, 8)
+    be.wgrad_defer_begin()
+    for P, Q, g in big[:3]:
+        _wgrad_auto(be, P, Q, g)
+    _wgrad_auto(be, *small)                                  # an ordinary layer in between: its own split-K kernel at once, reduction pending
+    for P, Q, g in big[3:]:
+        _wgrad_auto(be, P, Q, g)
+    st = ops.WS._state()
+    assert len(st['defer_queue']) == 5 and len(st['defer_pending']) == 1 and not getattr(be.lib, 'multi', None)
+    assert all(it[2] is P and it[3] is Q for it, (P, Q, _) in zip(st['defer_queue'], big))        # the operands are kept alive by the queue
+    be.wgrad_defer_end()
+    assert len(be.lib.multi) == 1 and len(be.lib.batches) == 1
+    splitk, n, Ps, Gs, slab0 = be.lib.multi[0]
+    assert n == 5 and Gs == [g.data_ptr() for _, _, g in big] and Ps == [P.data_ptr() for P, _, _ in big]
+    from deepliif_amd.geometry import choose_wgrad_batch_splitk
+    assert splitk == choose_wgrad_batch_splitk(12, 4)        # a function of the layer alone: not of how many layers share the launch
+    entries, total = _entries(be, 0)
+    assert [e.grad for e in entries] == [small[2].data_ptr()] + Gs and total == sum(e.nblocks for e in entries)
+    assert [e.block0 for e in entries] == [sum(x.nblocks for x in entries[:i]) for i in range(len(entries))]
+    spans = sorted([(e.slab, e.slab + 4 * e.splitk * e.CAp * e.J) for e in entries])
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))            # no two slab sets of the batch overlap
+    assert not st['defer_queue'] and not st['defer_pending']
+
+
+def test_batch_is_cut_at_the_launch_limit_and_at_a_second_use(be, monkeypatch):
+    monkeypatch.setattr(ops, '_WGRAD_BATCH', True)
+    layers = [_big_layer() for _ in range(L.WGRAD_MULTI_MAX + 3)]
+    be.wgrad_defer_begin()
+    for P, Q, g in layers:
+        _wgrad_auto(be, P, Q, g)
+    _wgrad_auto(be, *layers[0])                              # the first gradient again (a discriminator's second pass): everything queued runs first
+    assert [m[1] for m in be.lib.multi] == [L.WGRAD_MULTI_MAX, 3] and len(ops.WS._state()['defer_queue']) == 1
+    be.wgrad_defer_end()
+    assert [m[1] for m in be.lib.multi] == [L.WGRAD_MULTI_MAX, 3, 1]
+    got = []
+    for k in range(len(be.lib.batches)):
+        entries, _ = _entries(be, k)
+        got += [e.grad for e in entries]
+    assert got == [g.data_ptr() for _, _, g in layers] + [layers[0][2].data_ptr()]
+
+
+def test_batching_can_be_switched_off(be, monkeypatch):
+    monkeypatch.setattr(ops, '_WGRAD_BATCH', False)
+    P, Q, g = _big_layer()
+    be.wgrad_defer_begin()
+    _wgrad_auto(be, P, Q, g)
+    assert len(be.lib.slab_calls) == 1 and not ops.WS._state().get('defer_queue')
+    be.wgrad_defer_end()
+    assert len(be.lib.batches) == 1 and not getattr(be.lib, 'multi', None)

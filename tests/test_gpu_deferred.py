@@ -115,8 +115,8 @@ def test_second_use_of_a_gradient_and_a_small_arena(be, monkeypatch):
     shared = sets[0][2].clone()
     got = [g0.clone() for _, _, g0 in sets[2:]]
     flushes = []
-    real_flush = be.wgrad_flush
-    monkeypatch.setattr(be, 'wgrad_flush', lambda: (flushes.append(len(st.get('defer_pending') or [])), real_flush())[1])
+    real_reduce = be._reduce_pending            # (a second use goes through wgrad_flush, a full arena straight to the batched reduction: both end here)
+    monkeypatch.setattr(be, '_reduce_pending', lambda s: (flushes.append(len(s.get('defer_pending') or [])), real_reduce(s))[1])
     be.wgrad_defer_begin()
     _wgrad(be, l, sets[0][0], sets[0][1], shared, prec)
     _wgrad(be, l, sets[1][0], sets[1][1], shared, prec)          # same gradient again: the first accumulation is flushed before this one is queued

@@ -96,3 +96,48 @@ def test_step_graph_declines_what_it_cannot_capture():
     sg.step(b)                                       # still trains, eagerly
     torch.cuda.synchronize()
     assert all(v == v for v in model.get_current_losses().values())
+
+
+def test_replays_without_a_synchronize_in_between():
+    """the Adam scalars of step N are staged in pinned memory and copied asynchronously; the host runs ahead of the GPU when nothing
+    synchronises, so the staging buffer of step N must not be rewritten before its copy has executed (optim.FusedAdam: ring of pinned slots guarded
+    by events).  Six replays back to back, a learning-rate change in the middle, ONE synchronize at the end -- against the eager run, bit for bit"""
+    batches = _batches('train', 2, 64, 10, 5)
+    eager, graphed = _build('train', 'bf16'), _build('train', 'bf16')
+    sg = M.StepGraph(graphed, warmup=2)
+    on_dev = [{k: ([t.to(DEV) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else (v.to(DEV) if torch.is_tensor(v) else v)) for k, v in b.items()}
+              for b in batches]
+    torch.cuda.synchronize()
+    for i, b in enumerate(on_dev):
+        if i in (5, 7):
+            for o in graphed.optimizers:
+                o.param_groups[0]['lr'] *= 0.5
+        sg.step(b)                                   # steps 0-1 eager, 2 captured, 3.. replayed: no synchronize from here on
+    torch.cuda.synchronize()
+    for i, b in enumerate(on_dev):
+        if i in (5, 7):
+            for o in eager.optimizers:
+                o.param_groups[0]['lr'] *= 0.5
+        eager.set_input(b)
+        eager.optimize_parameters()
+    torch.cuda.synchronize()
+    assert sg.graph is not None and sg.calls == 10
+    assert torch.equal(_flat(eager), _flat(graphed))
+
+
+def test_a_batch_of_another_shape_runs_eagerly_and_the_graph_survives():
+    """the last batch of an epoch may be smaller (the reference's loaders do not drop it); StepGraph must not copy it into the captured
+    tensors (a remainder of 1 would broadcast silently)"""
+    big, small = _batches('train', 2, 64, 5, 5), _batches('train', 1, 64, 1, 5)
+    order = big[:4] + small + big[4:]
+    eager, graphed = _build('train', 'bf16'), _build('train', 'bf16')
+    sg = M.StepGraph(graphed, warmup=2)
+    for b in order:
+        eager.set_input(b)
+        eager.optimize_parameters()
+        sg.step(b)
+        torch.cuda.synchronize()
+        le, lg = eager.get_current_losses(), graphed.get_current_losses()
+        assert all(le[k] == lg[k] for k in le)
+    assert sg.graph is not None and sg.eager_steps == 1
+    assert torch.equal(_flat(eager), _flat(graphed)) and all(o.step_count == 6 for o in graphed.optimizers)

@@ -41,4 +41,4 @@ def test_inference_dag_on_streams_is_bit_identical(nstreams, precision, monkeypa
                 assert torch.equal(got[k], ref[k]), (k, seg_only, rep)
     st = ops.WS._thread_state()
     assert len(st[('infer_streams', 0)]) == nstreams
-    st.pop(('infer_streams', 0)), st.pop('branch_ids', None), st.pop('streams', None)
+    st.pop(('infer_streams', 0)), ops.WS.forget_branch_streams()

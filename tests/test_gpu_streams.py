@@ -18,11 +18,9 @@ DEV = 'cuda'
 @pytest.fixture(autouse=True)
 def _reset():
     ops._impl = None
-    ops.WS._thread_state().pop('branch_ids', None)       # (models of earlier test files leave their branch streams' scratch states behind)
-    ops.WS._thread_state().pop('streams', None)
+    ops.WS.forget_branch_streams()       # (models of earlier test files leave their branch streams' scratch states behind)
     yield
-    ops.WS._thread_state().pop('branch_ids', None)
-    ops.WS._thread_state().pop('streams', None)
+    ops.WS.forget_branch_streams()
 
 
 def _run(model, batches):

@@ -288,3 +288,25 @@ def test_training_step_on_stand_in_streams_matches_the_plain_step(seg_gen, modal
             assert fwd[0] < bwd[0] < fwd[1] < bwd[1]
     finally:
         fake_backend.uninstall()
+
+
+def test_branch_streams_are_recognised_from_another_thread(fake_cuda):
+    """a model registers its branch streams once (first forward); a trainer that later runs on a worker thread must get per-stream scratch too"""
+    import threading
+    ws = ops.Workspace()
+    ws.branch_streams_on([FakeStream(31), FakeStream(32)])
+    seen = {}
+
+    def worker():
+        fake_cuda['cur'] = FakeStream(31)
+        a = ws._state()
+        fake_cuda['cur'] = FakeStream(32)
+        b = ws._state()
+        seen['ok'] = a is not b and a is not ws._thread_state() and a['stream_obj'] == FakeStream(31)
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen['ok']
+    ws.forget_branch_streams()
+    fake_cuda['cur'] = FakeStream(31)
+    assert ws._state() is ws._thread_state()
