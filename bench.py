@@ -163,6 +163,77 @@ def cpu_baseline_child(norm, size, batch=1, budget=45.0):
     print(json.dumps({'seconds': sum(times) / len(times), 'steps': len(times), 'total_seconds': sum(times), 'cores': cores, 'size': size, 'batch': batch}), flush=True)
 
 
+def cpu_infer_child(size, budget=30.0):
+    """(child process) the inference DAG of BASELINE configs[1] on the CPU oracle, one tile per forward like the reference (deepliif/models/__init__.py:293-361):
+    4 x resnet_9blocks on the tile, 5 x unet_512 on the tile / the four translated images, weighted seg sum; BatchNorm on the tile's own statistics"""
+    from oracle import deepliif_oracle as O
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    G = [O.random_state_dict('resnet_9blocks', 3, 3, 64, 'batch', 'zero', generator=g) for _ in range(4)]
+    S = [O.random_state_dict('unet_512', 3, 3, 64, 'batch', 'zero', generator=g) for _ in range(5)]
+    x = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    w = [0.25, 0.15, 0.25, 0.1, 0.25]
+
+    def tile():
+        with torch.no_grad():
+            mods = [O.run_generator('resnet_9blocks', sd, x, 'batch', 'zero') for sd in G]
+            segs = [O.run_generator('unet_512', sd, src, 'batch', 'zero') for sd, src in zip(S, [x] + mods)]
+            return sum(wi * si for wi, si in zip(w, segs))
+    tile()
+    times = []
+    while len(times) < 3 and (sum(times) < budget or not times):
+        t0 = time.time()
+        tile()
+        times.append(time.time() - t0)
+    print(json.dumps({'seconds': sum(times) / len(times), 'steps': len(times), 'total_seconds': sum(times), 'cores': cores, 'size': size, 'batch': 1}), flush=True)
+
+
+def cpu_baseline_infer(args):
+    """cpu_baseline of the inference workload: the oracle's 9-generator DAG on one 512 x 512 tile at a time (the reference infers one tile per forward), a bounded
+    sample in a child process"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-infer-child', '--size', str(args.size)], capture_output=True, text=True, timeout=240,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    except Exception as e:
+        return {'value': None, 'unit': 'tiles/s', 'cores': usable_cores(), 'kind': 'port', 'sample': f'CPU oracle inference did not finish ({type(e).__name__})'}
+    return {'value': round(1.0 / d['seconds'], 5), 'unit': 'tiles/s', 'cores': d['cores'], 'kind': 'port',
+            'sample': f"1 warm-up + {d['steps']} timed tiles through the fp32 CPU oracle's inference DAG (4 Resnet-9 + 5 UNet-512 + weighted seg sum, one {args.size}x{args.size} tile per "
+                      f"forward as the reference does), {d['total_seconds']:.1f} s of CPU work, {d['seconds']:.1f} s per tile"}
+
+
+def other_workloads(args):
+    """The driver only ever runs `bench.py --gpus 1`: so that BASELINE configs[1] / [3] / [4] and the real 18-network step get driver-timed numbers too, the
+    default run appends a SHORT measurement of each (5 steps, 2 warm-up; a child process per workload, so nothing of it touches the contract line's model or
+    clock).  Each entry is that child's own JSON line reduced to the figures that matter."""
+    import subprocess
+    out = {}
+    for wl in ('infer', 'train18', 'ext', 'wsi'):
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', '5', '--warmup', '2', '--no-strict', '--no-graph', '--no-timer-check', '--no-other-workloads',
+               '--batch', str(args.batch), '--size', str(args.size), '--ngf', str(args.ngf)]
+        if wl != 'infer':
+            cmd.append('--no-cpu-baseline')
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        except Exception as e:
+            out[wl] = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
+            continue
+        rf = d.get('roofline') or {}
+        out[wl] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'], 'dtype': d['dtype'],
+                   'model_tflops': d.get('model_tflops'), 'model_frac_of_bf16_peak': d.get('model_frac_of_bf16_peak'), 'streams': d['config'].get('streams'),
+                   'workload': d['config']['workload'],
+                   'roofline': ({k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'launches_timed', 'avg_launch_us', 'launch_times_from')} if rf else None),
+                   'wall_s': round(time.time() - t0, 1)}
+        for k in ('whole_slide', 'cpu_baseline'):
+            if d.get(k):
+                out[wl][k] = d[k]
+    return out
+
+
 def cpu_baseline(args, batch=None, budget=45.0, half_tile=False):
     """The CPU oracle (a port of the reference's PyTorch training step) timed on this box's host cores: a bounded sample of whole steps at batch
     `batch` (default args.cpu_batch = 1, the reference's default batch size, cli.py:110; SURVEY 8d also asks for the GPU line's per-GPU batch 8 ->
@@ -214,11 +285,17 @@ def main():
                     '8 = the per-GPU batch of the GPU line (SURVEY 8d asks for both), ~2 minutes of CPU work')
     ap.add_argument('--no-cpu-baseline-n8', action='store_true', help='skip the second CPU leg at the per-GPU batch of the GPU line (batch 8: 1 warm-up + up to 3 '
                     'steps inside a 100 s budget, about 2 minutes of CPU work)')
+    ap.add_argument('--no-other-workloads', action='store_true', help='the default train run appends short measurements of the infer / train18 / ext / wsi workloads '
+                    '(other_workloads); this skips them')
+    ap.add_argument('--no-wsi-whole', action='store_true', help='wsi workload: skip the end-to-end pass over the WHOLE region (all tiles + gather of the bands + stitch)')
     ap.add_argument('--cpu-baseline-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-infer-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=45.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.norm, args.size, args.cpu_batch, args.cpu_budget)
+    if args.cpu_infer_child:
+        return cpu_infer_child(args.size)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under torchrun: become `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one process per
@@ -270,6 +347,8 @@ def main():
         sync()
 
     last_batch = {}
+    wsi_state = {'bands': None}
+    whole_slide = None
 
     def build(precision):
         """-> (step function, model or None, GF per tile, dominant conv shape, workload description) for args.workload on `precision`"""
@@ -321,10 +400,8 @@ def main():
         R = args.region
         g = torch.Generator(device=dev).manual_seed(77)
         region = torch.randint(0, 256, (R, R, 3), dtype=torch.uint8, device=dev, generator=g)
-        state = {'bands': None}
-
         def run(limit):
-            state['bands'] = I.infer_region([region], s, s // 16, nets, iopt, seg_weights=sw, batch_size=n, rank=rank, world=world, limit_tiles=limit)
+            wsi_state['bands'] = I.infer_region([region], s, s // 16, nets, iopt, seg_weights=sw, batch_size=n, rank=rank, world=world, limit_tiles=limit)
         return run, None, GF_PER_TILE_INFER, dom, \
             (f'tile-parallel whole-slide inference: synthetic {R}x{R} uint8 region in HBM, tile {s}, overlap {s // 16}, crop + is_empty + 4x Resnet-9block '
              f'+ 5x UNet-512 + uint8 stitch on the GPU, batches of {n} tiles, one band of tile rows per rank (BASELINE configs[4])')
@@ -386,18 +463,46 @@ def main():
         per_rank = min((r1 - r0) * len(plan.xs) for r0, r1 in rows)           # every rank processes the same number of tiles in the timed region
         n_batches = min(args.steps, per_rank // n)
         assert n_batches >= 1, 'region too small for this many ranks'
+        timer = KernelTimer(ops.impl(), dom_shape) if not dry else types.SimpleNamespace(mean_seconds=lambda: None, pairs=[], kernel='?', enabled=False)
         step(n * max(args.warmup, 1))
         barrier()
+        timer.enabled = True
         t0 = time.perf_counter()
         step(n * n_batches)
         barrier()
         dt = time.perf_counter() - t0
+        timer.enabled = False
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         args.steps = n_batches
-        timer = types.SimpleNamespace(mean_seconds=lambda: None, pairs=[], kernel='?')
+        if not args.no_wsi_whole:
+            # configs[4] end to end, once: EVERY tile of this rank's band (crop, is_empty, 9 generators, uint8 paste), then the bands of all ranks gathered on rank 0
+            # (inference.gather_bands) -- the stitched result images exist on rank 0 when the clock stops
+            from deepliif_amd import inference as I2
+            barrier()
+            t0 = time.perf_counter()
+            step(None)
+            local, band = wsi_state['bands']
+            keys = sorted(local.keys()) if local else []
+            if world > 1:
+                allk = [None] * world
+                torch.distributed.all_gather_object(allk, keys)
+                keys = sorted({k for ks in allk for k in ks})
+            full = I2.gather_bands(local, band, args.region, args.region, keys, rank, world)
+            barrier()
+            wdt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([wdt], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                wdt = float(t.item())
+            ntiles = len(plan.ys) * len(plan.xs)
+            whole_slide = {'tiles': ntiles, 'seconds': round(wdt, 3), 'tiles_per_s': round(ntiles / wdt, 2), 'result_images': len(keys),
+                           'what': f'the whole {args.region}x{args.region} region once: every tile of every band (crop + is_empty + 9 generators + uint8 paste), bands gathered on '
+                                   f'rank 0; wall clock between two barriers, max over ranks'}
+            del full, local
+            wsi_state['bands'] = None
     else:
         timer = KernelTimer(ops.impl(), dom_shape) if not dry else types.SimpleNamespace(mean_seconds=lambda: None, pairs=[], kernel='?', enabled=False)
         exch = getattr(model, 'exchange', None) if (model is not None and D.active()) else None
@@ -442,6 +547,29 @@ def main():
     conc_info, dt_solo = None, None
     if n_streams(model) > 1 and not dry and timer.pairs:
         conc_info, dt_solo = solo_pass(step, model, timer)
+    infer_solo = None
+    if args.workload in ('infer', 'wsi') and not dry and timer.pairs:
+        from deepliif_amd import inference as I3
+        if I3._INFER_STREAMS > 1:
+            # the inference DAG runs its chains G_i -> GS_i on DL_INFER_STREAMS streams: as above, launch durations come from one more pass on ONE stream
+            conc_info = (timer.mean_seconds(), timer.median_seconds(), len(timer.pairs))
+            saved_streams, I3._INFER_STREAMS = I3._INFER_STREAMS, 1
+            try:
+                timer.pairs = []
+                if args.workload == 'wsi':
+                    step(n)
+                    barrier()
+                    timer.enabled = True
+                    t0 = time.perf_counter()
+                    step(n * args.steps)
+                    barrier()
+                    dt_solo = time.perf_counter() - t0
+                    timer.enabled = False
+                else:
+                    dt_solo = timed(step, 1, args.steps, timer)
+            finally:
+                I3._INFER_STREAMS = saved_streams
+            infer_solo = saved_streams
     kt = timer.mean_seconds()
     kt_median = timer.median_seconds() if hasattr(timer, 'median_seconds') else kt
 
@@ -544,7 +672,7 @@ def main():
                 roofline['sustained'] = {'error': str(exc)[:200]}
         if conc_info is not None:
             roofline.update({'launch_times_from': f'a second pass of the same {args.steps} steps on ONE stream, per-launch events on ({round(dt_solo / args.steps * 1e3, 3)} ms/step): the timed region '
-                                                  f'runs the independent (G_i, D_i) branches on {n_streams(model)} HIP streams, where the event-bracketed duration of one launch measures the '
+                                                  f'runs the independent branches / chains on {infer_solo or n_streams(model)} HIP streams, where the event-bracketed duration of one launch measures the '
                                                   'share of the GPU it got, not the kernel',
                              'one_stream_ms_per_step': round(dt_solo / args.steps * 1e3, 3),
                              'concurrent_avg_launch_us': round(conc_info[0] * 1e6, 2), 'concurrent_median_launch_us': round(conc_info[1] * 1e6, 2),
@@ -585,7 +713,11 @@ def main():
                              'the oracle by the GPU tests) is timed on the same workload in strict_parity.value')
     if dry:
         out['data'] = 'DRY RUN on CPU through the test emulation backend (launch-path check only; numbers are meaningless)'
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train' and not dry:
+    if whole_slide is not None:
+        out['whole_slide'] = whole_slide
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'infer' and not dry:
+        out['cpu_baseline'] = cpu_baseline_infer(args)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'train' and not dry:
         out['cpu_baseline'] = cpu_baseline(args)
         if not args.no_cpu_baseline_n8 and args.batch != args.cpu_batch:
             # "N=1 (reference default batch_size) and N=8": the same oracle at the GPU line's per-GPU batch.  A batch-8 step at
@@ -596,8 +728,10 @@ def main():
         out['cpu_baseline'] = None
         out['cpu_baseline_note'] = ('disabled by --no-cpu-baseline' if args.no_cpu_baseline else
                                     'only timed on rank 0 of a 1-GPU run' if world != 1 else
-                                    'the CPU oracle leg is implemented for the train workload only (oracle optimize_parameters); '
-                                    'run the default workload for the CPU baseline')
+                                    'the CPU oracle legs are implemented for the train workload (oracle optimize_parameters) and the infer workload (oracle inference DAG)')
+    if rank == 0 and world == 1 and args.workload == 'train' and not dry and not args.no_other_workloads and (n, s, args.ngf) == (8, 512, 64):
+        torch.cuda.empty_cache()
+        out['other_workloads'] = other_workloads(args)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     os.close(json_fd)

@@ -332,11 +332,11 @@ def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, s
     return res
 
 
-_INFER_STREAMS = max(1, int(os.environ.get('DL_INFER_STREAMS', '1')))
+_INFER_STREAMS = max(1, int(os.environ.get('DL_INFER_STREAMS', '3')))
 
 
 def _infer_streams(device):
-    """DL_INFER_STREAMS=N (opt-in, default 1): the independent chains G_i -> GS_i of the DeepLIIF inference DAG on N HIP streams of the calling thread
+    """DL_INFER_STREAMS=N (default 3 since round 5; 1 = everything on the current stream): the independent chains G_i -> GS_i of the DeepLIIF inference DAG on N HIP streams of the calling thread
     (the training step's branch streams, models.BaseModel._branch_streams, applied to run_dask's DAG)"""
     if _INFER_STREAMS <= 1 or device.type != 'cuda':
         return None

@@ -31,9 +31,11 @@ from .distributed import GradExchanger
 # (BaseModel._branch_streams).  Measured r04, same box, 5G+5D step at batch 8: 94.8 ms on one stream, 88.6 on two, 83.8 on three, 84.0 on five -- the
 # ~600 launch-latency-bound kernels of a step, every big kernel's ramp and drain and the HBM-bound norm passes overlap with another branch's MFMA work.
 _N_STREAMS = max(1, int(os.environ.get('DL_STREAMS', '3')))
-# DL_STREAMS_SEG=1 (opt-in this round): branch streams also for the model WITH segmentation generators (the reference's default configuration): chain i =
+# DL_STREAMS_SEG=0 switches off (default on since round 5, the complete GPU suite runs with it): branch streams also for the model WITH segmentation generators (the reference's default configuration): chain i =
 # G_i -> GS_i on its own stream, the seg discriminators and everything that reads the summed seg image on the main stream (DeepLIIFModel.forward)
-_SEG_STREAMS = os.environ.get('DL_STREAMS_SEG', '0') == '1'
+_SEG_STREAMS = os.environ.get('DL_STREAMS_SEG', '1') == '1'
+# DL_STREAMS_EXT=0: DeepLIIFExt / SDG on one stream (round 4); default: their chains G_i -> GS_i (+ D_i, DS_i) on the branch streams as well
+_EXT_STREAMS = os.environ.get('DL_STREAMS_EXT', '1') == '1'
 
 
 def _get(opt, name, default):
@@ -167,10 +169,15 @@ class StepGraph:
         else:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            wst = ops.WS._thread_state()
             try:
-                with torch.cuda.graph(g):
-                    m.set_input(static)
-                    m.optimize_parameters()
+                wst['capturing'] = True             # (ops.Workspace._state: the capture stream keeps this thread's scratch state)
+                try:
+                    with torch.cuda.graph(g):
+                        m.set_input(static)
+                        m.optimize_parameters()
+                finally:
+                    wst['capturing'] = False
             except Exception as exc:
                 # something on the step path still needs the host during the step (e.g. a table that is only complete after another eager step:
                 # the batched weight-repack table grows while data-gradient images appear).  Nothing was executed; run this step -- and all later
@@ -179,6 +186,9 @@ class StepGraph:
                 where = [l.strip() for l in traceback.format_exc().splitlines() if 'deepliif_amd' in l and 'StepGraph' not in l][-1:]
                 self.why_eager = f'capture failed: {str(exc).splitlines()[0][:160]} {where}'
                 print(f'deepliif_amd: StepGraph runs eagerly: {self.why_eager}')
+                abandon = getattr(ops.impl(), 'wgrad_abandon', None)
+                if abandon is not None:
+                    abandon()                        # weight gradients recorded by the aborted pass never ran: nothing of them may be reduced later
                 for o in m.optimizers:               # back to the scalar-argument Adam kernel (same arithmetic); prepare_step() had counted this step
                     o.hyper_dev, o._prepared = None, False
                     o.step_count -= 1
@@ -278,13 +288,17 @@ class BaseModel:
                 ops.WS.branch_streams_on(self._streams)
         return self._streams
 
-    def _fork(self):
-        """start of a phase: every branch stream waits for what the main stream has issued so far (inputs, zeroed gradients, repacked weights)"""
+    def _fork(self, tape=None):
+        """start of a phase: every branch stream waits for what the main stream has issued so far (inputs, zeroed gradients, repacked weights).
+        With a tape the fork is a point INSIDE a recorded pass (branches consume a main-stream result): its mirror image is recorded, so that in
+        backward the main stream waits for every branch there before it runs the nodes recorded in front of this point."""
         streams = self._branch_streams()
         if streams:
             main = torch.cuda.current_stream()
             for s in streams:
                 s.wait_stream(main)
+            if tape is not None:
+                tape.record(self._join)
 
     def _join(self, tape=None):
         """end of a phase: the main stream (optimizer step, loss read-out) waits for every branch.  With a tape the join is a point INSIDE a recorded pass
@@ -788,6 +802,13 @@ class DeepLIIFExtModel(BaseModel):
             self.optimizers += [self.optimizer_G, self.optimizer_D]
             self.exchange = GradExchanger()
         self._tape_G = None
+        # branch streams (round 5): chain i = G_i -> [cat(A, fake_1, fake_i) on the main stream] -> GS_i, with D_i / DS_i, runs on stream i % DL_STREAMS.
+        # The only tensor two chains share is fake_1 (every seg generator's input, DeepLIIFExt_model.py:173): the concatenations -- and in backward the
+        # accumulation of its gradient -- stay on the main stream between a join and a fork.  SDG's VGG term keeps everything on one stream (branch_parallel).
+
+    @property
+    def branch_parallel(self):
+        return _EXT_STREAMS and getattr(self, 'criterionVGG', None) is None
 
     def _input_channels(self, opt):
         return opt.input_nc
@@ -811,19 +832,28 @@ class DeepLIIFExtModel(BaseModel):
 
     def forward(self, record=None):
         record = self.is_train if record is None else record
-        tape = E.Tape() if record else None
+        tape = self._new_tape() if record else None
         ctx = E.Ctx(self.precision, self._hook_tape(tape), training=record)
-        self._fake = []
-        for net in self.netG:
-            self._mark_net(tape, net)
-            self._fake.append(net.run(ctx, self._A))
-        self.fake_B = [E.from_engine(f) for f in self._fake]
-        self._fake_s = []
-        for i, net in enumerate(self.netGS):
-            if net is not None:
+        self._fake, self.fake_B = [], []
+        self._fork()
+        for i, net in enumerate(self.netG):
+            with self._branch(i):
                 self._mark_net(tape, net)
-                self._fake_s.append(net.run(ctx, E.concat_channels(ctx, [self._A, self._fake[0], self._fake[i]])))
-        self.fake_BS = [E.from_engine(f) for f in self._fake_s]
+                self._fake.append(net.run(ctx, self._A))
+                self.fake_B.append(E.from_engine(self._fake[-1]))
+        self._fake_s, self.fake_BS = [], []
+        if any(n is not None for n in self.netGS):
+            self._join(tape)                         # fake_1 feeds every seg generator: concatenate on the main stream ...
+            cats = [E.concat_channels(ctx, [self._A, self._fake[0], self._fake[i]]) if net is not None else None for i, net in enumerate(self.netGS)]
+            self._fork(tape)                         # ... and let chain i continue on its stream
+            for i, net in enumerate(self.netGS):
+                if net is not None:
+                    with self._branch(i):
+                        self._mark_net(tape, net)
+                        self._fake_s.append(net.run(ctx, cats[i]))
+                        self.fake_BS.append(E.from_engine(self._fake_s[-1]))
+        if not record:
+            self._join()
         for i, t in enumerate(self.fake_B):
             setattr(self, f'fake_B_{i + 1}', t)
         for i, t in enumerate(self.fake_BS):
@@ -836,46 +866,60 @@ class DeepLIIFExtModel(BaseModel):
         return self._real_cat
 
     def backward_D(self):
-        tape = E.Tape()
+        tape = self._new_tape()
         ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
         cg, cs, M = self.criterionGAN_mod, self.criterionGAN_seg, self.mod_gen_no
-        for net in self._d_nets():
-            self._mark_net(tape, net)
-        rc = self._cat_real(ctx)
+        rc = self._cat_real(ctx)                     # (main stream, before the fork)
+        self._fork()                                 # (the gradients were zeroed on the main stream)
         for i in range(M):
-            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i].detach()]))
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * self.loss_D_weights[i], self._slot(f'D_fake_{i + 1}'))
+            with self._branch(i):
+                # every discriminator runs twice below (fake, real): mark before the first use, on the stream of its branch (the marker's all-reduce is
+                # ordered behind THAT stream)
+                self._mark_net(tape, self.netD[i])
+                pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i].detach()]))
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * self.loss_D_weights[i], self._slot(f'D_fake_{i + 1}'))
         for i in range(len(self._fake_s)):
-            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i].detach()]))
-            E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_fake_{i + 1}'))
+            with self._branch(i):
+                self._mark_net(tape, self.netDS[i])
+                pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i].detach()]))
+                E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_fake_{i + 1}'))
         for i in range(M):
-            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._B[i]]))
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * self.loss_D_weights[i], self._slot(f'D_real_{i + 1}'))
+            with self._branch(i):
+                pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._B[i]]))
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * self.loss_D_weights[i], self._slot(f'D_real_{i + 1}'))
         for i in range(len(self._fake_s)):
-            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._BS[i]]))
-            E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_real_{i + 1}'))
+            with self._branch(i):
+                pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._BS[i]]))
+                E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * self.loss_DS_weights[i], self._slot(f'DS_real_{i + 1}'))
         tape.backward()
+        self._join()
 
     def backward_G(self):
         tape = self._tape_G
         ctx = E.Ctx(self.precision, self._hook_tape(tape), training=True)
         cg, M = self.criterionGAN_mod, self.mod_gen_no
         rc = self._cat_real(E.Ctx(self.precision, None, training=True))
+        self._fork()                                 # (D was updated and repacked, the G gradients zeroed, on the main stream)
         for i in range(M):
-            pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i]]))
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_G_weights[i], self._slot(f'G_GAN_{i + 1}'))
+            with self._branch(i):
+                pred = self.netD[i].run(ctx, E.concat_channels(ctx, [self._A, self._fake[i]]))
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_G_weights[i], self._slot(f'G_GAN_{i + 1}'))
         for i in range(len(self._fake_s)):
-            pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i]]))
-            E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_GS_weights[i], self._slot(f'GS_GAN_{i + 1}'))   # criterionGAN_mod (:236)
+            with self._branch(i):
+                pred = self.netDS[i].run(ctx, E.concat_channels(ctx, [rc[i], self._fake_s[i]]))
+                E.loss_op(ctx, cg.kind, pred, None, cg.target(True), self.loss_GS_weights[i], self._slot(f'GS_GAN_{i + 1}'))   # criterionGAN_mod (:236)
         for i in range(M):
-            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, self.loss_G_weights[i] * self.lambda_L1, self._slot(f'G_L1_{i + 1}'))
+            with self._branch(i):
+                E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake[i], self._B[i], 0.0, self.loss_G_weights[i] * self.lambda_L1, self._slot(f'G_L1_{i + 1}'))
         for i in range(len(self._fake_s)):
-            E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_s[i], self._BS[i], 0.0, self.loss_GS_weights[i] * self.lambda_L1, self._slot(f'GS_L1_{i + 1}'))
+            with self._branch(i):
+                E.loss_op(ctx, L.LOSS_SMOOTH_L1, self._fake_s[i], self._BS[i], 0.0, self.loss_GS_weights[i] * self.lambda_L1, self._slot(f'GS_L1_{i + 1}'))
         vgg = getattr(self, 'criterionVGG', None)
         if vgg is not None:                           # SDG_model.py:176-184 (DeepLIIFExt has the term commented out, DeepLIIFExt_model.py:257-265)
             for i in range(M):
                 vgg.run(ctx, self._fake[i], self._B[i], self.loss_G_weights[i] * self.lambda_feat, self._slot(f'G_VGG_{i + 1}'))
         tape.backward()
+        self._join()
         self._tape_G = None
         # index tensors built ONCE: torch.tensor(..., device=cuda) is a host-to-device copy per step (and not capturable, models.StepGraph)
         if not hasattr(self, '_idx_cache'):

@@ -86,7 +86,9 @@ class Workspace:
         streams of one thread run concurrently on the GPU, so they may not share a slab, a statistics workspace or a slab arena"""
         st = self._thread_state()
         ids = self._branch_ids
-        if ids:
+        # (while models.StepGraph captures -- one stream by construction -- the capture stream keeps the thread's state whatever its handle: torch hands out
+        # POOLED streams, 32 per device, so the capture stream can carry the handle of a branch stream some earlier model registered)
+        if ids and not st.get('capturing'):
             s = torch.cuda.current_stream()
             if s.cuda_stream in ids:           # (any other stream -- torch's default stream, a graph-capture stream -- keeps the thread's own state, as before)
                 sub = st.setdefault('streams', {}).get(s.cuda_stream)
@@ -355,6 +357,15 @@ class HipBackend:
                 self.wgrad_flush_all()
         finally:
             st['defer_depth'] = max(0, st.get('defer_depth', 0) - 1)
+
+    def wgrad_abandon(self):
+        """forget everything queued / pending on this thread WITHOUT launching (models.StepGraph: a capture that failed half-way recorded weight gradients whose
+        kernels never ran; reducing their slabs later would add garbage to the gradients)"""
+        st = WS._thread_state()
+        for sub in [st] + WS.stream_states():
+            sub['defer_pending'], sub['defer_queue'], sub['defer_blocks'], sub['defer_off'] = [], [], 0, 0
+            sub['defer_grads'] = set()
+        st['defer_depth'] = 0
 
     def wgrad_flush_all(self):
         """wgrad_flush() on every stream of this thread that has slabs pending (each batch is launched on the stream that wrote its slabs)"""

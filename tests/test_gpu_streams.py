@@ -53,14 +53,37 @@ def test_branch_streams_are_bit_identical_to_one_stream(nstreams, precision, mon
         assert torch.equal(a, b)
 
 
-def test_models_with_dependent_branches_stay_on_one_stream(monkeypatch):
+def test_switches_keep_dependent_models_on_one_stream(monkeypatch):
     monkeypatch.setattr(M, '_N_STREAMS', 3)
-    seg = _build('train18', 'bf16')                   # segmentation generators read the other branches' outputs
+    monkeypatch.setattr(M, '_SEG_STREAMS', False)
+    monkeypatch.setattr(M, '_EXT_STREAMS', False)
+    seg = _build('train18', 'bf16')                   # segmentation generators read the other branches' outputs: DL_STREAMS_SEG=0 keeps round 3's single stream
     assert seg.branch_parallel is False and seg._branch_streams() is None
     ext = _build('ext', 'bf16')
-    assert not getattr(ext, 'branch_parallel', False) and ext._branch_streams() is None
+    assert not ext.branch_parallel and ext._branch_streams() is None
     sg = M.StepGraph(_build('train', 'bf16'))
     assert sg.why_eager and 'streams' in sg.why_eager
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+@pytest.mark.parametrize('nstreams', [2, 3])
+def test_ext_model_chains_on_streams_are_bit_identical(nstreams, precision, monkeypatch):
+    """DeepLIIFExt (round 5): chain i = G_i -> GS_i (+ D_i, DS_i) on stream i % N; fake_1 feeds EVERY seg generator (DeepLIIFExt_model.py:173), so the
+    concatenations and -- in backward -- the accumulation of its gradient stay on the main stream between a recorded join and a recorded fork.  2 G + 2 GS
+    + 2 D + 2 DS at fixture width, both policies: losses, parameters and images bit-identical to one stream."""
+    batches = _batches('ext', 2, 64, 3, 2)
+    monkeypatch.setattr(M, '_N_STREAMS', 1)
+    ref = _run(_build('ext', precision), batches)
+    monkeypatch.setattr(M, '_N_STREAMS', nstreams)
+    monkeypatch.setattr(M, '_EXT_STREAMS', True)
+    model = _build('ext', precision)
+    assert model.branch_parallel
+    got = _run(model, batches)
+    assert model._streams is not None and len(model._streams) == nstreams
+    assert got[0] == ref[0]
+    assert torch.equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        assert torch.equal(a, b)
 
 
 def test_branch_streams_under_the_gradient_exchange(monkeypatch):
@@ -92,7 +115,7 @@ def test_branch_streams_under_the_gradient_exchange(monkeypatch):
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
 @pytest.mark.parametrize('nstreams', [3, 5])
 def test_seg_model_chains_on_streams_are_bit_identical(nstreams, precision, monkeypatch):
-    """DL_STREAMS_SEG=1 (opt-in): the model WITH segmentation generators -- chain i = G_i -> GS_i (+ D_i) on its own stream, GS_0 on the next one, the seg
+    """DL_STREAMS_SEG (default on since round 5): the model WITH segmentation generators -- chain i = G_i -> GS_i (+ D_i) on its own stream, GS_0 on the next one, the seg
     discriminators and the summed seg image on the main stream; the join in front of the weighted sum is a tape node whose backward makes every branch
     wait for the seg image's gradient.  4 G + 5 GS + 4 D + 5 DS at fixture width, BatchNorm, both policies: bit-identical to one stream."""
     batches = _batches('train18', 2, 64, 3, 5)

@@ -92,7 +92,27 @@ def test_w4_channel_slice_operands(be):
     assert float((grad.double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_strict_layers_are_not_queued(be, monkeypatch):
+    """the batch is the w4 kernel's (ops.HipBackend.conv_wgrad: measured, the strict glds_x3 kernel gains nothing from it): a strict ResnetBlock layer inside a
+    pass launches its split-K kernel at once and only its reduction is deferred"""
+    monkeypatch.setattr(ops, '_WGRAD_BATCH', True)
+    monkeypatch.setattr(ops, '_WGRAD_DEFER', True)
+    P, Q = _ops(2, 16, 256, 256, 7, torch.float32)
+    g = torch.zeros(256, 256, 3, 3, device=DEV)
+    ref = torch.zeros_like(g)
+    be.conv_wgrad(P, Q, ref, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, L.PREC_BF16X3, False)
+    be.wgrad_defer_begin()
+    be.conv_wgrad(P, Q, g, 3, 1, 1, L.PAD_ZERO, L.ACT_NONE, L.ACT_NONE, L.PREC_BF16X3, False)
+    st = ops.WS._state()
+    assert not st.get('defer_queue') and len(st['defer_pending']) == 1
+    be.wgrad_defer_end()
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    r64 = _reference(P, Q)
+    assert float((g.double() - r64).abs().max() / r64.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('precision', ['bf16'])
 def test_batched_launch_is_bit_identical_to_single_launches(be, precision, monkeypatch):
     dtype, prec = (torch.bfloat16, L.PREC_BF16) if precision == 'bf16' else (torch.float32, L.PREC_BF16X3)
     n, h, ca, cb, layers = 2, 16, 256, 256, 5

@@ -17,6 +17,9 @@ data = os.environ.get('TIME_DATA', 'randn')       # randn | zero | bf16 (fp32 va
 w = torch.randn(256, 256, 3, 3, device=DEV) * 0.02
 x = torch.randn(8, 128, 128, 256, device=DEV).to(prec.dtype)
 dy = torch.randn(8, 128, 128, 256, device=DEV).to(prec.dtype)
+if data == 'halfzero':          # what a data gradient really reads behind a ReLU: about half of dL/dy is exactly zero (r05: the fwd / dgrad asymmetry)
+    x = x * (torch.rand_like(x.float()) < 0.5).to(x.dtype)
+    dy = dy * (torch.rand_like(dy.float()) < 0.5).to(dy.dtype)
 if data == 'zero':
     w, x, dy = w * 0, x * 0, dy * 0
 elif data == 'bf16':
@@ -52,6 +55,11 @@ def timeit(fn, iters=20, warm=3):
 res = {}
 if 'fwd' in which:
     res['fwd_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, **KW)); res['fwd_kernel'] = be.last_conv_kernel
+if 'fwdstats' in which:          # the forward as the step launches it: bias + fused norm statistics in the store epilogue
+    bias = torch.randn(256, device=DEV)
+    res['fwd_bias_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, bias, 0, 0, prec.prec, **KW))
+    res['fwd_bias_stats_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, bias, 0, 0, prec.prec, want_stats=True, **KW))
+    res['fwd_stats_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, want_stats=True, **KW))
 if 'dgrad' in which:
     res['dgrad_us'] = timeit(lambda: be.conv_forward(pd, dy, out, 128, 128, None, 0, 0, prec.prec, **KW))
 if 'wgrad' in which:
