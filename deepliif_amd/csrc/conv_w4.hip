@@ -49,7 +49,7 @@ constexpr int W4_BUF = 256 * 128;                     // one weight buffer (256 
 constexpr int W4_X0 = 1 * W4_BUF;                     // slab s at W4_X0 + s * W4_BUF
 __host__ __device__ constexpr int w4_wofs(int b) { return b == 0 ? 0 : (b == 1 ? 3 * W4_BUF : 4 * W4_BUF); }
 constexpr size_t W4_LOOP_LDS = (size_t)5 * W4_BUF;
-constexpr size_t W4_EPI_LDS = (size_t)256 * 512 + 256 * sizeof(int) + (size_t)2 * 2 * 256 * sizeof(float);
+constexpr size_t W4_EPI_LDS = (size_t)256 * 512 + 256 * sizeof(int) + (size_t)2 * 2 * 256 * sizeof(float) + 256 * sizeof(float);
 constexpr size_t W4_LDS = W4_LOOP_LDS > W4_EPI_LDS ? W4_LOOP_LDS : W4_EPI_LDS;
 static_assert(W4_LDS <= 160 * 1024, "the whole LDS of a CU");
 
@@ -353,6 +353,10 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     lds_char_t *tile = lds;                                                         // [256 pixels][256 channels] bf16, 8-byte units XOR-swizzled by the pixel
     __attribute__((address_space(3))) int *rowtab = reinterpret_cast<__attribute__((address_space(3))) int *>(lds + 256 * 512);
     __attribute__((address_space(3))) float *red = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4);       // [wm][2][256]
+    // the tile's 256 bias values go through LDS (r05): fetched inside the accumulator loop below, hipcc had made them four guarded dword loads and an
+    // s_waitcnt vmcnt(0) per (i, q) -- sixteen global round trips in a row in front of the stores (isolated forward launch with bias: 138.9-156.1 us against
+    // 133.5-133.8 without, profiles/r05/kd_bisect_asymmetry_serialize.txt).  (64 registers of preloaded float4s instead made the allocator spill in this kernel.)
+    __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 4 * 256 * 4);
     const bool want_stats = a.stats_part != nullptr;
     {
         const int m = m0 + tid;
@@ -363,18 +367,16 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
             opix = (n * a.Ho + hq) * a.Wo + wq;
         }
         rowtab[tid] = opix;
+        const int cb = tn * 256 + tid;
+        bias_lds[tid] = (a.bias && cb < a.bias_n) ? a.bias[cb] : 0.f;
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = wn * 128 + i * 32 + q * 8 + lh * 4;           // channel inside the tile
-            const int co = tn * 256 + cl;
-            float bias[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bias[e] = (co + e < a.bias_n) ? a.bias[co + e] : 0.f;
-            }
+            const f32x4_t bias = *reinterpret_cast<__attribute__((address_space(3))) const f32x4_t *>(bias_lds + cl);
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
             const int unit = (cl >> 2) ^ (((lr & 15) << 1) & 62);
             lds_char_t *dst = tile + (wm * 128 + lr) * 512 + unit * 8;

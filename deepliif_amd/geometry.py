@@ -192,6 +192,21 @@ def choose_splitk(plan: GatherPlan, n: int, hq: int, wq: int, co_pad: int, targe
 
 def fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, ho: int, wo: int, out_cp: int, out_pstride: int,
                    hq: int, wq: int, dtype: int, prec: int, act: int, in_act: int, bias_n: int, splitk: int, raw_out: int = 0) -> L.ConvDesc:
+    """the dl_conv_desc of one launch.  Filling ~70 ctypes fields (9-49 taps) from Python costs 10-24 us -- about a tenth of the host time of a training step
+    (r05, tools/host_profile.py) -- and a layer launches with the same geometry every step: the filled descriptor is kept on the plan and every call gets its own
+    COPY (0.5 us; callers set in_split / splitk on it)."""
+    key = (n, hi, wi, in_pstride, ho, wo, out_cp, out_pstride, hq, wq, dtype, prec, act, in_act, bias_n, splitk, raw_out)
+    cache = plan.__dict__.setdefault('_desc_cache', {})
+    d = cache.get(key)
+    if d is None:
+        if len(cache) > 64:
+            cache.clear()
+        d = cache[key] = _fill_conv_desc(plan, *key)
+    return L.ConvDesc.from_buffer_copy(d)
+
+
+def _fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int, ho: int, wo: int, out_cp: int, out_pstride: int,
+                    hq: int, wq: int, dtype: int, prec: int, act: int, in_act: int, bias_n: int, splitk: int, raw_out: int = 0) -> L.ConvDesc:
     d = L.ConvDesc()
     d.N, d.Hi, d.Wi, d.Ci, d.in_pstride = n, hi, wi, plan.cc_pad, in_pstride
     d.Ho, d.Wo, d.Co, d.out_pstride = ho, wo, out_cp, out_pstride

@@ -62,6 +62,18 @@ _NO_NARROW_ROLL = os.environ.get('DL_NO_NARROW_ROLL', '0') == '1'      # A/B swi
 _SHARED_STATE: dict = {}
 
 
+# The raw handle of torch's current HIP stream, asked from torch's C layer directly: torch.cuda.current_stream() builds a Stream object and resolves the device
+# index through is_available() / os.environ on every call -- ~7 us, several times per launch, 4-5 ms of host time per training step (r05, tools/host_profile.py).
+# (tests that replace torch.cuda.current_stream by a recorder switch the shortcut off)
+_FAST_STREAM = hasattr(torch._C, '_cuda_getCurrentRawStream') and hasattr(torch._C, '_cuda_getDevice')
+
+
+def _current_stream_handle(dev_index=None) -> int:
+    if _FAST_STREAM and torch.cuda.is_initialized():
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if dev_index is None else dev_index)
+    return torch.cuda.current_stream(dev_index).cuda_stream if dev_index is not None else torch.cuda.current_stream().cuda_stream
+
+
 class Workspace:
     """Grow-only fp32 scratch buffers, one per purpose AND PER THREAD.  Within a thread all kernels run in stream order, so a buffer
     can be reused by the next call of the same kind.  Across threads nothing may be shared: one C call launches e.g. the split-K conv
@@ -89,11 +101,11 @@ class Workspace:
         # (while models.StepGraph captures -- one stream by construction -- the capture stream keeps the thread's state whatever its handle: torch hands out
         # POOLED streams, 32 per device, so the capture stream can carry the handle of a branch stream some earlier model registered)
         if ids and not st.get('capturing'):
-            s = torch.cuda.current_stream()
-            if s.cuda_stream in ids:           # (any other stream -- torch's default stream, a graph-capture stream -- keeps the thread's own state, as before)
-                sub = st.setdefault('streams', {}).get(s.cuda_stream)
+            h = _current_stream_handle()
+            if h in ids:                       # (any other stream -- torch's default stream, a graph-capture stream -- keeps the thread's own state, as before)
+                sub = st.setdefault('streams', {}).get(h)
                 if sub is None:
-                    sub = st['streams'][s.cuda_stream] = {'stream_obj': s}
+                    sub = st['streams'][h] = {'stream_obj': torch.cuda.current_stream()}
                 st = sub
         if 'bufs' not in st:
             st['bufs'], st['norm_ws_token'] = {}, 0
@@ -156,10 +168,10 @@ def _stream(t: Optional[torch.Tensor] = None):
     torch.cuda.set_device(gpu_ids[0]) once, cli.py:250-256; the model classes here do the same in BaseModel.__init__)."""
     dev = t.device if t is not None else getattr(_LAUNCH, 'dev', None)
     if dev is None:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    if dev.index is not None and dev.index != torch.cuda.current_device():
+        return C.c_void_p(_current_stream_handle())
+    if dev.index is not None and dev.index != (torch._C._cuda_getDevice() if _FAST_STREAM else torch.cuda.current_device()):
         torch.cuda.set_device(dev)
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return C.c_void_p(_current_stream_handle(dev.index))
 
 
 def _need_cuda(*ts):
@@ -181,7 +193,13 @@ class HipBackend:
 
     def __init__(self):
         self.lib = L.load()
-        self.last_conv_kernel = ''
+        self._last_conv_desc = None
+
+    @property
+    def last_conv_kernel(self) -> str:
+        """name of the kernel the last dl_conv_forward of this backend dispatched to (dl_conv_kernel_name)"""
+        d = self._last_conv_desc
+        return '' if d is None else self.lib.dl_conv_kernel_name(C.byref(d)).decode()
 
     def norm_ws_token(self) -> int:
         return WS.norm_token()           # bumped whenever this thread's 'norm_ws' workspace is overwritten
@@ -258,7 +276,7 @@ class HipBackend:
                 splitk = 1
             else:
                 d.splitk = splitk
-        self.last_conv_kernel = self.lib.dl_conv_kernel_name(C.byref(d)).decode()      # diagnostic (bench.py roofline label)
+        self._last_conv_desc = d          # diagnostic (bench.py roofline label): the kernel name is asked from the library only when somebody reads last_conv_kernel
         slab = WS.get('conv_slab', splitk * n * ho * wo * cop, x.device) if splitk > 1 else None
         nch, part = 0, None
         if want_stats:

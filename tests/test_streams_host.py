@@ -31,6 +31,7 @@ class FakeStream:
 def fake_cuda(monkeypatch):
     state = {'cur': FakeStream(0), 'log': []}
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda device=None: state['cur'])
+    monkeypatch.setattr(ops, '_FAST_STREAM', False)            # (ops asks torch's C layer for the raw stream handle; here the recorder above must answer)
 
     def set_stream(s):
         state['log'].append(s)
