@@ -353,9 +353,10 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     lds_char_t *tile = lds;                                                         // [256 pixels][256 channels] bf16, 8-byte units XOR-swizzled by the pixel
     __attribute__((address_space(3))) int *rowtab = reinterpret_cast<__attribute__((address_space(3))) int *>(lds + 256 * 512);
     __attribute__((address_space(3))) float *red = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4);       // [wm][2][256]
-    // the tile's 256 bias values go through LDS (r05): fetched inside the accumulator loop below, hipcc had made them four guarded dword loads and an
-    // s_waitcnt vmcnt(0) per (i, q) -- sixteen global round trips in a row in front of the stores (isolated forward launch with bias: 138.9-156.1 us against
-    // 133.5-133.8 without, profiles/r05/kd_bisect_asymmetry_serialize.txt).  (64 registers of preloaded float4s instead made the allocator spill in this kernel.)
+    // the tile's 256 bias values reach the accumulator pass through LDS (r05): fetched inside the pass, hipcc had made them four guarded dword loads and an
+    // s_waitcnt vmcnt(0) per (i, q); 64 registers of preloaded float4s made the allocator spill.  A forward launch WITH a bias still measures 9-12 us more than
+    // one without (isolated: 141.8 vs 129.2 us; the same whether the values come from guarded dword loads, from LDS, or from a register filled before the K
+    // loop -- profiles/r05/epilogue_bias_hostprofile.txt, w4_epilogue_variants.txt): not the fetch; unexplained
     __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 4 * 256 * 4);
     const bool want_stats = a.stats_part != nullptr;
     {
@@ -371,50 +372,60 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
         bias_lds[tid] = (a.bias && cb < a.bias_n) ? a.bias[cb] : 0.f;
     }
     __syncthreads();
+    // the two run-time choices of this pass (ReLU, statistics) as COMPILE-TIME flags of four copies of it (r05): tested per (i, q, j) they had cut the pass into
+    // ~130 basic blocks of a dozen instructions, each behind a scalar branch
+    auto acc_pass = [&](auto RELUc, auto STATSc) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(RELUc)::value != 0, STATS = decltype(STATSc)::value != 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cl = wn * 128 + i * 32 + q * 8 + lh * 4;           // channel inside the tile
-            const f32x4_t bias = *reinterpret_cast<__attribute__((address_space(3))) const f32x4_t *>(bias_lds + cl);
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            const int unit = (cl >> 2) ^ (((lr & 15) << 1) & 62);
-            lds_char_t *dst = tile + (wm * 128 + lr) * 512 + unit * 8;
+            for (int q = 0; q < 4; ++q) {
+                const int cl = wn * 128 + i * 32 + q * 8 + lh * 4;           // channel inside the tile
+                const f32x4_t bias = *reinterpret_cast<__attribute__((address_space(3))) const f32x4_t *>(bias_lds + cl);
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                const int unit = (cl >> 2) ^ (((lr & 15) << 1) & 62);
+                lds_char_t *dst = tile + (wm * 128 + lr) * 512 + unit * 8;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] + bias[e];
-                if (a.act == DL_ACT_RELU) {
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] + bias[e];
+                    if constexpr (RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    u32x2_t p;
+                    p[0] = pack2_bf16(v[0], v[1]);
+                    p[1] = pack2_bf16(v[2], v[3]);
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x2_t *>(dst + j * 32 * 512) = p;
+                    if constexpr (STATS) {          // statistics of exactly what is stored (bf16-rounded), like the stand-alone kernel sees
+                        const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
+                        const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                        s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
+                        s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
+                    }
                 }
-                u32x2_t p;
-                p[0] = pack2_bf16(v[0], v[1]);
-                p[1] = pack2_bf16(v[2], v[3]);
-                *reinterpret_cast<__attribute__((address_space(3))) u32x2_t *>(dst + j * 32 * 512) = p;
-                if (want_stats) {          // statistics of exactly what is stored (bf16-rounded), like the stand-alone kernel sees
-                    const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                    const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
-                    s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
-                    s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
-                }
-            }
-            if (want_stats) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1[e] = w4_row16_sum(s1[e]); s2[e] = w4_row16_sum(s2[e]);
-                    s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
-                }
-                if (lr == 0) {
+                if constexpr (STATS) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        red[(wm * 2 + 0) * 256 + cl + e] = s1[e];
-                        red[(wm * 2 + 1) * 256 + cl + e] = s2[e];
+                        s1[e] = w4_row16_sum(s1[e]); s2[e] = w4_row16_sum(s2[e]);
+                        s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
+                    }
+                    if (lr == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            red[(wm * 2 + 0) * 256 + cl + e] = s1[e];
+                            red[(wm * 2 + 1) * 256 + cl + e] = s2[e];
+                        }
                     }
                 }
             }
-        }
+    };
+    if (want_stats) {
+        if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}, W4IC<1>{}); else acc_pass(W4IC<0>{}, W4IC<1>{});
+    } else {
+        if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}, W4IC<0>{}); else acc_pass(W4IC<0>{}, W4IC<0>{});
+    }
     __syncthreads();
     bf16_t *out = reinterpret_cast<bf16_t *>(a.out);
 #pragma unroll 4

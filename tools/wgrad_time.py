@@ -58,12 +58,14 @@ def timeit(fn, iters=6, warm=2):
 gf = 2 * 8 * 128 * 128 * 256 * 2304 / 1e9
 res = {'precision': prec.name, 'layers': NL, 'split_copies': SPLIT,
        'env': {k: v for k, v in os.environ.items() if k.startswith('DL_')}}
-for name, fn in (('immediate_us_per_layer', immediate), ('deferred_reduce_us_per_layer', lambda: one_pass(False)), ('batched_us_per_layer', lambda: one_pass(True))):
+ONLY = os.environ.get('TIME_ONLY')          # e.g. batched: a PMC pass over the batched launch alone
+for name, fn in [v for v in (('immediate_us_per_layer', immediate), ('deferred_reduce_us_per_layer', lambda: one_pass(False)), ('batched_us_per_layer', lambda: one_pass(True))) if not ONLY or v[0].startswith(ONLY)]:
     us = timeit(fn)
     res[name] = round(us, 1)
     res[name.replace('_us_per_layer', '_tf')] = round(gf / us * 1e3, 1)
-ref = [g.clone() for g in grads]
-one_pass(False)
-torch.cuda.synchronize()
-res['batched_vs_single_max_rel'] = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(ref, grads))
+if not ONLY:
+    ref = [g.clone() for g in grads]
+    one_pass(False)
+    torch.cuda.synchronize()
+    res['batched_vs_single_max_rel'] = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(ref, grads))
 print(json.dumps(res))
