@@ -41,7 +41,7 @@ GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 +
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 STRICT_PMC_FILE = os.path.join('r03', 'pmc_strict_conv256.json')     # the same passes over the strict ResnetBlock kernel (tools/gpu_r03_pmc_strict.sh)
-PMC_FILE = os.path.join('r04', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
+PMC_FILE = os.path.join('r05', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
 def make_opt(args, device_index, M=5, seg_gen=False):
@@ -452,7 +452,7 @@ def main():
                 img_err = max(img_err, float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30)))
         loss_err = max(abs(la[k] - lb[k]) / max(abs(lb[k]), 1e-3) for k in la)
         strict = {'dtype': 'f32 storage, split-bf16x3 MFMA (fp32-class products)', 'asserted_vs_oracle': 'network outputs / step-0 losses <= 1e-3 '
-                  '(tests/test_gpu_networks.py, profiles/parity_errors_r04.json)',
+                  '(tests/test_gpu_networks.py, tests/test_gpu_fullsize_step.py: the benched step itself; profiles/parity_errors_r05.json)',
                   'headline_vs_strict': {'what': f'{args.precision} policy vs strict policy, same weights, this batch, before any update',
                                          'generated_images_max_abs_over_max': round(img_err, 6), 'losses_max_rel': round(float(loss_err), 6)}}
 
@@ -653,7 +653,7 @@ def main():
             same = (n, s, args.precision, args.ngf) == (8, 512, 'bf16', 64) and dom_kernel != '?' and dom_kernel.split('<')[0] in pmc.get('kernel', '')
             traffic = pmc['traffic_bytes'] if same else None
             traffic_note = (f'NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same kernel and shape '
-                            f'(profiles/{PMC_FILE}, collected with tools/gpu_r04_pmc.sh on forward launches only)') if same else None
+                            f'(profiles/{PMC_FILE}, collected with tools/gpu_r05_pmc.sh on forward launches only)') if same else None
     except Exception:
         traffic = None
     if kt:

@@ -7,6 +7,8 @@ ConvTranspose2d weight IOHW = src[A=in][B=out][kh][kw].
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
@@ -227,6 +229,10 @@ def _fill_conv_desc(plan: GatherPlan, n: int, hi: int, wi: int, in_pstride: int,
 
 
 NUM_CUS = 256      # MI355X
+# experiment switches (r05): share of the chip one weight-gradient launch is sized for -- a smaller share means fewer split-K partials (slab bytes ~ share x 67 MB
+# per launch whatever the layer), more K steps per workgroup, and relies on the other branch streams to fill the remaining CUs
+WGRAD_FILL = float(os.environ.get('DL_WGRAD_FILL', '1.0'))               # one layer per launch (choose_wgrad_splitk, fast path)
+WGRAD_BATCH_FILL = float(os.environ.get('DL_WGRAD_BATCH_FILL', '0.3333'))    # a layer inside a batch (choose_wgrad_batch_splitk)
 
 
 def wgrad_fast_path(cap: int, j: int, bf16: bool, no_act: bool, zero_pad: bool, strict: bool = False, strict_act_ok: bool = True) -> bool:
@@ -242,9 +248,10 @@ def choose_wgrad_splitk(cap: int, j: int, ptot: int, fast: bool = False, target_
         # 8-wave kernel: one workgroup per CU (248 VGPRs) -> the grid must not exceed one round of 256 CUs by a few blocks
         ba = 256 if cap % 256 == 0 else 128
         tiles = (cap // ba) * ((j + 255) // 256)
-        if tiles >= NUM_CUS:
+        cus = max(1, int(NUM_CUS * WGRAD_FILL))
+        if tiles >= cus:
             return 1
-        return max(1, min(NUM_CUS // tiles, ptot // 128, max_split))
+        return max(1, min(cus // tiles, ptot // 128, max_split))
     ba = 16 if cap <= 16 else (64 if cap <= 64 else 128)
     tiles = ((cap + ba - 1) // ba) * ((j + 127) // 128)
     sk = min(max_split, (target_blocks + tiles - 1) // tiles, max(1, ptot // 64))
@@ -263,7 +270,7 @@ def choose_wgrad_batch_splitk(tiles: int, ksteps: int) -> int:
     then does not depend on how many layers share its launch (a flush in the middle of a network, branch streams or not, leaves every gradient
     bit-identical), three layers fill the chip, and 18 make ~6 rounds of it, so every workgroup's slab store hides behind the next round's main loops.
     ResnetBlock conv at batch 8: 12 tiles x 7 row ranges (w4 kernel; r04: 9 tiles x 28 pixel ranges, four times the slab bytes)."""
-    return max(1, min((NUM_CUS // 3 + tiles // 2) // tiles, max(1, ksteps // 16)))
+    return max(1, min((int(NUM_CUS * WGRAD_BATCH_FILL) + tiles // 2) // tiles, max(1, ksteps // 16)))
 
 
 WGRAD_C4_PARTS = 512

@@ -36,14 +36,4 @@ for r in rows[:16]:
 PY
 done
 timeout 600 python tools/layer_budget.py $TAG bf16 2>&1 | tail -26
-# PMC: the batched weight gradient (18 layers per launch): MFMA-busy, LDS conflicts, HBM-side bytes; WRITE_SIZE in its own pass
-bash tools/gpu_pmc_any.sh wgrad_w4_$TAG wgrad_w4_kernel python $GRAFT_REPO_ROOT/tools/wgrad_time.py bf16 18 2>&1 | tail -2
-(cd /tmp && timeout 180 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_ww/p4 -o p -- python $GRAFT_REPO_ROOT/tools/wgrad_time.py bf16 18 > /dev/null 2>&1)
-python - <<PY
-import csv, glob, json
-for pat in ('wgrad_w4_kernel', 'wgrad_reduce_batch_kernel'):
-    v = [float(r['Counter_Value']) for p in glob.glob('gpurun_out/pmc_ww/p4/p_counter_collection.csv') for r in csv.DictReader(open(p)) if pat in r['Kernel_Name'] and r['Counter_Name'] == 'WRITE_SIZE']
-    print(pat, 'WRITE_SIZE KB mean per launch', sum(v) / max(len(v), 1), 'launches', len(v))
-    open('gpurun_out/pmc_wgrad_w4_write_$TAG.txt', 'a').write('%s WRITE_SIZE_KB_mean %f over %d launches\n' % (pat, sum(v) / max(len(v), 1), len(v)))
-PY
-rm -rf gpurun_out/pmc_ww
+# (PMC passes over the new kernels: tools/gpu_r05_epi3.sh / gpu_r05_pmc.sh -> profiles/r05/pmc_*.json)
