@@ -182,3 +182,38 @@ def test_training_step_with_and_without_the_batch(precision, monkeypatch):
             assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (x, y)
     d = (outs['on'][1] - outs['off'][1]).abs().max()
     assert float(d) < 1e-3, float(d)            # Adam steps of 2e-4: a handful of sign-level flips at most
+
+
+@pytest.mark.parametrize('progressive', [False, True], ids=['one-message-per-network', 'progressive-buckets'])
+def test_batched_weight_gradient_under_the_gradient_exchange(progressive, monkeypatch):
+    """The queued weight gradients of a network must have RUN before its slice goes on the wire: the tape marker flushes them and GradExchanger._launch flushes
+    again (progressive buckets cut a network's batch in the middle -- a layer's split-K does not depend on the size of its batch, so nothing may change).
+    One-rank RCCL group, exchange forced on (an identity all-reduce), three branch streams, the w4 / batch shape: bit-identical to the plain step."""
+    import torch.distributed as dist
+    from deepliif_amd import distributed as D
+    from test_gpu_distributed import _free_port
+    monkeypatch.setattr(ops, '_WGRAD_BATCH', True)
+
+    def run():
+        m = _model('bf16')
+        for b in _step_batches(2, 2):
+            m.set_input(b)
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        return torch.cat([o.flat.data.clone() for o in m.optimizers]), [float(v) for v in m.get_current_losses().values()], m
+    ref_flat, ref_losses, _ = run()
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(D, 'FORCE', True)
+        if progressive:
+            monkeypatch.setattr(D, 'SPLIT_ELEMS', 200000)
+            monkeypatch.setattr(D, 'BUCKET_ELEMS', 400000)
+        assert D.active()
+        flat, losses, m = run()
+        assert len(m.exchange.launch_log) >= 2                       # slices left from the tape of the last backward_G
+        assert losses == ref_losses
+        assert torch.equal(flat, ref_flat)
+    finally:
+        dist.destroy_process_group()
