@@ -739,9 +739,19 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk,
     for (size_t i = bid * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x) {
         const int ca = (int)(i / J4), j = (int)(i % J4) * 4;
         const float *src = slab + (size_t)ca * J + j;
+        // eight partials in flight, then added in the SAME order as before (k = 0, 1, 2, ...: bit-identical results).  Since the deferred reduction the partials
+        // come from HBM, not from the Infinity Cache behind the kernel that wrote them: with four loads per thread in flight the batched pass ran at 1.7 TB/s
+        // (r05, profiles/r05/bench_train_kernel_stats_bf16_r05.csv: 20 launches x 146 us per step for 4.9 GB)
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k = 0; k < splitk; ++k) s += *reinterpret_cast<const f32x4_t *>(src + k * kstride);
+        int k = 0;
+        for (; k + 8 <= splitk; k += 8) {
+            f32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + (size_t)(k + u) * kstride));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splitk; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + (size_t)k * kstride));
         const int t = j / CBp, b0 = j % CBp;            // 4 consecutive j share the tap (CBp is a multiple of 8)
         if (t >= KK) continue;
 #pragma unroll
