@@ -354,9 +354,9 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     __attribute__((address_space(3))) int *rowtab = reinterpret_cast<__attribute__((address_space(3))) int *>(lds + 256 * 512);
     __attribute__((address_space(3))) float *red = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4);       // [wm][2][256]
     // the tile's 256 bias values reach the accumulator pass through LDS (r05): fetched inside the pass, hipcc had made them four guarded dword loads and an
-    // s_waitcnt vmcnt(0) per (i, q); 64 registers of preloaded float4s made the allocator spill.  A forward launch WITH a bias still measures 9-12 us more than
-    // one without (isolated: 141.8 vs 129.2 us; the same whether the values come from guarded dword loads, from LDS, or from a register filled before the K
-    // loop -- profiles/r05/epilogue_bias_hostprofile.txt, w4_epilogue_variants.txt): not the fetch; unexplained
+    // s_waitcnt vmcnt(0) per (i, q); 64 registers of preloaded float4s made the allocator spill.  (Isolated 20-launch timings seemed to show a bias costing
+    // 9-12 us whatever its fetch; a probe that repeated the SAME launch found 138.8 us first and 122.6 us six measurements later -- the clock drifts for seconds
+    // under the power cap, profiles/r05/bias_probe_clock_drift.txt -- so effects below ~10 us are read from the in-step rocprof averages only.)
     __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 4 * 256 * 4);
     const bool want_stats = a.stats_part != nullptr;
     {

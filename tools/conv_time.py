@@ -57,6 +57,10 @@ if 'fwd' in which:
     res['fwd_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, **KW)); res['fwd_kernel'] = be.last_conv_kernel
 if 'fwdstats' in which:          # the forward as the step launches it: bias + fused norm statistics in the store epilogue
     bias = torch.randn(256, device=DEV)
+    if 'biasprobe' in which:         # is the cost of a bias its fetch or its VALUES?  (r05: 9-12 us per forward launch whatever the fetch)
+        for tag, b in (('zero', torch.zeros(256, device=DEV)), ('small', bias * 1e-3), ('randn', bias), ('const', torch.full((256,), 0.5, device=DEV))):
+            res[f'fwd_bias_{tag}_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, b, 0, 0, prec.prec, **KW))
+        res['fwd_again_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, **KW))
     res['fwd_bias_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, bias, 0, 0, prec.prec, **KW))
     res['fwd_bias_stats_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, bias, 0, 0, prec.prec, want_stats=True, **KW))
     res['fwd_stats_us'] = timeit(lambda: be.conv_forward(pf, x, out, 128, 128, None, 0, 0, prec.prec, want_stats=True, **KW))
