@@ -140,3 +140,19 @@ def test_x3_swizzle_is_conflict_free():
         assert old == 2 and new == 1, (e, old, new)
         w = _b128_worst_way(lambda l: (l & 15) * 128 + (((e * 4 + (l >> 4)) ^ (((l & 15) >> 1) & 7)) << 4))
         assert w == 1, (e, w)
+
+
+def test_conv_descriptor_cache_hands_out_independent_copies():
+    """fill_conv_desc keeps the filled descriptor on the plan (r05: ~10-24 us of ctypes field stores per launch) -- callers set in_split / splitk on what they get,
+    so every call must return its OWN copy, equal to a freshly filled one"""
+    from deepliif_amd.geometry import ConvSpec, fill_conv_desc, _fill_conv_desc
+    from deepliif_amd import _lib as L
+    plan = ConvSpec('conv', 64, 128, 3, 2, 1).forward_plan()
+    args = (2, 64, 64, 64, 32, 32, 128, 128, 32, 32, L.DL_BF16, L.PREC_BF16, L.ACT_RELU, L.ACT_NONE, 128, 1)
+    a = fill_conv_desc(plan, *args)
+    a.in_split, a.splitk = 1, 7
+    b = fill_conv_desc(plan, *args)
+    assert (b.in_split, b.splitk) == (0, 1) and b is not a
+    assert bytes(b) == bytes(_fill_conv_desc(plan, *args))
+    c = fill_conv_desc(plan, *(args[:-1] + (4,)))                 # another split-K: another entry
+    assert c.splitk == 4 and bytes(fill_conv_desc(plan, *args)) == bytes(b)
