@@ -766,15 +766,66 @@ __device__ __forceinline__ void wgrad_reduce_body(const float *slab, int splitk,
     }
 }
 
+// The same reduction with coalesced writes (r05).  grad[a][b][t] has the tap index fastest, the slab row has b fastest: the loop above writes one
+// float per 64-byte line (KK = 16: UNet-512 gradients, 218 MB per generator, cost 8-16 x their size in write traffic; rocprofv3 of the 18-net step:
+// 46 launches x 253 us = 8.4 % of the step, profiles/r05/bench_train18_kernel_stats_r05.csv).  Here a workgroup owns one weight row ca and RED_BCHUNK
+// consecutive b: it reads the KK runs of the slab row (float4, coalesced, eight partials in flight, summed in the same order k = 0, 1, 2 ...: bit-identical
+// to wgrad_reduce_body), transposes through LDS and writes nreal * KK CONSECUTIVE floats of the gradient.
+constexpr int RED_BCHUNK = 64, RED_KK_MAX = 64, RED_MAX_BLOCKS = 8192;
+
+__device__ __forceinline__ bool wgrad_reduce_tiled(int KK, int stack_kw) { return stack_kw == 0 && KK <= RED_KK_MAX; }
+
+__device__ __forceinline__ void wgrad_reduce_tiles(const float *slab, int splitk, int kstride_, int CBp, int J, int CA, int CB, int KK, float *grad,
+                                                   int accumulate, int bid, int nb, float *lds) {
+    const int nbc = (CBp + RED_BCHUNK - 1) / RED_BCHUNK, KP = KK + 1;
+    const size_t kstride = (size_t)kstride_;
+    for (int item = bid; item < CA * nbc; item += nb) {
+        const int ca = item / nbc, b0 = (item - ca * nbc) * RED_BCHUNK;
+        const int width = min(RED_BCHUNK, CBp - b0), q = width / 4;         // CBp is a multiple of 8
+        const int nreal = min(width, CB - b0);                              // the padded channels have no gradient
+        if (nreal > 0) {
+            const float *base = slab + (size_t)ca * J + b0;
+            for (int i = threadIdx.x; i < KK * q; i += 256) {
+                const int t = i / q, c = (i - t * q) * 4;
+                const float *src = base + (size_t)t * CBp + c;
+                f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+                int k = 0;
+                for (; k + 8 <= splitk; k += 8) {
+                    f32x4_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + (size_t)(k + u) * kstride));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; k < splitk; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + (size_t)k * kstride));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lds[(c + e) * KP + t] = s[e];
+            }
+        }
+        __syncthreads();
+        if (nreal > 0) {
+            float *g = grad + ((size_t)ca * CB + b0) * KK;
+            for (int o = threadIdx.x; o < nreal * KK; o += 256) {
+                const float v = lds[o + o / KK];                            // [b][t] at pitch KK + 1
+                g[o] = accumulate ? g[o] + v : v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *slab, int splitk, int kstride, int CBp, int J, int CA, int CB,
                                                            int KK, float *grad, int accumulate, int stack_kw) {
-    wgrad_reduce_body(slab, splitk, kstride, CBp, J, CA, CB, KK, grad, accumulate, stack_kw, blockIdx.x, gridDim.x);
+    __shared__ float lds[RED_BCHUNK * (RED_KK_MAX + 1)];
+    if (wgrad_reduce_tiled(KK, stack_kw)) wgrad_reduce_tiles(slab, splitk, kstride, CBp, J, CA, CB, KK, grad, accumulate, blockIdx.x, gridDim.x, lds);
+    else wgrad_reduce_body(slab, splitk, kstride, CBp, J, CA, CB, KK, grad, accumulate, stack_kw, blockIdx.x, gridDim.x);
 }
 
 // Deferred form (dl_conv_wgrad_slabs + dl_wgrad_reduce_batch): the slabs of MANY layers, each in its own region of a caller-owned arena, are
 // combined by ONE launch at the end of a network's backward pass -- every workgroup looks its layer up in a table sorted by first block.
 // Per element the summation is the loop above, so the result is bit-identical to the immediate reduction.
 __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dl_wgrad_reduce_entry *tab, int n) {
+    __shared__ float lds[RED_BCHUNK * (RED_KK_MAX + 1)];
     int lo = 0, hi = n - 1;
     const int b = blockIdx.x;
     while (lo < hi) {
@@ -782,7 +833,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const dl_wgrad_
         if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
     }
     const dl_wgrad_reduce_entry e = tab[lo];
-    wgrad_reduce_body(e.slab, e.splitk, e.kstride, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, e.stack_kw, b - e.block0, e.nblocks);
+    if (wgrad_reduce_tiled(e.KK, e.stack_kw))
+        wgrad_reduce_tiles(e.slab, e.splitk, e.kstride, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, b - e.block0, e.nblocks, lds);
+    else wgrad_reduce_body(e.slab, e.splitk, e.kstride, e.CBp, e.J, e.CA, e.CB, e.KK, e.grad, e.accumulate, e.stack_kw, b - e.block0, e.nblocks);
 }
 
 template <typename T, int PREC, int BA, int WA, int WJ>
@@ -974,6 +1027,8 @@ extern "C" int dl_wgrad_plan(const dl_wgrad_desc *d, int32_t *tiles, int32_t *ks
 }
 
 static int reduce_blocks(const dl_wgrad_desc *d, int J) {
+    if (d->stack_kw == 0 && d->KH * d->KW <= RED_KK_MAX)                    // wgrad_reduce_tiles: one (weight row, 64 channels) item per workgroup pass
+        return (int)min((size_t)RED_MAX_BLOCKS, (size_t)d->CA * ((d->CBp + RED_BCHUNK - 1) / RED_BCHUNK));
     const size_t total = (size_t)d->CA * (J / 4);
     return (int)min((size_t)4096, (total + 255) / 256);
 }
