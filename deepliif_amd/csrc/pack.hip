@@ -1,16 +1,7 @@
 // pack.hip -- parameter packing (fp32 OIHW/IOHW -> K-contiguous bf16 hi/lo GEMM images) and the NCHW<->NHWC boundary
 // converters.  All pure HBM streaming; see include/deepliif_hip.h.
 #include "common.h"
-
-struct PackArgs {
-    const float *src;
-    bf16_t *w_hi, *w_lo;
-    int A, B, KH, KW, row_is_a, rows_real, rows_pad, Cc, Cc_pad, log2Cc, n_phase, kstride, stack_kw;
-    int phase_tap_begin[DL_MAX_PHASES + 1];
-    int phase_kbase[DL_MAX_PHASES];
-    int phase_kend[DL_MAX_PHASES];
-    int8_t tap_kh[DL_MAX_TAPS], tap_kw[DL_MAX_TAPS];
-};
+#include "pack_tile.h"
 
 // one image: element i of the K-contiguous GEMM image <- the OIHW/IOHW master weight it comes from (0 in the padding)
 __device__ __forceinline__ void pack_image(const PackArgs &a, int block, int nblocks) {
@@ -52,11 +43,18 @@ constexpr int PACK_CHUNKS_PER_BLOCK = 256 * 4;       // 256 threads x 4 chunks =
 
 __global__ void __launch_bounds__(256) pack_weights_batch_kernel(const char *jobs, size_t job_stride, const int2 *block_tab) {
     __shared__ PackArgs a;
-    const int2 bt = block_tab[blockIdx.x];           // x = job, y = first chunk of this block inside the job's image
-    const int *src = reinterpret_cast<const int *>(jobs + (size_t)bt.x * job_stride);      // stride = dl_pack_job_bytes()
+    __shared__ __attribute__((aligned(16))) float tile_lds[PT_LDS_FLOATS];
+    const int2 bt = block_tab[blockIdx.x];           // x = job (| PT_TILED_FLAG), y = first chunk of this block inside the job's image (or its tile)
+    const int *src = reinterpret_cast<const int *>(jobs + (size_t)(bt.x & ~PT_TILED_FLAG) * job_stride);      // stride = dl_pack_job_bytes()
     int *dst = reinterpret_cast<int *>(&a);
     for (int i = threadIdx.x; i < (int)(sizeof(PackArgs) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
+    if (bt.x & PT_TILED_FLAG) {                      // pack_tile.h: master weight read in its own order, transposed through LDS
+        pack_tile_load(a, bt.y, threadIdx.x, tile_lds);
+        __syncthreads();
+        pack_tile_store(a, bt.y, threadIdx.x, tile_lds);
+        return;
+    }
     const int cpr = a.kstride >> 3;                  // chunks per row
     const int nchunks = a.rows_pad * cpr;
 #pragma unroll
@@ -102,21 +100,7 @@ __global__ void __launch_bounds__(256) pack_weights_batch_kernel(const char *job
 
 static int fill_pack_args(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, PackArgs &a, const char *who) {
     if (!d || !src || !w_hi) DL_FAIL("%s: null argument", who);
-    const int l2 = ilog2_exact(d->Cc_pad);
-    if (l2 < 3) DL_FAIL("%s: Cc_pad=%d must be a power of two >= 8", who, d->Cc_pad);
-    if (d->n_phase < 1 || d->n_phase > DL_MAX_PHASES) DL_FAIL("%s: n_phase=%d", who, d->n_phase);
-    memset(&a, 0, sizeof(a));
-    a.src = src; a.w_hi = (bf16_t *)w_hi; a.w_lo = (bf16_t *)w_lo;
-    a.A = d->A; a.B = d->B; a.KH = d->KH; a.KW = d->KW; a.row_is_a = d->row_is_a;
-    a.rows_real = d->rows_real; a.rows_pad = d->rows_pad; a.Cc = d->Cc; a.Cc_pad = d->Cc_pad; a.log2Cc = l2;
-    a.n_phase = d->n_phase; a.kstride = d->kstride; a.stack_kw = d->stack_kw;
-    for (int p = 0; p <= DL_MAX_PHASES; ++p) a.phase_tap_begin[p] = d->phase_tap_begin[p];
-    for (int p = 0; p < d->n_phase; ++p) {
-        a.phase_kbase[p] = d->phase_kbase[p];
-        a.phase_kend[p] = d->phase_kbase[p] + (d->phase_tap_begin[p + 1] - d->phase_tap_begin[p]) * d->Cc_pad;
-        if (a.phase_kend[p] > d->kstride) DL_FAIL("%s: phase %d exceeds kstride", who, p);
-    }
-    for (int t = 0; t < DL_MAX_TAPS; ++t) { a.tap_kh[t] = d->tap_kh[t]; a.tap_kw[t] = d->tap_kw[t]; }
+    if (const char *why = pack_args_from_desc(d, src, w_hi, w_lo, a)) DL_FAIL("%s: %s", who, why);
     return 0;
 }
 
@@ -147,6 +131,8 @@ extern "C" int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w
 extern "C" int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *block_tab_host) {
     if (!jobs_host || count < 0) DL_FAIL("dl_pack_batch_blocks: bad arguments");
     const size_t jb = dl_pack_job_bytes();
+    const char *sw = getenv("DL_PACK_TILED");           // A/B switch: 0 = every job in the chunk-per-thread form (the r01-r05 kernel)
+    const bool tiled = !(sw && sw[0] == '0');
     long n = 0;
     for (int j = 0; j < count; ++j) {
         PackArgs a;
@@ -154,6 +140,13 @@ extern "C" int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *b
         if (a.kstride % 8) DL_FAIL("dl_pack_batch_blocks: job %d: kstride %d is not a multiple of 8", j, a.kstride);
         const long chunks = (long)a.rows_pad * (a.kstride / 8);
         if (chunks > 0x7fffffffL) DL_FAIL("dl_pack_batch_blocks: job %d is too large", j);
+        if (j >= PT_TILED_FLAG) DL_FAIL("dl_pack_batch_blocks: too many jobs");
+        if (tiled && pack_tiled_ok(a)) {
+            const long tiles = pack_tile_count(a);
+            for (long t = 0; t < tiles; ++t, ++n)
+                if (block_tab_host) { block_tab_host[2 * n] = j | PT_TILED_FLAG; block_tab_host[2 * n + 1] = (int32_t)t; }
+            continue;
+        }
         for (long c = 0; c < chunks; c += PACK_CHUNKS_PER_BLOCK, ++n)
             if (block_tab_host) { block_tab_host[2 * n] = j; block_tab_host[2 * n + 1] = (int32_t)c; }
     }

@@ -207,7 +207,9 @@ int dl_pack_weights(const dl_pack_desc *d, const float *src, void *w_hi, void *w
  * arguments dl_pack_weights takes (device pointers are only recorded, nothing is launched).  dl_pack_batch_blocks() turns `count`
  * back-to-back host records into the workgroup table {job, first 16-byte chunk} (int32 pairs; pass NULL to get the entry count).
  * The caller copies both tables to device memory once and calls dl_pack_weights_batch after every weight update; they stay valid
- * as long as the descriptors and the three pointers of each job do.  Results are bit-identical to dl_pack_weights. */
+ * as long as the descriptors and the three pointers of each job do.  Results are bit-identical to dl_pack_weights.
+ * The table is opaque: images whose phases are whole taps back to back (>= 64 contracted channels, kernels up to 4x4) get one entry per
+ * 8-row x 64-channel tile (job | 1 << 30, tile) and are packed through LDS in the master weight's own order; DL_PACK_TILED=0 turns that off. */
 size_t dl_pack_job_bytes(void);
 int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w_hi, void *w_lo, void *job_host);
 int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *block_tab_host);

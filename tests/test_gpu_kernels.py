@@ -313,7 +313,11 @@ def test_pack_weights_batch_matches_single_packs():
     be = hip()
     specs = [ConvSpec('conv', 3, 64, 7, 1, 3), ConvSpec('conv', 64, 128, 3, 2, 1), ConvSpec('conv', 256, 256, 3, 1, 1),
              ConvSpec('convT', 256, 128, 3, 2, 1, L.PAD_ZERO, 1), ConvSpec('conv', 6, 64, 4, 2, 1), ConvSpec('conv', 512, 1, 4, 1, 1),
-             ConvSpec('conv', 64, 3, 7, 1, 3)]
+             ConvSpec('conv', 64, 3, 7, 1, 3),
+             # r05: the shapes that take the tiled form of the batch kernel (csrc/pack_tile.h; host twin: test_pack_tile_host.py) -- UNet-512 / PatchGAN 4x4 layers
+             # (one-phase and 4-phase images, master rows = image rows and = contracted channels), a 1x1 layer, one real row out of 128
+             ConvSpec('conv', 128, 256, 4, 2, 1), ConvSpec('conv', 512, 512, 4, 2, 1), ConvSpec('convT', 1024, 512, 4, 2, 1),
+             ConvSpec('convT', 512, 256, 4, 2, 1), ConvSpec('conv', 256, 128, 1, 1, 0), ConvSpec('convT', 128, 64, 3, 2, 1, L.PAD_ZERO, 1)]
     jobs, refs = [], []
     for i, spec in enumerate(specs):
         wshape = (spec.cout, spec.cin, spec.k, spec.k) if spec.kind == 'conv' else (spec.cin, spec.cout, spec.k, spec.k)
@@ -333,12 +337,26 @@ def test_pack_weights_batch_matches_single_packs():
                 refs.append(single)
     table = be.pack_batch_build(jobs)
     assert table[0].numel() == len(jobs) * int(be.lib.dl_pack_job_bytes()) and table[1].numel() == 2 * table[2] and table[2] >= len(jobs)
+    tiled = (table[1][0::2] & (1 << 30)) != 0
+    assert tiled.any() and not tiled.all()                     # both forms of the kernel are in this launch
     be.pack_batch_run(table, len(jobs))
     sync()
     for (batched, _), single in zip(jobs, refs):
         assert torch.equal(batched.hi.view(torch.int16), single.hi.view(torch.int16))
         if single.lo is not None:
             assert torch.equal(batched.lo.view(torch.int16), single.lo.view(torch.int16))
+    os.environ['DL_PACK_TILED'] = '0'                           # the A/B switch: every job in the chunk-per-thread form
+    try:
+        chunk_table = be.pack_batch_build(jobs)
+    finally:
+        del os.environ['DL_PACK_TILED']
+    assert not ((chunk_table[1][0::2] & (1 << 30)) != 0).any()
+    for batched, _ in jobs:
+        batched.hi.fill_(float('nan'))
+    be.pack_batch_run(chunk_table, len(jobs))
+    sync()
+    for (batched, _), single in zip(jobs, refs):
+        assert torch.equal(batched.hi.view(torch.int16), single.hi.view(torch.int16))
 
 
 @pytest.mark.parametrize('precname,ca,q_act', [('bf16', 256, L.ACT_NONE), ('fp32', 256, L.ACT_NONE), ('fp32', 128, L.ACT_LRELU), ('fp32', 256, L.ACT_RELU)])
