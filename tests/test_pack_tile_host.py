@@ -80,3 +80,40 @@ def test_tiled_packing_writes_the_bits_of_the_elementwise_decode(checker, tmp_pa
 
 def test_pack_descriptor_layout_matches_the_header():
     assert C.sizeof(L.PackDesc) == 4 * (4 + 1 + 2 + 2 + 1 + 5 + 4) + 2 * 64 + 4 + 4
+
+
+def test_block_table_of_the_shipped_library(monkeypatch):
+    """dl_pack_job_fill / dl_pack_batch_blocks are host-only (nothing is launched): the table the SHIPPED library builds marks the eligible images as
+    tiled -- one entry per 8-row x 64-channel tile -- and DL_PACK_TILED=0 puts every image back into chunks of 1024 x 16 bytes."""
+    lib = L.load()
+    descs = _descs()
+    jb = int(lib.dl_pack_job_bytes())
+    host = (C.c_ubyte * (jb * len(descs)))()
+    base = C.addressof(host)
+    for i, (_, _, d) in enumerate(descs):           # the pointers are only recorded
+        L.check(lib.dl_pack_job_fill(C.byref(d), C.c_void_p(0x10000), C.c_void_p(0x20000), C.c_void_p(0x30000), C.c_void_p(base + i * jb)), 'dl_pack_job_fill')
+
+    def table():
+        n = int(lib.dl_pack_batch_blocks(C.c_void_p(base), len(descs), None))
+        assert n > 0
+        tab = (C.c_int32 * (2 * n))()
+        assert int(lib.dl_pack_batch_blocks(C.c_void_p(base), len(descs), C.c_void_p(C.addressof(tab)))) == n
+        return [(tab[2 * i], tab[2 * i + 1]) for i in range(n)]
+
+    monkeypatch.delenv('DL_PACK_TILED', raising=False)
+    tiled = table()
+    monkeypatch.setenv('DL_PACK_TILED', '0')
+    chunk = table()
+    flag = 1 << 30
+    assert not any(j & flag for j, _ in chunk)
+    for i, (_, _, d) in enumerate(descs):
+        chunks = d.rows_pad * (d.kstride // 8)
+        mine_c = [y for j, y in chunk if j == i]
+        assert mine_c == list(range(0, chunks, 1024))                       # first chunk of each workgroup
+        mine_t = [(j, y) for j, y in tiled if (j & ~flag) == i]
+        if mine_t[0][0] & flag:
+            assert d.Cc == d.Cc_pad and d.Cc_pad >= 64 and d.KH * d.KW <= 16 and not d.stack_kw
+            assert [y for _, y in mine_t] == list(range((d.rows_pad // 8) * (d.Cc_pad // 64)))
+        else:
+            assert [y for _, y in mine_t] == mine_c
+    assert sum(1 for j, _ in tiled if j & flag) > 0 and [j & ~flag for j, _ in tiled] == sorted(j & ~flag for j, _ in tiled)
