@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdeepliif_hip.so')
+# DEEPLIIF_AMD_LIB: another build of the same ABI (tools/ load libdeepliif_hip_dev.so, the -DDL_DEV_SWITCHES build with every A/B variant)
+LIB_PATH = os.environ.get('DEEPLIIF_AMD_LIB') or os.path.join(_HERE, 'libdeepliif_hip.so')
 
 DL_F32, DL_BF16 = 0, 1
 PREC_BF16, PREC_BF16X3 = 1, 3
@@ -16,7 +17,7 @@ NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1, LOSS_LINEAR = 0, 1, 2, 3, 4
 MAX_TAPS, MAX_PHASES = 64, 4
 WGRAD_MULTI_MAX = 24
-DL_VERSION = 112
+DL_VERSION = 113
 
 i32 = C.c_int32
 
@@ -70,6 +71,10 @@ _vp, _f, _i, _i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
 SIGNATURES = {
     'dl_version': (_i, []),
     'dl_last_error': (C.c_char_p, []),
+    'dl_switch_count': (_i, []),
+    'dl_switch_name': (C.c_char_p, [_i]),
+    'dl_switches_reload': (None, []),
+    'dl_dev_build': (_i, []),
     'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
     'dl_conv_bnstats_chunks': (_i, [C.POINTER(ConvDesc)]),

@@ -21,7 +21,7 @@ struct C4Args {
 };
 
 static bool c4_geometry_ok(const dl_conv_desc *d) {
-    static const bool off = getenv("DL_NO_C4") != nullptr;
+    static const bool off = DL_DEV_ENV("DL_NO_C4") != nullptr;
     if (off || d->in_act != DL_ACT_NONE) return false;
     if (d->act != DL_ACT_NONE && d->act != DL_ACT_RELU && d->act != DL_ACT_LRELU) return false;
     if (d->n_phase != 1 || d->in_step != 1 || d->out_step != 1 || d->splitk != 1 || d->raw_out) return false;
@@ -38,7 +38,7 @@ static bool c4_bf16_eligible(const dl_conv_desc *d) { return d->in_dtype == DL_B
 
 // strict policy (fp32 activations, split-bf16 x3 products): conv_c4_patch_x3_kernel (conv_x3.h)
 static bool c4_x3_eligible(const dl_conv_desc *d) {
-    static const bool off = getenv("DL_NO_C4_X3") != nullptr;       // A/B: the strict stem / head gradient on the general x3 kernels (round 3 before this kernel)
+    const bool off = dl_switch(DL_SW_NO_C4_X3) != nullptr;       // A/B: the strict stem / head gradient on the general x3 kernels (round 3 before this kernel)
     return !off && d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && !d->in_split && c4_geometry_ok(d);
 }
 
@@ -247,7 +247,7 @@ static void c4_fill_args(C4Args &ca, const ConvArgs &a0, const dl_conv_desc *d) 
     for (int t = 0; t < nt; ++t) ca.tap_src[d->tap_dh[t] + 3][d->tap_dw[t] + 3] = (int8_t)t;
     ca.tiles_w = d->Wo / 64;
     ca.tiles_h = d->Ho / 4;
-    static const char *abl_env = getenv("DL_C4_ABL");
+    static const char *abl_env = DL_DEV_ENV("DL_C4_ABL");
     ca.abl = abl_env ? atoi(abl_env) : 0;
 }
 

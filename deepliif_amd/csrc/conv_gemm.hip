@@ -25,6 +25,9 @@ bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
 int launch_conv_s2f(const ConvArgs &a0, hipStream_t stream);
 // conv_s2f_x3.hip: the same tile under the strict policy (split-copy input, three products)
+bool s2d_eligible(const ConvArgs &a);
+int s2d_stats_chunks(const ConvArgs &a);
+int launch_conv_s2d(const ConvArgs &a0, hipStream_t stream);
 bool s2f_x3_eligible(const ConvArgs &a);
 int launch_conv_s2f_x3(const ConvArgs &a0, hipStream_t stream);
 
@@ -1101,7 +1104,7 @@ static int launch_conv_8ph(const ConvArgs &a0, hipStream_t stream) {
     // channel-chunk-major K order by default (DL_8PH_KORDER=0: tap-major).  Same-box A/B (r03, two alternations): step 101.64 / 101.88 ms tap-major,
     // 100.97 / 101.00 ms chunk-major (78.6 -> 79.2 tiles/s); isolated launches within noise (165-177 us).  r01 had measured the same idea on the
     // one-barrier kernel as a loss inside the step; on the 8-phase kernels it is a small gain for bf16 and -2.8 % of the strict step.
-    static const char *korder = getenv("DL_8PH_KORDER");
+    static const char *korder = DL_DEV_ENV("DL_8PH_KORDER");
     a.k_order8 = (korder && korder[0] == '0') ? 0 : 1;
     constexpr size_t smem_loop = (size_t)8 * 128 * 64 * sizeof(bf16_t) + DL_MAX_TAPS * sizeof(int);
     constexpr size_t smem = smem_loop > epilogue_lds_bytes<256, 256, 2>() ? smem_loop : epilogue_lds_bytes<256, 256, 2>();
@@ -1490,7 +1493,7 @@ static bool kwr_eligible(const ConvArgs &a) {
 
 template <int ABL>
 static int dispatch_p32(const ConvArgs &a, hipStream_t stream) {
-    static const char *kwr_env = getenv("DL_CONV_KWR");          // "0": stage every K tile's activations separately
+    static const char *kwr_env = DL_DEV_ENV("DL_CONV_KWR");          // "0": stage every K tile's activations separately
     if (!(kwr_env && kwr_env[0] == '0') && kwr_eligible(a)) return launch_conv_p32<true, ABL>(a, stream);
     return launch_conv_p32<false, ABL>(a, stream);
 }
@@ -1531,14 +1534,14 @@ static bool big_tile_fills_gpu(int mtot, int Co, int n_phase, int splitk) {
 // conv_gemm_w4_kernel (conv_w4.hip) serves the ResnetBlock shape by default since r04; DL_CONV_W4=0 puts it back on the 8-phase kernel (same-box
 // A/B, profiles/r04/w4_v2_variants.txt: 158.9 -> 139.8 us per launch inside the training step, 103.9 -> 100.5 ms per step)
 static bool w4_enabled() {
-    static const char *w4 = getenv("DL_CONV_W4");
+    static const char *w4 = DL_DEV_ENV("DL_CONV_W4");
     return !(w4 && w4[0] == '0');
 }
 
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
-    static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
+    static const bool no_big = DL_DEV_ENV("DL_NO_BIGTILE") != nullptr;
     // 256x256x64, 8 waves (each 128 pixels x 64 channels): twice the FLOP per staged byte of the 128x128 tile; needs
     // enough tiles to fill 256 CUs
     if (!no_big && big_tile_fills_gpu(a.Mtot, a.Co, a.n_phase, a.splitk))
@@ -1549,30 +1552,34 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
         // stays the default and this one is kept for the next tuning pass (it moves 33% fewer bytes into LDS).
         // "1": 4 waves x (128 px x 128 ch) on v_mfma_32x32x16, kernel-column reuse, one barrier per K step (conv_w4.hip) for the ResnetBlock shape
         if (w4_enabled() && w4_eligible(a)) return launch_conv_w4(a, stream);
-        static const char *p32 = getenv("DL_CONV_P32");
+#ifdef DL_DEV_SWITCHES       // older kernels kept for same-box A/Bs and the timing-only ablations (results WRONG by construction): dev build only
+        static const char *p32 = DL_DEV_ENV("DL_CONV_P32");
         if (p32 && p32[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) {
-            static const char *ablp = getenv("DL_CONV_ABLATE");
+            static const char *ablp = DL_DEV_ENV("DL_CONV_ABLATE");
             if (ablp && ablp[0] == '1') return dispatch_p32<1>(a, stream);
             if (ablp && ablp[0] == '2') return dispatch_p32<2>(a, stream);
             if (ablp && ablp[0] == '3') return dispatch_p32<3>(a, stream);
             return dispatch_p32<0>(a, stream);
         }
-        static const char *ph8 = getenv("DL_CONV_8PH");            // "0": fall back to the one-barrier-per-step kernel
+        static const char *ph8 = DL_DEV_ENV("DL_CONV_8PH");            // "0": fall back to the one-barrier-per-step kernel
         if (!(ph8 && ph8[0] == '0') && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) {
-            static const char *abl8 = getenv("DL_CONV_ABLATE");
+            static const char *abl8 = DL_DEV_ENV("DL_CONV_ABLATE");
             if (abl8 && abl8[0] == '1') return launch_conv_8ph<1>(a, stream);
             if (abl8 && abl8[0] == '2') return launch_conv_8ph<2>(a, stream);
             if (abl8 && abl8[0] == '3') return launch_conv_8ph<3>(a, stream);
             if (abl8 && abl8[0] == '4') return launch_conv_8ph<4>(a, stream);
             return launch_conv_8ph<0>(a, stream);
         }
-        static const bool stag = getenv("DL_CONV_STAGGER") != nullptr;
-        static const char *abl = getenv("DL_CONV_ABLATE");       // "1": no DMA in the loop, "2": no LDS reads / MFMAs (timing only!)
+        static const bool stag = DL_DEV_ENV("DL_CONV_STAGGER") != nullptr;
+        static const char *abl = DL_DEV_ENV("DL_CONV_ABLATE");       // "1": no DMA in the loop, "2": no LDS reads / MFMAs (timing only!)
         if (abl && abl[0] == '1' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 1>(a, stream);
         if (abl && abl[0] == '2' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 2>(a, stream);
         if (abl && abl[0] == '4' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 4>(a, stream);
         if (abl && abl[0] == '5' && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, false, 5>(a, stream);
         if (stag && a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO) return launch_conv_glds_impl<256, 256, 64, 2, 4, true, true>(a, stream);
+#else
+        if (a.Ci >= 64 && a.pad_mode == DL_PAD_ZERO && !a.k_order) return launch_conv_8ph<0>(a, stream);
+#endif
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
     return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
@@ -1649,10 +1656,10 @@ static void fill_conv_geometry(ConvArgs &a, const dl_conv_desc *d) {
 
 // does dl_conv_forward send this descriptor to the fused four-phase kernel (conv_s2f.hip)?  DL_CONV_S2F=0: keep the 4-phase gather GEMM (A/B)
 static bool s2f_applies(const dl_conv_desc *d) {
-    static const char *env = getenv("DL_CONV_S2F");
-    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    const char *env = dl_switch(DL_SW_CONV_S2F);
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;
     if ((env && env[0] == '0') || no_glds || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE || d->n_phase != 4) return false;
-    static const bool epi_old = getenv("DL_OLD_EPILOGUE") != nullptr;
+    static const bool epi_old = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
     if (epi_old) return false;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1660,10 +1667,24 @@ static bool s2f_applies(const dl_conv_desc *d) {
     return s2f_eligible(a);
 }
 
+// does dl_conv_forward send this descriptor to the register-stationary stride-2 kernel (conv_s2d.hip: down1 forward, up2 data gradient)?
+// DL_CONV_S2D=0: keep the gather GEMM (A/B)
+static bool s2d_applies(const dl_conv_desc *d) {
+    const char *env = dl_switch(DL_SW_CONV_S2D);
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;
+    static const bool epi_old = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
+    if ((env && env[0] == '0') || no_glds || epi_old || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE || d->n_phase != 1 || d->in_step != 2)
+        return false;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_conv_geometry(a, d);
+    return s2d_eligible(a);
+}
+
 // ... and to its strict twin (conv_s2f_x3.hip)?  Needs the split copy of the input; DL_CONV_S2F=0 or DL_CONV_S2FX3=0: keep the 4-phase strict kernel (A/B)
 static bool s2fx3_applies(const dl_conv_desc *d) {
-    static const char *env = getenv("DL_CONV_S2F");
-    static const char *env3 = getenv("DL_CONV_S2FX3");
+    const char *env = dl_switch(DL_SW_CONV_S2F);
+    const char *env3 = dl_switch(DL_SW_CONV_S2FX3);
     if ((env && env[0] == '0') || (env3 && env3[0] == '0') || d->in_dtype != DL_F32 || d->prec != DL_PREC_BF16X3 || d->in_act != DL_ACT_NONE || d->n_phase != 4 ||
         !d->in_split || !x3_glds_applies(d))
         return false;
@@ -1675,11 +1696,11 @@ static bool s2fx3_applies(const dl_conv_desc *d) {
 
 // tile height (pixels) the dispatch picks for the bf16 direct-to-LDS path; 0 when that path is not taken
 static int glds_tile_bm(const dl_conv_desc *d) {
-    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;
     if (no_glds || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE) return 0;
     if (d->Co <= 16) return 256;
     if (d->Co <= 64) return 128;
-    static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
+    static const bool no_big = DL_DEV_ENV("DL_NO_BIGTILE") != nullptr;
     const int mtot = d->N * d->Hq * d->Wq;
     if (!no_big && big_tile_fills_gpu(mtot, d->Co, d->n_phase, d->splitk)) return 256;
     return 128;
@@ -1692,6 +1713,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (c4_bf16_eligible(d)) return "conv_c4_patch_kernel";
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
+    if (s2d_applies(d)) return "conv_s2d_kernel";
     if (s2fx3_applies(d)) return "conv_s2f_x3_kernel";
     const int bm = glds_tile_bm(d);
     if (bm == 0 && x3_glds_applies(d)) {
@@ -1715,10 +1737,10 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
         if (w4_eligible(a)) return "conv_gemm_w4_kernel";
     }
     const bool utap = d->Ci >= 64 && d->pad_mode == DL_PAD_ZERO;
-    static const char *korder_env = getenv("DL_CONV_KORDER");
+    static const char *korder_env = DL_DEV_ENV("DL_CONV_KORDER");
     const bool korder = korder_env && korder_env[0] == '1';
-    static const char *p32 = getenv("DL_CONV_P32");
-    static const char *ph8 = getenv("DL_CONV_8PH");
+    static const char *p32 = DL_DEV_ENV("DL_CONV_P32");
+    static const char *ph8 = DL_DEV_ENV("DL_CONV_8PH");
     if (utap && !korder && p32 && p32[0] == '1') return "conv_gemm_p32_kernel";
     if (utap && !korder && !(ph8 && ph8[0] == '0')) return "conv_gemm_8ph_kernel";
     return "conv_gemm_glds_kernel<256,256,64>";
@@ -1733,7 +1755,13 @@ extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
         fill_conv_geometry(a, d);
         return s2f_stats_chunks(a);
     }
-    static const bool no_x3_stats = getenv("DL_NO_X3_STATS") != nullptr;       // A/B: strict policy with the stand-alone statistics pass
+    if (s2d_applies(d)) {                                            // one chunk per workgroup (row segment x strip of output rows)
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        fill_conv_geometry(a, d);
+        return s2d_stats_chunks(a);
+    }
+    static const bool no_x3_stats = DL_DEV_ENV("DL_NO_X3_STATS") != nullptr;       // A/B: strict policy with the stand-alone statistics pass
     const int bm = (x3_glds_applies(d) && !no_x3_stats) ? x3_tile_bm(d) : glds_tile_bm(d);
     const int hw = d->Hq * d->Wq;
     if (bm == 0 || hw % bm) return 0;
@@ -1743,10 +1771,10 @@ extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
 extern "C" int dl_conv_bnstats_chunks(const dl_conv_desc *d) {
     // the reductions live in the LDS-transposed store epilogue of the direct-to-LDS kernels (tile_epilogue_lds): bf16, >= 64 output
     // channels per tile, no split-K, tiles that do not straddle images
-    static const bool off = getenv("DL_OLD_EPILOGUE") != nullptr;
-    static const char *p32 = getenv("DL_CONV_P32");
-    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d) || s2fx3_applies(d)) return 0;
-    static const int min_bm = getenv("DL_BNSTATS_MIN_BM") ? atoi(getenv("DL_BNSTATS_MIN_BM")) : 0;       // A/B: 256 = only the 256 x 256-tile kernels
+    static const bool off = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
+    static const char *p32 = DL_DEV_ENV("DL_CONV_P32");
+    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d) || s2fx3_applies(d) || s2d_applies(d)) return 0;
+    static const int min_bm = DL_DEV_ENV("DL_BNSTATS_MIN_BM") ? atoi(DL_DEV_ENV("DL_BNSTATS_MIN_BM")) : 0;       // A/B: 256 = only the 256 x 256-tile kernels
     if (glds_tile_bm(d) < min_bm) return 0;
     return dl_conv_stats_chunks(d);
 }
@@ -1799,13 +1827,13 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     fill_conv_geometry(a, d);
     if (d->in_split && !(d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && d->in_act == DL_ACT_NONE && x3_glds_applies(d)))
         DL_FAIL("dl_conv_forward: in_split needs the strict policy (fp32 + BF16X3) on the direct-to-LDS kernels and no input activation");
-    static const bool epi_old = getenv("DL_OLD_EPILOGUE") != nullptr;
+    static const bool epi_old = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
     a.epi_old = epi_old ? 1 : 0;
     a.Mtot = d->N * d->Hq * d->Wq;
     // A/B switch: "1" = channel-chunk-major K steps.  Measured on MI355X (r01): 4-7% faster in an isolated loop over one layer
     // (tools/ab_order.sh) but 3-12% SLOWER inside the training step (profiles/r01: 162.9 -> 168.7 us on the 256x256 tile),
     // so tap-major stays the default.
-    static const char *korder_env = getenv("DL_CONV_KORDER");
+    static const char *korder_env = DL_DEV_ENV("DL_CONV_KORDER");
     a.k_order = (korder_env && korder_env[0] == '1') ? 1 : 0;
     a.stats_part = nullptr;
     a.stats_nchunks = 0;
@@ -1820,11 +1848,12 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     }
 
     int rc;
-    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
     if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
     else if (!bn && s2f_applies(d)) rc = launch_conv_s2f(a, stream);
     else if (!bn && s2fx3_applies(d)) rc = launch_conv_s2f_x3(a, stream);
+    else if (!bn && s2d_applies(d)) rc = launch_conv_s2d(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->in_act == DL_ACT_NONE && !no_glds) rc = dispatch_tile_glds(a, stream);
     else if (d->in_dtype == DL_BF16 && d->prec == DL_PREC_BF16) rc = dispatch_tile<bf16_t, bf16_t, 1>(a, stream);
     else if (d->in_dtype == DL_F32 && d->prec == DL_PREC_BF16X3) rc = x3_glds_applies(d) ? dispatch_tile_x3(a, stream) : dispatch_tile<float, float, 3>(a, stream);

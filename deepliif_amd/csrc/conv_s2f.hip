@@ -270,7 +270,7 @@ bool s2f_eligible(const ConvArgs &a) {
     // Size rule (same-box A/B, profiles/r04/s2f_first_look.txt): the tile pays where the phase grid has >= 256 tiles of 256 pixels -- up2 forward 318 -> 216 us,
     // down1 data gradient 266 -> 190, up1 forward 187 -> 154, down2 data gradient 165 -> 137, PatchGAN c2 data gradient 98 -> 77 -- ties at 128 tiles (c3: 62 / 61)
     // and loses at 32 tiles x 8 channel tiles (c4: 53 -> 95 us: one workgroup per CU, the input tile staged by 8 channel tiles).  DL_CONV_S2F=2 lifts the rule (tests).
-    static const char *env = getenv("DL_CONV_S2F");
+    const char *env = dl_switch(DL_SW_CONV_S2F);
     if (a.Mtot < 65536 && !(env && env[0] == '2')) return false;
     int ndist = 0;
     int16_t seen[S2F_MAX_OFF + 1];

@@ -287,7 +287,7 @@ bool s2f_x3_eligible(const ConvArgs &a) {
     if (a.act != DL_ACT_NONE && a.act != DL_ACT_RELU) return false;
     if ((a.in_pstride & 3) || (a.out_pstride & 3)) return false;
     // the size rule of the bf16 kernel (profiles/r04/s2f_first_look.txt): >= 256 tiles of 256 phase-grid pixels; DL_CONV_S2F=2 lifts it (tests)
-    static const char *env = getenv("DL_CONV_S2F");
+    const char *env = dl_switch(DL_SW_CONV_S2F);
     if (a.Mtot < 65536 && !(env && env[0] == '2')) return false;
     int ndist = 0;
     int16_t seen[S3_MAX_OFF + 1];

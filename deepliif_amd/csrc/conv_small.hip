@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(640) conv_narrow_roll_x3_kernel(const NarrowX3
 }
 
 extern "C" int dl_conv_narrow_supported(int dtype, int Ci, int x_pstride, int Cout, int KH, int KW, int pad, int pad_mode) {
-    static const bool no_x3 = getenv("DL_NO_NARROW_X3") != nullptr;      // A/B switch: the strict head back on dl_conv_forward(raw_out) + dl_shift_sum
+    static const bool no_x3 = DL_DEV_ENV("DL_NO_NARROW_X3") != nullptr;      // A/B switch: the strict head back on dl_conv_forward(raw_out) + dl_shift_sum
     return (dtype == DL_BF16 || (dtype == DL_F32 && !no_x3)) && Ci == 64 && x_pstride % 8 == 0 && KH == 7 && KW == 7 && (Cout == 1 || Cout == 3) &&
            pad == KH / 2 && pad == KW / 2 && pad_mode == DL_PAD_ZERO;
 }
@@ -491,7 +491,7 @@ extern "C" int dl_conv_narrow_forward(const void *x, int N, int H, int W, int Ci
     if (bands > (H + 15) / 16) bands = (H + 15) / 16;
     a.band_rows = (H + bands - 1) / bands;
     a.bands = (H + a.band_rows - 1) / a.band_rows;
-    static const char *abl_env = getenv("DL_NARROW_ABL");
+    static const char *abl_env = DL_DEV_ENV("DL_NARROW_ABL");
     a.abl = abl_env ? atoi(abl_env) : 0;
     constexpr size_t smem = 8 * 64 * 64 * 2 + 4 * 32 * 68 * 4;
     void (*kern)(const NarrowArgs) = nullptr;

@@ -506,8 +506,11 @@ int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
-    static const char *abl = getenv("DL_W4_ABLATE");          // timing-only ablations, on the default variant
-    static const char *var = getenv("DL_W4_VAR");             // schedule / DMA variant (A/B): bits as documented at the kernel
+#ifndef DL_DEV_SWITCHES
+    return launch_w4_dir<DL_W4_DEFAULT_VAR, 0>(a, stream);
+#else       // schedule / DMA variants and the timing-only ablations (results WRONG by construction): dev build only
+    static const char *abl = DL_DEV_ENV("DL_W4_ABLATE");          // timing-only ablations, on the default variant
+    static const char *var = DL_DEV_ENV("DL_W4_VAR");             // schedule / DMA variant (A/B): bits as documented at the kernel
     if (abl && abl[0] >= '1' && abl[0] <= '5') {
         switch (abl[0]) {
             case '1': return launch_w4_dir<DL_W4_DEFAULT_VAR, 1>(a, stream);
@@ -527,6 +530,7 @@ int launch_conv_w4(const ConvArgs &a0, hipStream_t stream) {
         case 5: return launch_w4_dir<5, 0>(a, stream);
         default: return launch_w4_dir<13, 0>(a, stream);
     }
+#endif
 }
 
 

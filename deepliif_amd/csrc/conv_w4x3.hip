@@ -396,10 +396,12 @@ int launch_conv_w4x3(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
-    static const char *abl = getenv("DL_W4X3_ABLATE");
     const bool flip = w4x3_flipped(a);
+#ifdef DL_DEV_SWITCHES      // timing-only ablations (results WRONG by construction): dev build only
+    static const char *abl = DL_DEV_ENV("DL_W4X3_ABLATE");
     if (abl && abl[0] == '1') return flip ? launch_w4x3<true, 1>(a, stream) : launch_w4x3<false, 1>(a, stream);
     if (abl && abl[0] == '3') return flip ? launch_w4x3<true, 3>(a, stream) : launch_w4x3<false, 3>(a, stream);
     if (abl && abl[0] == '4') return flip ? launch_w4x3<true, 4>(a, stream) : launch_w4x3<false, 4>(a, stream);
+#endif
     return flip ? launch_w4x3<true, 0>(a, stream) : launch_w4x3<false, 0>(a, stream);
 }

@@ -534,7 +534,7 @@ static int launch_conv_8ph_x3(const ConvArgs &a0, hipStream_t stream) {
     ConvArgs a = a0;
     a.tiles_m = (a.Mtot + 255) / 256;
     a.tiles_n = a.Co / 256;
-    static const char *korder = getenv("DL_X3_KORDER");
+    static const char *korder = DL_DEV_ENV("DL_X3_KORDER");
     a.k_order8 = (korder && korder[0] == '0') ? 0 : 1;
     constexpr size_t smem = (size_t)8 * 128 * 128 + DL_MAX_TAPS * sizeof(int);
     auto kern = conv_gemm_8ph_x3_kernel<IN_ACT, ABL, VAR>;
@@ -786,14 +786,14 @@ static int dispatch_glds_x3_tiles(const ConvArgs &a, hipStream_t stream) {
 
 // which strict-policy descriptors take the direct-to-LDS kernels of this file (DL_NO_X3_GLDS=1: none -- the round-1 register-staged kernel, A/B)
 static bool x3_glds_applies(const dl_conv_desc *d) {
-    static const bool off = getenv("DL_NO_X3_GLDS") != nullptr;
+    const bool off = dl_switch(DL_SW_NO_X3_GLDS) != nullptr;
     if (off || d->in_dtype != DL_F32 || d->prec != DL_PREC_BF16X3) return false;
     if (d->in_act != DL_ACT_NONE && d->in_act != DL_ACT_RELU && d->in_act != DL_ACT_LRELU) return false;
     return d->in_pstride % 4 == 0 && d->Ci >= 8;
 }
 
 static bool x3_big_tile(int in_act, int pad_mode, int Ci, int mtot, int Co, int n_phase, int splitk) {
-    static const bool no_big = getenv("DL_NO_BIGTILE") != nullptr;
+    static const bool no_big = DL_DEV_ENV("DL_NO_BIGTILE") != nullptr;
     return !no_big && in_act == DL_ACT_NONE && pad_mode == DL_PAD_ZERO && Ci >= 32 && big_tile_fills_gpu(mtot, Co, n_phase, splitk);
 }
 
@@ -817,26 +817,28 @@ static const char *x3_kernel_name(const dl_conv_desc *d) {
 // kernel already issues three MFMAs per fragment pair, so halving the LDS bytes per MFMA buys nothing: both run at 1.3-1.35 PF/s executed, 80-90 % of
 // what a bare MFMA loop sustains on random operands on these boxes (1.5-1.7 PF/s, bench.py roofline.sustained) -- the strict conv is power-bound.
 static bool w4x3_enabled() {
-    static const char *e = getenv("DL_CONV_W4X3");
+    const char *e = dl_switch(DL_SW_CONV_W4X3);
     return e && e[0] == '1';
 }
 
 static int dispatch_tile_x3(const ConvArgs &a, hipStream_t stream) {
     if (x3_big_tile(a.in_act, a.pad_mode, a.Ci, a.Mtot, a.Co, a.n_phase, a.splitk)) {
         if (w4x3_enabled() && w4x3_eligible(a)) return launch_conv_w4x3(a, stream);
-        static const char *abl = getenv("DL_CONV_ABLATE");
+#ifdef DL_DEV_SWITCHES      // timing-only ablations (results WRONG by construction) and schedule variants: dev build only
+        static const char *abl = DL_DEV_ENV("DL_CONV_ABLATE");
         if (abl && abl[0] == '1') return launch_conv_8ph_x3<DL_ACT_NONE, 1>(a, stream);
         if (abl && abl[0] == '2') return launch_conv_8ph_x3<DL_ACT_NONE, 2>(a, stream);
         if (abl && abl[0] == '3') return launch_conv_8ph_x3<DL_ACT_NONE, 3>(a, stream);
         if (abl && abl[0] == '4') return launch_conv_8ph_x3<DL_ACT_NONE, 4>(a, stream);
         if (a.in_split) return launch_conv_8ph_x3<DL_ACT_NONE, 0>(a, stream);      // (the timing variants below re-split their input)
-        static const char *var = getenv("DL_X3_VAR");
+        static const char *var = DL_DEV_ENV("DL_X3_VAR");
         if (var && var[0] == '1') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 1>(a, stream);
         if (var && var[0] == '2') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 2>(a, stream);
         if (var && var[0] == '3') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 3>(a, stream);
         if (var && var[0] == '4') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 4>(a, stream);
         if (var && var[0] == '5') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 5>(a, stream);
         if (var && var[0] == '8') return launch_conv_8ph_x3<DL_ACT_NONE, 0, 8>(a, stream);
+#endif
         return launch_conv_8ph_x3<DL_ACT_NONE, 0>(a, stream);
     }
     if (a.in_act == DL_ACT_RELU) return dispatch_glds_x3_tiles<DL_ACT_RELU>(a, stream);

@@ -412,7 +412,7 @@ static dim3 apply_grid(const NormGeom &g) {
     const int rows = 256 / (cvec < 256 ? cvec : 256);
     int bx = (g.HW + rows * 16 - 1) / (rows * 16);
     // A/B switch for the open launch-shape question (profiles/r01/pmc_norm/README.txt): DL_NORM_GRID_MUL scales the block count
-    static const float mul = [] { const char *e = getenv("DL_NORM_GRID_MUL"); const float v = e ? (float)atof(e) : 1.f; return v > 0.f ? v : 1.f; }();
+    static const float mul = [] { const char *e = DL_DEV_ENV("DL_NORM_GRID_MUL"); const float v = e ? (float)atof(e) : 1.f; return v > 0.f ? v : 1.f; }();
     const int want = (int)((2048 * mul + g.N - 1) / g.N);
     if (bx > want) bx = want;
     if (bx < 1) bx = 1;

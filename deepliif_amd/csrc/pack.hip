@@ -131,7 +131,7 @@ extern "C" int dl_pack_job_fill(const dl_pack_desc *d, const float *src, void *w
 extern "C" int dl_pack_batch_blocks(const void *jobs_host, int count, int32_t *block_tab_host) {
     if (!jobs_host || count < 0) DL_FAIL("dl_pack_batch_blocks: bad arguments");
     const size_t jb = dl_pack_job_bytes();
-    const char *sw = getenv("DL_PACK_TILED");           // A/B switch: 0 = every job in the chunk-per-thread form (the r01-r05 kernel)
+    const char *sw = dl_switch(DL_SW_PACK_TILED);           // A/B switch: 0 = every job in the chunk-per-thread form (the r01-r05 kernel)
     const bool tiled = !(sw && sw[0] == '0');
     long n = 0;
     for (int j = 0; j < count; ++j) {

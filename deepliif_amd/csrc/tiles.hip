@@ -121,7 +121,7 @@ __global__ void tile_paste_kernel(const T *__restrict__ tiles, int in_pstride, i
 
 // tiles / rectangles per launch (gridDim.y <= 65535); DL_TILE_GRID_Y=<n> overrides it so that the chunked path can be tested on small regions
 static int tile_grid_y() {
-    static const int v = [] { const char *e = getenv("DL_TILE_GRID_Y"); const int n = e ? atoi(e) : 0; return (n >= 1 && n <= 65535) ? n : 32768; }();
+    static const int v = [] { const char *e = DL_DEV_ENV("DL_TILE_GRID_Y"); const int n = e ? atoi(e) : 0; return (n >= 1 && n <= 65535) ? n : 32768; }();
     return v;
 }
 #define DL_TILE_GRID_Y (tile_grid_y())

@@ -874,7 +874,7 @@ static int dispatch_wgrad(const WgradArgs &a, hipStream_t stream) {
 // Tested r04 (DL_WGRAD_SLAB_PAD = 1088 and 4160 floats vs 0, same box, tools/gpu_r04_streams.sh): 94.75 / 94.69 vs 94.74-94.82 ms per step -- nothing;
 // the memory system hashes the channel.  The pad stays available (floats, default 0) because the slab size is now asked from the library anyway.
 static int wgrad_slab_pad() {
-    static const int pad = [] { const char *e = getenv("DL_WGRAD_SLAB_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
+    static const int pad = [] { const char *e = DL_DEV_ENV("DL_WGRAD_SLAB_PAD"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
     return pad;
 }
 
@@ -890,16 +890,16 @@ static int wgrad_kernel_of(const dl_wgrad_desc *d, int *err) {
     *err = 0;
     const int J = d->KH * d->KW * d->CBp;
     const long Ptot = (long)d->N * d->Hp * d->Wp;
-    static const bool no_glds = getenv("DL_NO_GLDS") != nullptr;
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;
     const bool fast = d->dtype == DL_BF16 && d->prec == DL_PREC_BF16 && d->p_act == DL_ACT_NONE && d->q_act == DL_ACT_NONE &&
                       d->pad_mode == DL_PAD_ZERO && J >= 256 && Ptot >= 64L * d->splitk && !no_glds;
     // "1": the four-phase schedule (wgrad_8ph_kernel).  OFF by default -- measured r02, same box, ResnetBlock shape, kernel + reduce:
     // 217-225 us vs 191-193 us for the one-barrier kernel in all three variants tried (reads retired before the first barrier; restage
     // two phases later without forced waits; address arithmetic moved into the MFMA shadow).  The one-barrier kernel alone is 172 us,
     // within 8 % of the forward's 8-phase kernel (155-160 us), so there was little left to win here.
-    static const char *w8 = getenv("DL_WGRAD_8PH");
+    static const char *w8 = DL_DEV_ENV("DL_WGRAD_8PH");
     // strict policy on the direct-to-LDS path (wgrad_x3.h); DL_NO_X3_GLDS=1: the round-1 register-staged kernel (A/B)
-    static const bool no_x3 = getenv("DL_NO_X3_GLDS") != nullptr;
+    const bool no_x3 = dl_switch(DL_SW_NO_X3_GLDS) != nullptr;
     const bool act_ok3 = (d->p_act == DL_ACT_NONE || d->p_act == DL_ACT_RELU || d->p_act == DL_ACT_LRELU) &&
                          (d->q_act == DL_ACT_NONE || d->q_act == DL_ACT_RELU || d->q_act == DL_ACT_LRELU);
     const bool fast3 = d->dtype == DL_F32 && d->prec == DL_PREC_BF16X3 && act_ok3 && d->pad_mode == DL_PAD_ZERO && J >= 256 &&
@@ -907,7 +907,7 @@ static int wgrad_kernel_of(const dl_wgrad_desc *d, int *err) {
     // DL_WGRAD_X3 = "2": the staggered two-phase schedule (wgrad_4ph_x3_kernel), "3": the same without s_setprio.  OFF by default -- measured r03,
     // same box, ResnetBlock shape, kernel + reduce: 627 us (604 without s_setprio) vs 577 us for the one-barrier kernel; PMC: the stagger
     // raises the time waves spend parked at barriers / waitcnt (43 % vs 28 % of wave cycles) more than it overlaps (MFMA-busy 31.6 % vs 35.6 %).
-    static const char *w3 = getenv("DL_WGRAD_X3");
+    static const char *w3 = DL_DEV_ENV("DL_WGRAD_X3");
     if ((d->p_split || d->q_split) && !(fast3 && (d->CAp % 128) == 0 && (!d->p_split || d->p_act == DL_ACT_NONE) && (!d->q_split || d->q_act == DL_ACT_NONE))) {
         *err = 1;
         return WK_GENERIC;
@@ -954,9 +954,9 @@ static int wgrad_slabs(const dl_wgrad_desc *d, const WgradLayers &lay, int n, hi
     a.dn = 32 / hw; a.dh = (32 % hw) / d->Wp; a.dw = (32 % hw) % d->Wp;
     a.p_act = d->p_act; a.q_act = d->q_act;
     a.p_split = d->p_split; a.q_split = d->q_split;
-    static const char *tr_env = getenv("DL_WGRAD_TR_ASM");            // A/B switch: "0" = the transposing reads through the builtin (rounds 2-4)
+    static const char *tr_env = DL_DEV_ENV("DL_WGRAD_TR_ASM");            // A/B switch: "0" = the transposing reads through the builtin (rounds 2-4)
     a.tr_asm = (tr_env && tr_env[0] == '0') ? 0 : 1;
-    static const char *xg_env = getenv("DL_WGRAD_XCDGROUP");          // A/B switch: "0" keeps the plain 2-D block order
+    static const char *xg_env = DL_DEV_ENV("DL_WGRAD_XCDGROUP");          // A/B switch: "0" keeps the plain 2-D block order
     a.xcd_group = (xg_env && xg_env[0] == '0') ? 0 : 1;
 
     int err = 0;
@@ -1023,7 +1023,10 @@ extern "C" int dl_wgrad_plan(const dl_wgrad_desc *d, int32_t *tiles, int32_t *ks
     if (tiles) *tiles = t;
     if (ksteps) *ksteps = ks;
     if (name) *name = nm;
-    return err ? -1 : multi;
+    if (err)
+        DL_FAIL("dl_wgrad_plan: split-copy operands (p_split / q_split) need the strict direct-to-LDS kernels: fp32 + BF16X3, zero padding, KH*KW*CBp >= 256, "
+                "CAp %% 128 == 0, pixel strides %% 4 == 0, no staged activation on a split operand (CAp=%d, J=%d, p_split=%d, q_split=%d)", d->CAp, J, d->p_split, d->q_split);
+    return multi;
 }
 
 static int reduce_blocks(const dl_wgrad_desc *d, int J) {

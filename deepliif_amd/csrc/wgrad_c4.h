@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) wgrad_c4_reduce_kernel(const float *slab,
 
 #define DL_WGRAD_C4_PARTS 512
 static int wgrad_c4_form(const dl_wgrad_desc *d) {          // 0: not eligible, 1: P wide / Q small (stem), 2: P small / Q wide (head)
-    static const bool off = dl_env_is_one("DL_NO_WGRAD_C4");       // "1" switches the kernel off (same parse as deepliif_amd/ops.py)
+    const bool off = dl_switch_is_one(DL_SW_NO_WGRAD_C4);       // "1" switches the kernel off (same parse as deepliif_amd/ops.py)
     if (off || d->dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->p_act != DL_ACT_NONE || d->q_act != DL_ACT_NONE) return 0;
     if (d->KH != 7 || d->KW != 7 || d->step != 1 || d->pad != 3 || (d->pad_w >= 0 && d->pad_w != 3) || d->pad_mode != DL_PAD_ZERO || d->stack_kw) return 0;
     if (d->Hp != d->Hq || d->Wp != d->Wq || d->Hp % 4 || d->Wp % 64 || d->splitk != DL_WGRAD_C4_PARTS) return 0;
@@ -192,7 +192,7 @@ static int launch_wgrad_c4(const dl_wgrad_desc *d, int form, const void *P, cons
     a.slab = slab;
     a.N = d->N; a.H = d->Hp; a.W = d->Wp;
     a.tiles_w = d->Wp / 64; a.tiles_h = d->Hp / 4;
-    static const char *abl_env = getenv("DL_WC4_ABL");
+    static const char *abl_env = DL_DEV_ENV("DL_WC4_ABL");
     a.abl = abl_env ? atoi(abl_env) : 0;
     const int ntiles = a.N * a.tiles_w * a.tiles_h;
     const int parts = ntiles < DL_WGRAD_C4_PARTS ? ntiles : DL_WGRAD_C4_PARTS;

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) wgrad_w4_kernel(const WgradW4Args a, cons
 
 // the layers this kernel serves (see the header comment)
 static bool w4w_eligible(const dl_wgrad_desc *d) {
-    static const bool off = getenv("DL_NO_WGRAD_W4") != nullptr;
+    static const bool off = DL_DEV_ENV("DL_NO_WGRAD_W4") != nullptr;
     if (off) return false;
     if (d->dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->p_act != DL_ACT_NONE || d->q_act != DL_ACT_NONE || d->pad_mode != DL_PAD_ZERO) return false;
     if (d->KH != 3 || d->KW != 3 || d->step != 1 || d->pad != 1 || (d->pad_w >= 0 && d->pad_w != 1) || d->stack_kw || d->p_split || d->q_split) return false;

@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_c4_x3_kernel(const WgradC4X3Args
 }
 
 static int wgrad_c4_x3_form(const dl_wgrad_desc *d) {          // as wgrad_c4_form, for fp32 operands + BF16X3
-    static const bool off = dl_env_is_one("DL_NO_WGRAD_C4") || getenv("DL_NO_C4_X3") != nullptr;
+    const bool off = dl_switch_is_one(DL_SW_NO_WGRAD_C4) || dl_switch(DL_SW_NO_C4_X3) != nullptr;
     if (off || d->dtype != DL_F32 || d->prec != DL_PREC_BF16X3 || d->p_act != DL_ACT_NONE || d->q_act != DL_ACT_NONE || d->p_split || d->q_split) return 0;
     if (d->KH != 7 || d->KW != 7 || d->step != 1 || d->pad != 3 || (d->pad_w >= 0 && d->pad_w != 3) || d->pad_mode != DL_PAD_ZERO || d->stack_kw) return 0;
     if (d->Hp != d->Hq || d->Wp != d->Wq || d->Hp % 4 || d->Wp % 64 || d->splitk != DL_WGRAD_C4_PARTS) return 0;

@@ -188,13 +188,14 @@ def diff_original_serialized(original, serialized, example: torch.Tensor, verbos
         b = serialized(example.clone()).detach().float().cpu()
     d = (a - b).abs()
     total = float(d.sum())
-    if mean_tol is not None:
-        assert total <= mean_tol * d.numel(), f'the two models differ by {total / d.numel():.3e} per output value on average (bound {mean_tol:.0e})'
+    if mean_tol is not None and total > mean_tol * d.numel():         # (an explicit exception: `python -O` strips asserts)
+        raise AssertionError(f'the two models differ by {total / d.numel():.3e} per output value on average (bound {mean_tol:.0e})')
     if verbose > 0:
         print('Original:', tuple(a.shape), 'min abs value:{}'.format(float(a.abs().min())))
         print('Torchscript:', tuple(b.shape), 'min abs value:{}'.format(float(b.abs().min())))
         print('Dif sum:', total, 'max dif:{}'.format(float(d.max())))
-    assert total <= threshold, f'Sum of difference in predicted values {total} is larger than threshold {threshold}'
+    if total > threshold:                  # the reference's own check (util/__init__.py:739) as an exception that survives `python -O`
+        raise AssertionError(f'Sum of difference in predicted values {total} is larger than threshold {threshold}')
     return total
 
 
@@ -247,6 +248,8 @@ def serialize(model_dir: str, output_dir: Optional[str] = None, device: str = 'c
             if total > SIMILARITY_THRESHOLD:
                 print(f'note: engine ({check_precision} policy) vs serialized sum |diff| = {total:.2f} > {SIMILARITY_THRESHOLD:g}: fp32 rounding noise between two '
                       f'implementations (bound: a mean of {ENGINE_MEAN_ABS_TOL:.0e} per value); the reference compares one implementation with itself')
-            report[name] = total
+            # callers that compare report[name] with the reference's threshold of 10 must not be misled by the relaxed engine check:
+            # report[name] stays the REFERENCE test's value (eager ATen vs file), the engine's distance goes next to it
+            report[name + '@engine'] = total
         print('PASS')
     return report

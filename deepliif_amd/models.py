@@ -156,6 +156,12 @@ class StepGraph:
                 o.step_eager_once = True
             m.set_input(batch)
             m.optimize_parameters()
+            if self.graph is not None and ops.Workspace.realloc_generation != self._ws_generation:
+                # the odd batch was LARGER than the captured one somewhere: a grow-only scratch buffer or the slab arena was replaced, and the graph's kernel
+                # nodes still carry the old (now freed) addresses.  Drop the graph; the next fitting batches warm up and capture again.
+                torch.cuda.synchronize()
+                self.graph, self.calls = None, 0
+                self.recaptures = getattr(self, 'recaptures', 0) + 1
             return
         static = self._to_static(batch)
         for o in m.optimizers:
@@ -197,6 +203,7 @@ class StepGraph:
                 m.optimize_parameters()
                 return
             self.graph = g
+            self._ws_generation = ops.Workspace.realloc_generation
             g.replay()                  # capture records, it does not execute: this step's work
 
 

@@ -126,10 +126,17 @@ class Workspace:
         """every per-stream state of this thread (empty unless branch_streams_on() was called)"""
         return list(self._thread_state().get('streams', {}).values())
 
+    # Counts every REPLACEMENT of a scratch buffer or slab arena that already existed (process-wide, monotonic).  A captured step (models.StepGraph) has the
+    # addresses of these buffers baked into its kernel nodes; when a later eager step needs more scratch, the old buffer goes back to the allocator and
+    # every replay would write into freed memory (ADVICE r5): StepGraph compares this counter and re-captures.
+    realloc_generation = 0
+
     def get(self, name: str, nfloats: int, device) -> torch.Tensor:
         bufs = self._state()['bufs']
         b = bufs.get(name)
         if b is None or b.numel() < nfloats or b.device != device:
+            if b is not None:
+                Workspace.realloc_generation += 1
             b = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
             bufs[name] = b
         return b
@@ -400,6 +407,8 @@ class HipBackend:
             self._reduce_pending(st)
         if arena is None or arena.numel() < need or arena.device != device:
             self._reduce_pending(st)
+            if arena is not None:
+                Workspace.realloc_generation += 1          # (see Workspace.realloc_generation: a captured graph holds the old arena's address)
             arena = torch.empty(max(need, _WGRAD_ARENA_MB * (1 << 18)), dtype=torch.float32, device=device)
             st['defer_arena'], st['defer_off'] = arena, 0
         off = st.get('defer_off', 0)
@@ -413,7 +422,13 @@ class HipBackend:
             self.wgrad_flush()
         st['defer_grads'].add(gp)
         d.splitk = choose_wgrad_batch_splitk(tiles, ksteps)
-        st.setdefault('defer_queue', []).append((bytes(d), d, P, Q, grad))
+        queue = st.setdefault('defer_queue', [])
+        queue.append((bytes(d), d, P, Q, grad))
+        # a launch takes at most WGRAD_MULTI_MAX layers anyway: once that many are queued (a tape that never reaches a network marker -- CycleGAN, KD, direct
+        # Tape users -- would otherwise keep the operands of EVERY layer of the pass alive, 2 x 67 MB each at batch 8), compute them now.  A layer's split-K
+        # does not depend on how many layers share its launch, so the bits are the same.
+        if len(queue) >= L.WGRAD_MULTI_MAX:
+            self._launch_queued(st)
 
     def _launch_queued(self, st):
         """one dl_conv_wgrad_multi per group of same-descriptor layers (<= WGRAD_MULTI_MAX each); their reductions join the pending list"""

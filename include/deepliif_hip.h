@@ -4,7 +4,8 @@
  * The reference (nadeemlab/DeepLIIF) has no native layer: its hot path is a sequence of torch.nn module calls
  * (SURVEY.md 2.2).  Each entry point below replaces one family of those calls; the citation is the reference
  * call site (paths relative to /root/reference).  Everything is `extern "C"`, plain pointers and sizes, caller-owned
- * device memory, an explicit hipStream_t (passed as void*), no hidden global stream, no allocation, thread-safe.
+ * device memory, an explicit hipStream_t (passed as void*), no hidden global stream, no allocation, thread-safe
+ * (the only process-wide state is the table of runtime switches below, filled once when the library is loaded and read-only afterwards).
  * Return value: 0 = ok, negative = error (message via dl_last_error(), thread-local).
  * Arguments are validated on the host before anything is launched; an empty problem (N = 0 or a zero-sized image) is an error
  * ("empty problem ..."), not a no-op: the reference never produces one and a silent success would hide a caller bug.
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 112
+#define DL_VERSION 113
 
 enum { DL_F32 = 0, DL_BF16 = 1 };
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
@@ -45,6 +46,26 @@ enum { DL_LOSS_BCE_LOGITS = 0, DL_LOSS_MSE = 1, DL_LOSS_SMOOTH_L1 = 2, DL_LOSS_L
 
 int dl_version(void);
 const char *dl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Runtime switches.  The shipped library looks at EIGHT environment variables, each a choice between two CORRECT code paths (kept for same-box A/B
+ * measurements and for tests that must reach a kernel at small sizes).  They are copied out of the environment ONCE, when the library is loaded; no entry
+ * point calls getenv.  Anything that can change RESULTS (timing-only ablations) or selects superseded kernel variants exists only in the dev build
+ * (`make -C deepliif_amd/csrc dev` -> libdeepliif_hip_dev.so, compiled with -DDL_DEV_SWITCHES; dl_dev_build() == 1), which tools/ load explicitly.
+ *   DL_CONV_S2F=0      stride-2 transposed convs / stride-2 data gradients on the 4-phase gather GEMM instead of conv_s2f_kernel; =2 lifts its size rule
+ *   DL_CONV_S2FX3=0    the same for the strict policy's conv_s2f_x3_kernel
+ *   DL_CONV_S2D=0      ResnetGenerator down1 forward / up2 data gradient on the gather GEMM instead of conv_s2d_kernel
+ *   DL_CONV_W4X3=1     strict ResnetBlock conv on conv_gemm_w4x3_kernel (opt-in; a measured tie with the default 8-phase strict kernel)
+ *   DL_PACK_TILED=0    dl_pack_weights_batch with every image in the chunk-per-thread form
+ *   DL_NO_X3_GLDS      (set) strict policy on the register-staged round-1 kernels           -- deepliif_amd/ops.py reads the same variable
+ *   DL_NO_WGRAD_C4=1   7x7 stem / head weight gradient on the general kernels               -- deepliif_amd/ops.py reads the same variable
+ *   DL_NO_C4_X3        (set) strict 7x7 stem / head on the general strict kernels           -- deepliif_amd/ops.py reads the same variable
+ * dl_switches_reload() re-reads the eight variables (tests that flip one inside a process); NOT thread-safe against concurrent launches.
+ * ---------------------------------------------------------------------------------------------------------- */
+int dl_switch_count(void);
+const char *dl_switch_name(int id);          /* 0 <= id < dl_switch_count() */
+void dl_switches_reload(void);
+int dl_dev_build(void);                      /* 1: compiled with -DDL_DEV_SWITCHES (A/B variants and timing-only ablations reachable); 0: the shipped library */
 /* number of bytes of fp32 scratch a call needs; see each function */
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -173,7 +194,7 @@ int dl_wgrad_reduce_batch(const dl_wgrad_reduce_entry *table_dev, int count, int
  *   dl_wgrad_plan        which kernel dl_conv_wgrad would run for `d` (pass splitk = 1): *tiles = its output tiles per layer, *ksteps = K steps of one
  *                        tile at split-K 1, *name = kernel name (static string, diagnostic); returns 1 when that kernel has a batched form, 0 when
  *                        not, < 0 on error.  Callers size split-K from it: one layer: tiles x splitk ~ one round of 256 CUs; a batch: see
- *                        deepliif_amd/geometry.py choose_wgrad_multi_splitk.
+ *                        deepliif_amd/geometry.py choose_wgrad_batch_splitk.
  *   dl_conv_wgrad_multi  n <= DL_WGRAD_MULTI_MAX layers sharing the descriptor `d` (HOST arrays P[n], Q[n], grad[n]) in one split-K launch; layer
  *                        l's slabs start at slab + l * dl_wgrad_slab_floats(d); entries_host[l] = its pending reduction for dl_wgrad_reduce_batch
  *                        (as dl_conv_wgrad_slabs).  Per element the result is the fixed-order sum of d->splitk partials: deterministic, and

@@ -30,6 +30,35 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.dl_last_error(), bytes)
 
 
+def test_shipped_library_has_no_result_changing_switches():
+    """the default build carries no timing-only ablation (results wrong by construction) and no getenv on a launch path -- the only
+    environment variables it knows are the eight documented A/B switches of include/deepliif_hip.h, copied once at load time."""
+    lib = L.load()
+    if os.environ.get('DEEPLIIF_AMD_LIB'):
+        pytest.skip('a non-default library was selected')
+    assert lib.dl_dev_build() == 0
+    names = [lib.dl_switch_name(i).decode() for i in range(lib.dl_switch_count())]
+    assert len(names) == 8 and len(set(names)) == 8
+    header = open(HEADER).read()
+    for n in names:
+        assert n in header, f'{n} is not documented in include/deepliif_hip.h'
+    blob = open(L.LIB_PATH, 'rb').read()
+    found = sorted(set(m.decode() for m in re.findall(rb'DL_[A-Z0-9_]{3,}', blob)))
+    assert not [f for f in found if 'ABL' in f], found           # DL_CONV_ABLATE, DL_W4_ABLATE, DL_C4_ABL ... are gone
+    assert sorted(f for f in found if f in names) == sorted(names)
+    extra = [f for f in found if f not in names]
+    assert not extra, f'undocumented switch strings in the shipped library: {extra}'
+    # every getenv in the sources goes through the load-time table (error.cpp) or the dev-only macro
+    csrc = os.path.join(ROOT, 'deepliif_amd', 'csrc')
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(('.hip', '.h', '.cpp')):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, fn)), 1):
+            code = line.split('//')[0]
+            if 'getenv(' in code and fn != 'error.cpp' and '#define DL_DEV_ENV' not in code:
+                raise AssertionError(f'{fn}:{i}: getenv outside the switch table: {line.strip()}')
+
+
 def test_ctypes_struct_sizes_match_the_header(tmp_path):
     c = tmp_path / 'sz.c'
     c.write_text('#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n", sizeof(dl_conv_desc), sizeof(dl_wgrad_desc), '

@@ -346,10 +346,12 @@ def test_pack_weights_batch_matches_single_packs():
         if single.lo is not None:
             assert torch.equal(batched.lo.view(torch.int16), single.lo.view(torch.int16))
     os.environ['DL_PACK_TILED'] = '0'                           # the A/B switch: every job in the chunk-per-thread form
+    L.load().dl_switches_reload()                               # (the library reads its switches once, at load)
     try:
         chunk_table = be.pack_batch_build(jobs)
     finally:
         del os.environ['DL_PACK_TILED']
+        L.load().dl_switches_reload()
     assert not ((chunk_table[1][0::2] & (1 << 30)) != 0).any()
     for batched, _ in jobs:
         batched.hi.fill_(float('nan'))

@@ -100,10 +100,17 @@ def test_block_table_of_the_shipped_library(monkeypatch):
         assert int(lib.dl_pack_batch_blocks(C.c_void_p(base), len(descs), C.c_void_p(C.addressof(tab)))) == n
         return [(tab[2 * i], tab[2 * i + 1]) for i in range(n)]
 
+    # the library copies its eight runtime switches out of the environment when it is loaded: a test that flips one re-reads the table
     monkeypatch.delenv('DL_PACK_TILED', raising=False)
+    lib.dl_switches_reload()
     tiled = table()
     monkeypatch.setenv('DL_PACK_TILED', '0')
-    chunk = table()
+    lib.dl_switches_reload()
+    try:
+        chunk = table()
+    finally:
+        monkeypatch.delenv('DL_PACK_TILED', raising=False)
+        lib.dl_switches_reload()
     flag = 1 << 30
     assert not any(j & flag for j, _ in chunk)
     for i, (_, _, d) in enumerate(descs):
