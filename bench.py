@@ -41,6 +41,8 @@ GF_PER_TILE_TRAIN_18NETS = 7051.0     # real DeepLIIF (4 Resnet-9 +
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 STRICT_PMC_FILE = os.path.join('r03', 'pmc_strict_conv256.json')     # the same passes over the strict ResnetBlock kernel (tools/gpu_r03_pmc_strict.sh)
+N8_FULL_FILE = os.path.join('r06', 'cpu_baseline_n8_full.json')     # bench.py --cpu-baseline-n8-full: the oracle at batch 8, 512 x 512 (SURVEY 8d on-spec)
+TRAJECTORY_FILE = os.path.join('r06', 'trajectory_r06.json')  # tests/test_gpu_trajectory.py: 100-step loss curves of both policies vs the oracle
 PMC_FILE = os.path.join('r05', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
@@ -285,6 +287,8 @@ def main():
                     '8 = the per-GPU batch of the GPU line (SURVEY 8d asks for both), ~2 minutes of CPU work')
     ap.add_argument('--no-cpu-baseline-n8', action='store_true', help='skip the second CPU leg at the per-GPU batch of the GPU line (batch 8: 1 warm-up + up to 3 '
                     'steps inside a 100 s budget, about 2 minutes of CPU work)')
+    ap.add_argument('--cpu-baseline-n8-full', action='store_true', help='time the second CPU leg ON SPEC: batch 8 at 512x512, 1 warm-up + 1 step (~100-200 s, ~105 GB of host '
+                    'memory) instead of the scaled 256x256 sample; writes gpurun_out/cpu_baseline_n8_full.json')
     ap.add_argument('--no-other-workloads', action='store_true', help='the default train run appends short measurements of the infer / train18 / ext / wsi workloads '
                     '(other_workloads); this skips them')
     ap.add_argument('--no-wsi-whole', action='store_true', help='wsi workload: skip the end-to-end pass over the WHOLE region (all tiles + gather of the bands + stitch)')
@@ -610,6 +614,19 @@ def main():
             except Exception:
                 pass
         del smodel, sstep
+    if strict is not None:
+        # multi-step fidelity of BOTH policies against the oracle (tests/test_gpu_trajectory.py): the committed summary of the 100-step curves, not measured here
+        try:
+            with open(os.path.join(ROOT, 'profiles', TRAJECTORY_FILE)) as f:
+                tj = json.load(f)
+            strict['trajectory'] = {'what': 'mean over steps and the 20 losses of |L - L_oracle| / max(1, |L_oracle|) along optimize_parameters() trajectories from identical weights '
+                                            'and batches; oracle_noise = the oracle against itself with fp32-sized rounding noise on every conv output (the band two correct '
+                                            'fp32-class implementations differ by)',
+                                    'config': {k: tj['config'][k] for k in ('steps', 'ngf', 'size', 'batch', 'norm')}, 'step0_max': tj.get('step0_max'), 'first10_max': tj['first10_max'], 'mean': tj['mean'],
+                                    'last20_mean_curve': tj['last20_mean_curve'], 'bands_asserted': tj.get('bands'),
+                                    'source': f'NOT measured in this run: profiles/{TRAJECTORY_FILE}, written by tests/test_gpu_trajectory.py on an MI355X'}
+        except Exception:
+            pass
 
     # ---- hipGraph leg: the same steps replayed from ONE captured graph (models.StepGraph): what the step costs when Python is out of it.  The headline
     # `value` above is the EAGER step (it carries the per-launch events the roofline block needs); this leg runs LAST, on the same model.
@@ -723,7 +740,22 @@ def main():
             # "N=1 (reference default batch_size) and N=8": the same oracle at the GPU line's per-GPU batch.  A batch-8 step at
             # 512x512 takes ~100 s on 16 host cores (measured r03), so this leg runs 256x256 tiles (reported in 512x512-tile equivalents by
             # pixel count, like the fallback of the N=1 leg): 1 warm-up + 2-3 steps, about a minute of CPU work
-            out['cpu_baseline_n8'] = cpu_baseline(args, batch=args.batch, budget=40.0, half_tile=True)
+            if args.cpu_baseline_n8_full:
+                # SURVEY 8(d) on-spec: batch 8 at 512 x 512 on the host cores, 1 warm-up + 1 timed step (~100-200 s and ~105 GB of host memory): behind a flag the
+                # driver's command does not set; the result is committed as profiles/r06/cpu_baseline_n8_full.json and quoted by the default run below
+                full = cpu_baseline(args, batch=args.batch, budget=1.0, half_tile=False)
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                with open(os.path.join(ROOT, 'gpurun_out', 'cpu_baseline_n8_full.json'), 'w') as f:
+                    json.dump(full, f, indent=1)
+                out['cpu_baseline_n8'] = full
+            else:
+                out['cpu_baseline_n8'] = cpu_baseline(args, batch=args.batch, budget=40.0, half_tile=True)
+                out['cpu_baseline_n8']['note'] = 'quick leg of the default run: 256x256 tiles scaled by pixel count; the on-spec measurement (batch 8 at 512x512) is in on_spec'
+                try:
+                    with open(os.path.join(ROOT, 'profiles', N8_FULL_FILE)) as f:
+                        out['cpu_baseline_n8']['on_spec'] = dict(json.load(f), source=f'NOT measured in this run: profiles/{N8_FULL_FILE} (bench.py --cpu-baseline-n8-full on an MI355X box)')
+                except Exception:
+                    pass
     else:
         out['cpu_baseline'] = None
         out['cpu_baseline_note'] = ('disabled by --no-cpu-baseline' if args.no_cpu_baseline else

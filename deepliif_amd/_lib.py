@@ -85,6 +85,8 @@ SIGNATURES = {
     'dl_pp_finish': (_i, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     'dl_conv_forward_bnstats': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvBnStats), _vp]),
     'dl_conv_kernel_name': (C.c_char_p, [C.POINTER(ConvDesc)]),
+    'dl_conv_add_supported': (_i, [C.POINTER(ConvDesc)]),
+    'dl_conv_forward_add': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'dl_conv_wgrad': (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_wgrad_deferrable': (_i, [C.POINTER(WgradDesc)]),
     'dl_wgrad_slab_floats': (C.c_size_t, [C.POINTER(WgradDesc)]),

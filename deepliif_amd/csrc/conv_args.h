@@ -28,6 +28,9 @@ struct ConvArgs {
     const bf16_t *bn_y;
     const float *bn_mean, *bn_rstd, *bn_scale, *bn_shift;
     int bn_y_pstride, bn_act;
+    // dl_conv_forward_add: out = conv + addend (bf16, same pixels / channels as out); only the kernels dl_conv_add_supported() names read it
+    const bf16_t *add;
+    int add_pstride;
     int16_t taps[DL_MAX_TAPS];      // (dh & 0xff) | (dw << 8)
 };
 

@@ -1538,6 +1538,16 @@ static bool w4_enabled() {
     return !(w4 && w4[0] == '0');
 }
 
+// EXPERIMENT (dev build, DL_CONV_T256X128=1): 256 x 128 tiles (8 waves of 64 px x 64 ch, 85 flop per staged byte instead of 64) where they fill the chip
+static bool t256x128_applies(int mtot, int Co, int n_phase, int splitk) {
+#ifdef DL_DEV_SWITCHES
+    static const char *e = DL_DEV_ENV("DL_CONV_T256X128");
+    return e && e[0] == '1' && Co >= 128 && (Co % 128) == 0 && (size_t)((mtot + 255) / 256) * (Co / 128) * n_phase * splitk >= 224;
+#else
+    return false;
+#endif
+}
+
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
@@ -1582,6 +1592,9 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
 #endif
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
+#ifdef DL_DEV_SWITCHES
+    if (t256x128_applies(a.Mtot, a.Co, a.n_phase, a.splitk)) return launch_conv_glds<256, 128, 64, 4, 2>(a, stream);
+#endif
     return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
 }
 
@@ -1703,6 +1716,7 @@ static int glds_tile_bm(const dl_conv_desc *d) {
     static const bool no_big = DL_DEV_ENV("DL_NO_BIGTILE") != nullptr;
     const int mtot = d->N * d->Hq * d->Wq;
     if (!no_big && big_tile_fills_gpu(mtot, d->Co, d->n_phase, d->splitk)) return 256;
+    if (t256x128_applies(mtot, d->Co, d->n_phase, d->splitk)) return 256;
     return 128;
 }
 
@@ -1780,11 +1794,26 @@ extern "C" int dl_conv_bnstats_chunks(const dl_conv_desc *d) {
 }
 
 static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
-                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_);
+                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_, const void *add = nullptr, int add_pstride = 0);
 
 extern "C" int dl_conv_forward(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
                                void *out, float *slab, float *stats_part, void *stream_) {
     return conv_forward_impl(d, in, w_hi, w_lo, bias, out, slab, stats_part, nullptr, stream_);
+}
+
+// out = conv(in) + addend in ONE pass (the addend is added in fp32 before the bf16 rounding of the store): the kernels that can do it in their store
+// epilogue -- today conv_gemm_w4_kernel, the ResnetBlock shape, where the data gradient of the block's first conv meets the gradient that came down the skip
+// connection (networks.py:509-513: out = x + conv_block(x)).  `addend` may be `out` itself (every thread reads its 16 bytes before it writes them).
+extern "C" int dl_conv_add_supported(const dl_conv_desc *d) {
+    return d && d->splitk == 1 && !d->raw_out && strcmp(dl_conv_kernel_name(d), "conv_gemm_w4_kernel") == 0;
+}
+
+extern "C" int dl_conv_forward_add(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const void *addend, int32_t addend_pstride,
+                                   void *out, void *stream_) {
+    if (!addend) DL_FAIL("dl_conv_forward_add: null addend");
+    if (addend_pstride % 8) DL_FAIL("dl_conv_forward_add: addend_pstride must keep 16-byte alignment");
+    if (!dl_conv_add_supported(d)) DL_FAIL("dl_conv_forward_add: not available for this descriptor (ask dl_conv_add_supported first)");
+    return conv_forward_impl(d, in, w_hi, w_lo, nullptr, out, nullptr, nullptr, nullptr, stream_, addend, addend_pstride);
 }
 
 extern "C" int dl_conv_forward_bnstats(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, void *out,
@@ -1798,7 +1827,7 @@ extern "C" int dl_conv_forward_bnstats(const dl_conv_desc *d, const void *in, co
 }
 
 static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const float *bias,
-                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_) {
+                             void *out, float *slab, float *stats_part, const dl_conv_bnstats *bn, void *stream_, const void *add, int add_pstride) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d) DL_FAIL("dl_conv_forward: null descriptor");
     if (d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hq <= 0 || d->Wq <= 0)
@@ -1842,6 +1871,8 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
         if (a.stats_nchunks == 0) DL_FAIL("dl_conv_forward: fused statistics are not available for this descriptor (ask dl_conv_stats_chunks first)");
         a.stats_part = stats_part;
     }
+    a.add = (const bf16_t *)add;
+    a.add_pstride = add_pstride;
     if (bn) {
         a.bn_y = (const bf16_t *)bn->y; a.bn_y_pstride = bn->y_pstride; a.bn_act = bn->act;
         a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; a.bn_scale = bn->scale; a.bn_shift = bn->shift;

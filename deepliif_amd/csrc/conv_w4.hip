@@ -49,7 +49,7 @@ constexpr int W4_BUF = 256 * 128;                     // one weight buffer (256 
 constexpr int W4_X0 = 1 * W4_BUF;                     // slab s at W4_X0 + s * W4_BUF
 __host__ __device__ constexpr int w4_wofs(int b) { return b == 0 ? 0 : (b == 1 ? 3 * W4_BUF : 4 * W4_BUF); }
 constexpr size_t W4_LOOP_LDS = (size_t)5 * W4_BUF;
-constexpr size_t W4_EPI_LDS = (size_t)256 * 512 + 256 * sizeof(int) + (size_t)2 * 2 * 256 * sizeof(float) + 256 * sizeof(float);
+constexpr size_t W4_EPI_LDS = (size_t)256 * 512 + 256 * sizeof(int) + (size_t)4 * 2 * 256 * sizeof(float) + 256 * sizeof(float);
 constexpr size_t W4_LDS = W4_LOOP_LDS > W4_EPI_LDS ? W4_LOOP_LDS : W4_EPI_LDS;
 static_assert(W4_LDS <= 160 * 1024, "the whole LDS of a CU");
 
@@ -352,12 +352,12 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     // ---- epilogue.  acc[i][j][r] = out[pixel = wm*128 + j*32 + lr][channel = wn*128 + i*32 + 8*(r>>2) + 4*lh + (r&3)]
     lds_char_t *tile = lds;                                                         // [256 pixels][256 channels] bf16, 8-byte units XOR-swizzled by the pixel
     __attribute__((address_space(3))) int *rowtab = reinterpret_cast<__attribute__((address_space(3))) int *>(lds + 256 * 512);
-    __attribute__((address_space(3))) float *red = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4);       // [wm][2][256]
+    __attribute__((address_space(3))) float *red = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4);       // [wave][2][256]
     // the tile's 256 bias values reach the accumulator pass through LDS (r05): fetched inside the pass, hipcc had made them four guarded dword loads and an
     // s_waitcnt vmcnt(0) per (i, q); 64 registers of preloaded float4s made the allocator spill.  (Isolated 20-launch timings seemed to show a bias costing
     // 9-12 us whatever its fetch; a probe that repeated the SAME launch found 138.8 us first and 122.6 us six measurements later -- the clock drifts for seconds
     // under the power cap, profiles/r05/bias_probe_clock_drift.txt -- so effects below ~10 us are read from the in-step rocprof averages only.)
-    __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 4 * 256 * 4);
+    __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 8 * 256 * 4);
     const bool want_stats = a.stats_part != nullptr;
     {
         const int m = m0 + tid;
@@ -372,17 +372,17 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
         bias_lds[tid] = (a.bias && cb < a.bias_n) ? a.bias[cb] : 0.f;
     }
     __syncthreads();
-    // the two run-time choices of this pass (ReLU, statistics) as COMPILE-TIME flags of four copies of it (r05): tested per (i, q, j) they had cut the pass into
-    // ~130 basic blocks of a dozen instructions, each behind a scalar branch
-    auto acc_pass = [&](auto RELUc, auto STATSc) __attribute__((always_inline)) {
-        constexpr bool RELU = decltype(RELUc)::value != 0, STATS = decltype(STATSc)::value != 0;
+    // ReLU as a COMPILE-TIME flag of two copies of this pass (r05: tested per (i, q, j) it had cut the pass into basic blocks behind scalar branches).
+    // The statistics left this pass in r06: per (i, q) they cost eight 16-lane DPP reductions + a cross-half shuffle of values every LANE held for different
+    // pixels; the store pass below gives every THREAD the same 8 channels for all of its 32 pixels, so the sums run in registers and meet once.
+    auto acc_pass = [&](auto RELUc) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(RELUc)::value != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = wn * 128 + i * 32 + q * 8 + lh * 4;           // channel inside the tile
                 const f32x4_t bias = *reinterpret_cast<__attribute__((address_space(3))) const f32x4_t *>(bias_lds + cl);
-                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
                 const int unit = (cl >> 2) ^ (((lr & 15) << 1) & 62);
                 lds_char_t *dst = tile + (wm * 128 + lr) * 512 + unit * 8;
 #pragma unroll
@@ -398,53 +398,77 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
                     p[0] = pack2_bf16(v[0], v[1]);
                     p[1] = pack2_bf16(v[2], v[3]);
                     *reinterpret_cast<__attribute__((address_space(3))) u32x2_t *>(dst + j * 32 * 512) = p;
-                    if constexpr (STATS) {          // statistics of exactly what is stored (bf16-rounded), like the stand-alone kernel sees
-                        const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                        const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
-                        s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
-                        s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
-                    }
-                }
-                if constexpr (STATS) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1[e] = w4_row16_sum(s1[e]); s2[e] = w4_row16_sum(s2[e]);
-                        s1[e] += __shfl_xor(s1[e], 16, 64); s2[e] += __shfl_xor(s2[e], 16, 64);
-                    }
-                    if (lr == 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            red[(wm * 2 + 0) * 256 + cl + e] = s1[e];
-                            red[(wm * 2 + 1) * 256 + cl + e] = s2[e];
-                        }
-                    }
                 }
             }
     };
-    if (want_stats) {
-        if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}, W4IC<1>{}); else acc_pass(W4IC<0>{}, W4IC<1>{});
-    } else {
-        if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}, W4IC<0>{}); else acc_pass(W4IC<0>{}, W4IC<0>{});
+    const bool want_add = a.add != nullptr;
+    u32x4_t pre[16];
+    if (want_add && tn * 256 + (tid & 31) * 8 < a.Co) {
+        const bf16_t *addp = a.add + (size_t)(m0 + (tid >> 5)) * a.add_pstride + tn * 256 + (tid & 31) * 8;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (m0 + (tid >> 5) + 8 * k < a.Mtot) pre[k] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * k) * a.add_pstride);
     }
+    if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}); else acc_pass(W4IC<0>{});
     __syncthreads();
     bf16_t *out = reinterpret_cast<bf16_t *>(a.out);
-#pragma unroll 4
-    for (int idx = tid; idx < 256 * 32; idx += 256) {
-        const int row = idx >> 5, cc = idx & 31;
-        const int opix = rowtab[row];
-        const int co = tn * 256 + cc * 8;
-        if (opix < 0 || co >= a.Co) continue;
-        const int unit = (cc * 2) ^ (((row & 15) << 1) & 62);
-        const u32x4_t v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4_t *>(tile + row * 512 + unit * 8);
-        *reinterpret_cast<u32x4_t *>(out + (size_t)opix * a.out_pstride + co) = v;
-    }
+    // store pass: thread t owns 16-byte chunk t & 31 (channels (t & 31) * 8 ..) of pixel rows (t >> 5) + 8 k.  Two compile-time options:
+    //   ADD   (dl_conv_forward_add): out = bf16(conv + addend) -- the residual block's "gradient so far" is added here instead of by a separate pass over
+    //         both tensors (Act.add_grad's axpby: 2 reads + 1 write of 67 MB for every ResnetBlock of the data-gradient chain);
+    //   STATS the fused norm statistics of exactly the values that are stored (bf16-rounded).
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    const int cc = tid & 31;
+    const int co_t = tn * 256 + cc * 8;
+    // (ADD: the thread's 32 addend chunks are PREFETCHED -- rows 0..15 before the accumulator pass, row k + 16 as soon as row k's register is free: fetched
+    // inside the loop, four at a time behind their stores, the pass paid one HBM round trip per four rows and cost as much as the axpby it replaced)
+    auto store_pass = [&](auto ADDc, auto STATSc, u32x4_t (&pre)[16]) __attribute__((always_inline)) {
+        constexpr bool ADD = decltype(ADDc)::value != 0, STATS = decltype(STATSc)::value != 0;
+        if (co_t >= a.Co) return;
+        const bf16_t *addp = ADD ? a.add + (size_t)(m0 + (tid >> 5)) * a.add_pstride + co_t : nullptr;       // w4 shapes: output pixel index = m
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int row = (tid >> 5) + 8 * k;
+            const bool live = m0 + row < a.Mtot;
+            const int unit = (cc * 2) ^ (((row & 15) << 1) & 62);
+            u32x4_t v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4_t *>(tile + row * 512 + unit * 8);
+            if constexpr (ADD) {
+                const u32x4_t r = pre[k & 15];
+                if (k + 16 < 32 && m0 + row + 128 < a.Mtot) pre[k & 15] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * (k + 16)) * a.add_pstride);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2_bf16(__uint_as_float(v[e] << 16) + __uint_as_float(r[e] << 16), __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(r[e] & 0xffff0000u));
+            }
+            if (live) {
+                *reinterpret_cast<u32x4_t *>(out + (size_t)(m0 + row) * a.out_pstride + co_t) = v;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        s1[2 * e] += lo; s2[2 * e] += lo * lo; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+                    }
+                }
+            }
+        }
+    };
+    if (want_stats) { if (want_add) store_pass(W4IC<1>{}, W4IC<1>{}, pre); else store_pass(W4IC<0>{}, W4IC<1>{}, pre); }
+    else { if (want_add) store_pass(W4IC<1>{}, W4IC<0>{}, pre); else store_pass(W4IC<0>{}, W4IC<0>{}, pre); }
     if (want_stats) {
+        // the 8 threads of a channel group are lanes c, c + 32 of the four waves: one shuffle, then the waves meet in LDS (fixed order: deterministic)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t1 = s1[e], t2 = s2[e];
+            t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+            if (lane < 32) { red[(wave * 2 + 0) * 256 + lane * 8 + e] = t1; red[(wave * 2 + 1) * 256 + lane * 8 + e] = t2; }
+        }
+        __syncthreads();
         const int chunk = (m0 - n_img * HWq) >> 8;                 // tile inside its image (n_phase == 1)
         const int co = tn * 256 + tid;
         if (co < a.Co) {
             float *o = a.stats_part + ((size_t)(n_img * a.stats_nchunks + chunk) * 2) * a.Co + co;
-            o[0] = red[0 * 256 + tid] + red[2 * 256 + tid];
-            o[a.Co] = red[1 * 256 + tid] + red[3 * 256 + tid];
+            o[0] = (red[0 * 256 + tid] + red[2 * 256 + tid]) + (red[4 * 256 + tid] + red[6 * 256 + tid]);
+            o[a.Co] = (red[1 * 256 + tid] + red[3 * 256 + tid]) + (red[5 * 256 + tid] + red[7 * 256 + tid]);
         }
     }
 }

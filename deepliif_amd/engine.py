@@ -480,7 +480,6 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 be.act_backward(in_act, dx, x.t, dx)
             x.add_grad(dx)
         elif x_needs:
-            dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
             if spec.kind == 'conv' and spec.stride == 2:
                 # four sub-pixel phases over a ceil(hi/2) x ceil(wi/2) grid; for odd sizes the kernels drop the outputs of the
                 # odd phases that fall outside dx (torch accepts any tile size, so does this path)
@@ -492,6 +491,14 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             # the sole contribution (Act.add_grad drops it otherwise)
             fuse = x.bn_ctx if (x.grad is None and in_act == L.ACT_NONE) else None
             g_split = gs is not None and be.conv_takes_split(g, ctx.prec.prec, L.ACT_NONE, L.PAD_ZERO)
+            # x already carries a gradient (a residual block's skip connection delivered it first, networks.py:509-513): the ResnetBlock-shape kernel adds it in
+            # its store epilogue -- in place, every thread reads its 16 bytes before it writes them -- instead of a separate pass over both tensors (axpby)
+            if x.grad is not None and x.grad_values_stored and in_act == L.ACT_NONE and not g_split and getattr(be, 'conv_forward_add', None) is not None \
+                    and tuple(x.grad.shape) == (n, hi, wi, x.t.shape[3]) and be.conv_forward_add(layer.packed_dgrad, g, x.grad, x.grad, dq[0], dq[1], ctx.prec.prec):
+                x.grad_stats = None          # (as Act.add_grad: what described the first contribution alone no longer describes the sum)
+                x.grad_split = None
+                return
+            dx = torch.empty((n, hi, wi, x.t.shape[3]), dtype=g.dtype, device=g.device)
             nch = be.conv_forward(layer.packed_dgrad, gs if g_split else g, dx, dq[0], dq[1], None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, bn=fuse,
                                   **({'in_split': True} if g_split else {}))
             if in_act != L.ACT_NONE:                # relu / lrelu keep the sign: mask from the un-activated input

@@ -44,6 +44,7 @@ _SHARED_SCRATCH = os.environ.get('DL_SHARED_SCRATCH', '0') == '1'
 # default: same-box A/B of the training step (r02) 104.9-105.0 ms with it vs 103.8-104.0 without -- the y tile read sits exposed in the
 # epilogue of a 1-workgroup-per-CU kernel (+37 us per fused ResnetBlock launch) and costs what the saved pass (49 us) was worth.
 _BNSTATS = os.environ.get('DL_BNSTATS', '0') == '1'
+_CONV_ADD = os.environ.get('DL_CONV_ADD', '1') != '0'      # A/B switch (Python side only): 0 = a second gradient contribution is always added by dl_axpby
 _NO_WGRAD_C4 = os.environ.get('DL_NO_WGRAD_C4', '0') == '1'
 _NO_X3_GLDS = os.environ.get('DL_NO_X3_GLDS') is not None           # A/B switch: the strict policy on the round-1 register-staged kernels (csrc reads the same variable)
 _X3_ACTS = (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU)
@@ -311,6 +312,23 @@ class HipBackend:
         L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
                                          _ptr(part), _stream()), 'dl_conv_forward')
         return nch
+
+    def conv_forward_add(self, packed: PackedWeights, x: torch.Tensor, addend: torch.Tensor, out: torch.Tensor, hq: int, wq: int, prec: int) -> bool:
+        """out = conv(x) + addend in the conv's store epilogue (dl_conv_forward_add; `out` may be `addend`).  Returns False -- nothing launched -- when the kernel
+        the dispatch picks for this layer has no fused form: the caller then runs conv_forward + axpby as before."""
+        if not _CONV_ADD or x.dtype != torch.bfloat16 or addend.dtype != torch.bfloat16 or addend.shape != out.shape:
+            return False
+        _need_cuda(x, addend, out)
+        plan = packed.plan
+        n, hi, wi, cp = x.shape
+        _, ho, wo, cop = out.shape
+        d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, pstride(out), hq, wq, dl_dtype(x), prec, L.ACT_NONE, L.ACT_NONE, 0, 1)
+        if not self.lib.dl_conv_add_supported(C.byref(d)):
+            return False
+        self._last_conv_desc = d
+        L.check(self.lib.dl_conv_forward_add(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(addend), pstride(addend), _ptr(out), _stream()),
+                'dl_conv_forward_add')
+        return True
 
     # ---- weight gradient
     def conv_wgrad(self, P: torch.Tensor, Q: torch.Tensor, grad: torch.Tensor, k: int, step: int, pad: int, pad_mode: int,

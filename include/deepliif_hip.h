@@ -132,6 +132,13 @@ typedef struct dl_conv_bnstats {
 int dl_conv_bnstats_chunks(const dl_conv_desc *d);
 int dl_conv_forward_bnstats(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, void *out,
                             float *stats_part, const dl_conv_bnstats *bn, void *stream);
+/* out = conv(in) + addend in one pass (bf16; the sum is formed in fp32 before the store's rounding).  Replaces the separate accumulation of a second gradient
+ * contribution where the data gradient of a residual block's first conv meets the gradient that came down the skip connection (networks.py:509-513,
+ * ResnetBlock.forward: out = x + conv_block(x); autograd adds the two contributions of x).  dl_conv_add_supported: 1 when the kernel dl_conv_forward picks for
+ * `d` has the fused form (today the ResnetBlock shape on conv_gemm_w4_kernel), else 0 -- the caller then adds with dl_axpby.  `addend` may alias `out`. */
+int dl_conv_add_supported(const dl_conv_desc *d);
+int dl_conv_forward_add(const dl_conv_desc *d, const void *in, const void *w_hi, const void *w_lo, const void *addend, int32_t addend_pstride,
+                        void *out, void *stream);
 /* Name of the kernel dl_conv_forward would launch for `d` (static string, matches the rocprofv3 kernel name up to template
  * arguments).  Diagnostic only: bench.py labels its roofline line with it. */
 const char *dl_conv_kernel_name(const dl_conv_desc *d);
