@@ -25,6 +25,9 @@ bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
 int launch_conv_s2f(const ConvArgs &a0, hipStream_t stream);
 // conv_s2f_x3.hip: the same tile under the strict policy (split-copy input, three products)
+bool s2u_eligible(const ConvArgs &a);
+int s2u_stats_chunks(const ConvArgs &a);
+int launch_conv_s2u(const ConvArgs &a0, hipStream_t stream);
 bool s2d_eligible(const ConvArgs &a);
 int s2d_stats_chunks(const ConvArgs &a);
 int launch_conv_s2d(const ConvArgs &a0, hipStream_t stream);
@@ -1694,6 +1697,19 @@ static bool s2d_applies(const dl_conv_desc *d) {
     return s2d_eligible(a);
 }
 
+// ... or to its mirror image for the UP direction (conv_s2u.hip: up2 forward, down1 data gradient)?  DL_CONV_S2D=0 switches both off (A/B)
+static bool s2u_applies(const dl_conv_desc *d) {
+    const char *env = dl_switch(DL_SW_CONV_S2D);
+    static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;
+    static const bool epi_old = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
+    if ((env && env[0] == '0') || no_glds || epi_old || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE || d->n_phase != 4 || d->Ci != 128)
+        return false;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_conv_geometry(a, d);
+    return s2u_eligible(a);
+}
+
 // ... and to its strict twin (conv_s2f_x3.hip)?  Needs the split copy of the input; DL_CONV_S2F=0 or DL_CONV_S2FX3=0: keep the 4-phase strict kernel (A/B)
 static bool s2fx3_applies(const dl_conv_desc *d) {
     const char *env = dl_switch(DL_SW_CONV_S2F);
@@ -1726,6 +1742,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (!d) return "(null)";
     if (c4_bf16_eligible(d)) return "conv_c4_patch_kernel";
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
+    if (s2u_applies(d)) return "conv_s2u_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
     if (s2d_applies(d)) return "conv_s2d_kernel";
     if (s2fx3_applies(d)) return "conv_s2f_x3_kernel";
@@ -1769,6 +1786,12 @@ extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
         fill_conv_geometry(a, d);
         return s2f_stats_chunks(a);
     }
+    if (s2u_applies(d)) {                                            // one chunk per workgroup (row segment x strip of input rows)
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        fill_conv_geometry(a, d);
+        return s2u_stats_chunks(a);
+    }
     if (s2d_applies(d)) {                                            // one chunk per workgroup (row segment x strip of output rows)
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -1787,7 +1810,7 @@ extern "C" int dl_conv_bnstats_chunks(const dl_conv_desc *d) {
     // channels per tile, no split-K, tiles that do not straddle images
     static const bool off = DL_DEV_ENV("DL_OLD_EPILOGUE") != nullptr;
     static const char *p32 = DL_DEV_ENV("DL_CONV_P32");
-    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d) || s2fx3_applies(d) || s2d_applies(d)) return 0;
+    if (!d || off || (p32 && p32[0] == '1') || d->Co <= 16 || d->act != DL_ACT_NONE || c4_eligible(d) || s2f_applies(d) || s2fx3_applies(d) || s2d_applies(d) || s2u_applies(d)) return 0;
     static const int min_bm = DL_DEV_ENV("DL_BNSTATS_MIN_BM") ? atoi(DL_DEV_ENV("DL_BNSTATS_MIN_BM")) : 0;       // A/B: 256 = only the 256 x 256-tile kernels
     if (glds_tile_bm(d) < min_bm) return 0;
     return dl_conv_stats_chunks(d);
@@ -1882,6 +1905,7 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
     if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
+    else if (!bn && s2u_applies(d)) rc = launch_conv_s2u(a, stream);
     else if (!bn && s2f_applies(d)) rc = launch_conv_s2f(a, stream);
     else if (!bn && s2fx3_applies(d)) rc = launch_conv_s2f_x3(a, stream);
     else if (!bn && s2d_applies(d)) rc = launch_conv_s2d(a, stream);

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     // 9-12 us whatever its fetch; a probe that repeated the SAME launch found 138.8 us first and 122.6 us six measurements later -- the clock drifts for seconds
     // under the power cap, profiles/r05/bias_probe_clock_drift.txt -- so effects below ~10 us are read from the in-step rocprof averages only.)
     __attribute__((address_space(3))) float *bias_lds = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + 256 * 512 + 256 * 4 + 8 * 256 * 4);
-    const bool want_stats = a.stats_part != nullptr;
+    const bool want_stats = a.stats_part != nullptr && a.bn_y == nullptr;
     {
         const int m = m0 + tid;
         int opix = -1;
@@ -401,13 +401,15 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
                 }
             }
     };
-    const bool want_add = a.add != nullptr;
+    const bool want_bn = a.bn_y != nullptr;                 // (never together with an addend: the host asks for the reductions only for a sole contribution)
+    const bool want_add = a.add != nullptr && !want_bn;
     u32x4_t pre[16];
-    if (want_add && tn * 256 + (tid & 31) * 8 < a.Co) {
-        const bf16_t *addp = a.add + (size_t)(m0 + (tid >> 5)) * a.add_pstride + tn * 256 + (tid & 31) * 8;
+    if ((want_add || want_bn) && tn * 256 + (tid & 31) * 8 < a.Co) {
+        const int pps = want_add ? a.add_pstride : a.bn_y_pstride;
+        const bf16_t *addp = (want_add ? a.add : a.bn_y) + (size_t)(m0 + (tid >> 5)) * pps + tn * 256 + (tid & 31) * 8;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (m0 + (tid >> 5) + 8 * k < a.Mtot) pre[k] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * k) * a.add_pstride);
+            pre[k] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * k) * pps);
     }
     if (a.act == DL_ACT_RELU) acc_pass(W4IC<1>{}); else acc_pass(W4IC<0>{});
     __syncthreads();
@@ -424,23 +426,37 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
     // (ADD: the thread's 32 addend chunks are PREFETCHED -- rows 0..15 before the accumulator pass, row k + 16 as soon as row k's register is free: fetched
     // inside the loop, four at a time behind their stores, the pass paid one HBM round trip per four rows and cost as much as the axpby it replaced)
     auto store_pass = [&](auto ADDc, auto STATSc, u32x4_t (&pre)[16]) __attribute__((always_inline)) {
-        constexpr bool ADD = decltype(ADDc)::value != 0, STATS = decltype(STATSc)::value != 0;
+        constexpr bool ADD = decltype(ADDc)::value != 0, STATS = decltype(STATSc)::value == 1, BNR = decltype(STATSc)::value == 2;
+        static_assert(!(ADD && BNR), "one prefetch array");
         if (co_t >= a.Co) return;
-        const bf16_t *addp = ADD ? a.add + (size_t)(m0 + (tid >> 5)) * a.add_pstride + co_t : nullptr;       // w4 shapes: output pixel index = m
+        const bf16_t *addp = ADD ? a.add + (size_t)(m0 + (tid >> 5)) * a.add_pstride + co_t : (BNR ? a.bn_y + (size_t)(m0 + (tid >> 5)) * a.bn_y_pstride + co_t : nullptr);
+        const int pre_ps = ADD ? a.add_pstride : a.bn_y_pstride;                                             // w4 shapes: output pixel index = m
+        // BNR (dl_conv_forward_bnstats): this conv's output is dz of the layer z = act(norm(y)) in front; S1 = sum dn, S2 = sum dn * xhat of the values stored
+        float mr[8], rs[8], sc[8], sh[8];
+        const float bn_slope = a.bn_act == DL_ACT_RELU ? 0.f : (a.bn_act == DL_ACT_LRELU ? 0.2f : 1.f);
+        if constexpr (BNR) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = n_img * a.Co + co_t + i;
+                rs[i] = a.bn_rstd[ci]; mr[i] = -a.bn_mean[ci] * rs[i]; sc[i] = a.bn_scale[ci]; sh[i] = a.bn_shift[ci];       // xhat = y * rstd - mean * rstd
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             const int row = (tid >> 5) + 8 * k;
-            const bool live = m0 + row < a.Mtot;
             const int unit = (cc * 2) ^ (((row & 15) << 1) & 62);
             u32x4_t v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4_t *>(tile + row * 512 + unit * 8);
+            u32x4_t r = u32x4_t{0u, 0u, 0u, 0u};
+            if constexpr (ADD || BNR) {
+                r = pre[k & 15];
+                if (k + 16 < 32) pre[k & 15] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * (k + 16)) * pre_ps);
+            }
             if constexpr (ADD) {
-                const u32x4_t r = pre[k & 15];
-                if (k + 16 < 32 && m0 + row + 128 < a.Mtot) pre[k & 15] = *reinterpret_cast<const u32x4_t *>(addp + (size_t)(8 * (k + 16)) * a.add_pstride);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     v[e] = pack2_bf16(__uint_as_float(v[e] << 16) + __uint_as_float(r[e] << 16), __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(r[e] & 0xffff0000u));
             }
-            if (live) {
+            {       // (w4 shapes: whole image rows of 128 pixels, an even number of them -- every tile row is a pixel of the tensor)
                 *reinterpret_cast<u32x4_t *>(out + (size_t)(m0 + row) * a.out_pstride + co_t) = v;
                 if constexpr (STATS) {
 #pragma unroll
@@ -449,12 +465,25 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
                         s1[2 * e] += lo; s2[2 * e] += lo * lo; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
                     }
                 }
+                if constexpr (BNR) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned dw = v[i >> 1], yw = r[i >> 1];
+                        float dn = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
+                        const float yy = __uint_as_float((i & 1) ? (yw & 0xffff0000u) : (yw << 16));
+                        const float nv = yy * sc[i] + sh[i];
+                        dn = nv > 0.f ? dn : dn * bn_slope;          // act'(nv): 1 above zero; below: 0 (ReLU), 0.2 (LeakyReLU), 1 (no activation) -- no branch per element
+                        s1[i] += dn;
+                        s2[i] += dn * (yy * rs[i] + mr[i]);
+                    }
+                }
             }
         }
     };
-    if (want_stats) { if (want_add) store_pass(W4IC<1>{}, W4IC<1>{}, pre); else store_pass(W4IC<0>{}, W4IC<1>{}, pre); }
+    if (want_bn) store_pass(W4IC<0>{}, W4IC<2>{}, pre);
+    else if (want_stats) { if (want_add) store_pass(W4IC<1>{}, W4IC<1>{}, pre); else store_pass(W4IC<0>{}, W4IC<1>{}, pre); }
     else { if (want_add) store_pass(W4IC<1>{}, W4IC<0>{}, pre); else store_pass(W4IC<0>{}, W4IC<0>{}, pre); }
-    if (want_stats) {
+    if (want_stats || want_bn) {
         // the 8 threads of a channel group are lanes c, c + 32 of the four waves: one shuffle, then the waves meet in LDS (fixed order: deterministic)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -483,7 +512,7 @@ bool w4_eligible(const ConvArgs &a) {
     if (a.n_phase != 1 || a.splitk != 1 || a.raw_out || a.in_step != 1 || a.out_step != 1 || a.Wq != 128 || a.Wi != 128 || (a.Hq & 1)) return false;
     if (a.Ho != a.Hq || a.Wo != a.Wq || a.Hi != a.Hq) return false;
     if (a.phase_tap_begin[1] - a.phase_tap_begin[0] != 9 || a.phase_tap_begin[0] != 0) return false;
-    if (a.Ci < 64 || (a.Ci & 63) || (a.Co & 255) || a.pad_mode != DL_PAD_ZERO || a.bn_y != nullptr || a.in_act != DL_ACT_NONE) return false;
+    if (a.Ci < 64 || (a.Ci & 63) || (a.Co & 255) || a.pad_mode != DL_PAD_ZERO || a.in_act != DL_ACT_NONE) return false;
     if (a.act != DL_ACT_NONE && a.act != DL_ACT_RELU) return false;
     if ((size_t)a.Hi * a.Wi * (size_t)a.in_pstride * 2 >= ((size_t)1 << 31) || (size_t)256 * a.w_kstride * 2 >= ((size_t)1 << 31)) return false;   // 32-bit lane offsets
     int seen = 0;

@@ -139,3 +139,91 @@ def test_s2d_fused_norm_statistics(shape, scope):
     assert rel(st1[0], st2[0]) < 1e-5 and rel(st1[1], st2[1]) < 1e-5
     assert rel(z1, z2) <= 2.0 ** -7
     assert float((z1 != z2).float().mean()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# conv_s2u_kernel (csrc/conv_s2u.hip): the mirror image -- ResnetGenerator up2 forward (ConvTranspose2d(128, 64, k3, s2, p1, op1)) and the data gradient of
+# down1 (Conv2d(64, 128, k3, s2, p1)): four sub-pixel phases, weights in registers, input rows streamed once
+# ------------------------------------------------------------------------------------------------------------------------------------------
+S2U_CASES = [
+    # kind, cin, cout, N, H, W of the layer INPUT, direction
+    ('convT', 128, 64, 2, 16, 64, 'fwd'),          # one 64-pixel segment, 16 input rows
+    ('convT', 128, 64, 1, 6, 128, 'fwd'),          # two segments (pixel 64 of segment 0 is real data, of segment 1 the padding), strips of 1-2 rows
+    ('convT', 128, 128, 3, 8, 64, 'fwd'),          # two channel tiles
+    ('convT', 128, 64, 8, 256, 256, 'fwd'),        # up2 at the benched size
+    ('conv', 64, 128, 2, 32, 128, 'dgrad'),        # down1 data gradient: dy 16 x 64 -> dx 32 x 128
+    ('conv', 64, 128, 8, 512, 512, 'dgrad'),       # ... at the benched size
+]
+
+
+@pytest.mark.parametrize('case', S2U_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}n{c[3]}h{c[4]}w{c[5]}{c[6]}')
+def test_s2u_kernel_against_the_emulation(case):
+    kind, cin, cout, N, H, W_, direction = case
+    prec = Precision.get('bf16')
+    spec = ConvSpec(kind, cin, cout, 3, 2, 1, L.PAD_ZERO, 1 if kind == 'convT' else 0)
+    wshape = (cout, cin, 3, 3) if kind == 'conv' else (cin, cout, 3, 3)
+    w = rnd(wshape, 1, prec, 0.05)
+    fake, real = fake_backend.FakeBackend(), hip()
+    if direction == 'fwd':
+        bias = rnd((cout,), 2, Precision.get('fp32'), 0.1)
+        x = rnd((N, H, W_, cin), 3, prec).to(prec.dtype)
+        ho, wo = spec.out_hw(H, W_)
+        probe = torch.empty((N, ho, wo, cpad(cout)), dtype=prec.dtype, device=DEV)
+        assert _kernel_name(real, spec.forward_plan(), x, probe, H, W_, prec) == 'conv_s2u_kernel'
+        for act, b in ((L.ACT_NONE, bias), (L.ACT_RELU, bias), (L.ACT_NONE, None)):
+            exp = _run_conv(fake, 'fwd', spec, prec, x, w, b, act, L.ACT_NONE, H, W_)
+            first = None
+            for rep in range(2):
+                got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), act, L.ACT_NONE, H, W_)
+                sync()
+                assert rel(got, exp) < tol(prec), ('fwd', act, rep)
+                if first is None:
+                    first = got.clone()
+                else:
+                    assert torch.equal(got, first), 'run-to-run difference'
+    else:
+        ho, wo = spec.out_hw(H, W_)
+        dy = rnd((N, ho, wo, cout), 4, prec).to(prec.dtype)
+        probe = torch.empty((N, H, W_, cpad(cin)), dtype=prec.dtype, device=DEV)
+        assert _kernel_name(real, spec.dgrad_plan(), dy, probe, ho, wo, prec) == 'conv_s2u_kernel'
+        exp = _run_conv(fake, 'dgrad', spec, prec, dy, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+        first = None
+        for rep in range(2):
+            got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+            sync()
+            assert rel(got, exp) < tol(prec), ('dgrad', rep)
+            if first is None:
+                first = got.clone()
+            else:
+                assert torch.equal(got, first), 'run-to-run difference (dgrad)'
+
+
+@pytest.mark.parametrize('scope', [L.NORM_INSTANCE, L.NORM_BATCH])
+@pytest.mark.parametrize('shape', [(2, 16, 64), (8, 256, 256), (1, 6, 128)])
+def test_s2u_fused_norm_statistics(shape, scope):
+    N, H, W_ = shape
+    prec = Precision.get('bf16')
+    cin, cout = 128, 64
+    spec = ConvSpec('convT', cin, cout, 3, 2, 1, L.PAD_ZERO, 1)
+    w = rnd((cin, cout, 3, 3), 1, prec, 0.05).to(DEV)
+    bias = rnd((cout,), 2, Precision.get('fp32'), 0.1).to(DEV)
+    x = rnd((N, H, W_, cin), 3, prec).to(prec.dtype).to(DEV)
+    be = hip()
+    packed = ops.PackedWeights(spec.forward_plan(), DEV, False)
+    be.pack_weights(packed, w)
+    ho, wo = spec.out_hw(H, W_)
+    y = torch.empty((N, ho, wo, cout), dtype=prec.dtype, device=DEV)
+    nch = be.conv_forward(packed, x, y, H, W_, bias, L.ACT_NONE, L.ACT_NONE, prec.prec, splitk=1, want_stats=True)
+    assert DRY or (be.last_conv_kernel.startswith('conv_s2u') and nch > 0)
+    affine = scope == L.NORM_BATCH
+    g = (1 + 0.1 * torch.randn(cout, generator=torch.Generator().manual_seed(4))).to(DEV) if affine else None
+    b = (0.1 * torch.randn(cout, generator=torch.Generator().manual_seed(5))).to(DEV) if affine else None
+    z1 = torch.empty_like(y)
+    st1 = be.norm_forward(y, z1, cout, scope, L.ACT_RELU, g, b, None, None, -1.0, None, ext_nchunks=nch)
+    st1 = [t.clone() for t in st1[:2]]
+    z2 = torch.empty_like(y)
+    st2 = be.norm_forward(y, z2, cout, scope, L.ACT_RELU, g, b, None, None, -1.0, None)
+    sync()
+    assert rel(st1[0], st2[0]) < 1e-5 and rel(st1[1], st2[1]) < 1e-5
+    assert rel(z1, z2) <= 2.0 ** -7
+    assert float((z1 != z2).float().mean()) < 1e-3

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 O=gpurun_out/s2d_${1:-a}.txt
 rm -f $O
 echo "== parity" >> $O
-timeout 900 python -m pytest tests/test_gpu_s2d.py -m gpu -q -x 2>&1 | tail -15 >> $O
+timeout 900 python -m pytest tests/test_gpu_s2d.py -m gpu -q -x ${KSEL:+-k "$KSEL"} 2>&1 | tail -15 >> $O
 for rep in 1 2; do
   for v in 0 1; do
     echo "== layers DL_CONV_S2D=$v (round $rep)" >> $O
