@@ -1780,17 +1780,17 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
     if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
-    if (s2f_applies(d) || s2fx3_applies(d)) {                        // one chunk per 256-pixel tile of the phase grid (all four phases summed)
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        fill_conv_geometry(a, d);
-        return s2f_stats_chunks(a);
-    }
     if (s2u_applies(d)) {                                            // one chunk per workgroup (row segment x strip of input rows)
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         fill_conv_geometry(a, d);
         return s2u_stats_chunks(a);
+    }
+    if (s2f_applies(d) || s2fx3_applies(d)) {                        // one chunk per 256-pixel tile of the phase grid (all four phases summed)
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        fill_conv_geometry(a, d);
+        return s2f_stats_chunks(a);
     }
     if (s2d_applies(d)) {                                            // one chunk per workgroup (row segment x strip of output rows)
         ConvArgs a;

@@ -148,6 +148,8 @@ def test_a_larger_batch_drops_the_graph_and_captures_again():
     freed addresses.  StepGraph watches ops.Workspace.realloc_generation, drops the graph and captures again on the next fitting batches -- every step
     stays bit-identical to the eager model."""
     from deepliif_amd import ops
+    torch.cuda.synchronize()
+    ops.WS._thread_state().clear()        # the scratch buffers are grow-only per thread: start from nothing, or an earlier (larger) test has already outgrown this one
     small, big = _batches('train', 1, 64, 8, 5), _batches('train', 3, 96, 1, 5)
     order = small[:4] + big + small[4:]
     eager, graphed = _build('train', 'bf16'), _build('train', 'bf16')
