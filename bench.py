@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 STRICT_PMC_FILE = os.path.join('r03', 'pmc_strict_conv256.json')     # the same passes over the strict ResnetBlock kernel (tools/gpu_r03_pmc_strict.sh)
 N8_FULL_FILE = os.path.join('r06', 'cpu_baseline_n8_full.json')     # bench.py --cpu-baseline-n8-full: the oracle at batch 8, 512 x 512 (SURVEY 8d on-spec)
 TRAJECTORY_FILE = os.path.join('r06', 'trajectory_r06.json')  # tests/test_gpu_trajectory.py: 100-step loss curves of both policies vs the oracle
-PMC_FILE = os.path.join('r05', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
+PMC_FILE = os.path.join('r06', 'pmc_dominant_conv256.json')     # dominant-kernel HBM traffic from separate --pmc passes (re-collected when the kernel changes)
 
 
 def make_opt(args, device_index, M=5, seg_gen=False):
@@ -68,10 +68,16 @@ class KernelTimer:
 
     def __init__(self, backend, shape):
         self.backend, self.shape, self.pairs, self.enabled = backend, tuple(shape), [], False
+        self.pairs_add = []           # launches that also add the skip-connection gradient in their store pass (dl_conv_forward_add): +67 MB of algorithmic reads
         self.kernel = '?'
         self.seen = 0
         self._orig = backend.conv_forward
         backend.conv_forward = self._wrapped
+        # the block's first conv's data gradient goes through conv_forward_add since r06 (the skip gradient is added in its store pass): the same kernel,
+        # the same shape, 45 of the 180 launches per step -- they belong in the average (they are the slower ones)
+        self._orig_add = getattr(backend, 'conv_forward_add', None)
+        if self._orig_add is not None:
+            backend.conv_forward_add = self._wrapped_add
 
     def _wrapped(self, packed, x, out, *args, **kwargs):
         hit = self.enabled and tuple(x.shape) == self.shape and tuple(out.shape) == self.shape and packed.plan.n_phase == 1
@@ -88,10 +94,30 @@ class KernelTimer:
             self.kernel = getattr(self.backend, 'last_conv_kernel', '') or self.kernel      # what the library dispatched
         return ret
 
+    def _wrapped_add(self, packed, x, addend, out, *args, **kwargs):
+        hit = self.enabled and tuple(x.shape) == self.shape and tuple(out.shape) == self.shape and packed.plan.n_phase == 1
+        if hit:
+            self.seen += 1
+            hit = self.seen % self.EVERY == 0
+        if hit:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+        ret = self._orig_add(packed, x, addend, out, *args, **kwargs)
+        if hit and ret:
+            e.record()
+            self.pairs_add.append((s, e))
+            self.kernel = getattr(self.backend, 'last_conv_kernel', '') or self.kernel
+        return ret
+
     def mean_seconds(self):
         if not self.pairs:
             return None
         return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs) * 1e-3
+
+    def mean_seconds_add(self):
+        if not self.pairs_add:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.pairs_add) / len(self.pairs_add) * 1e-3
 
     def median_seconds(self):
         if not self.pairs:
@@ -538,7 +564,7 @@ def main():
         conc = (tm.mean_seconds(), tm.median_seconds(), len(tm.pairs))
         saved, m._streams = m._streams, None
         try:
-            tm.pairs = []
+            tm.pairs, tm.pairs_add = [], []
             sdt_ = timed(stepfn, 1, args.steps, tm)
         finally:
             m._streams = saved
@@ -576,6 +602,7 @@ def main():
             infer_solo = saved_streams
     kt = timer.mean_seconds()
     kt_median = timer.median_seconds() if hasattr(timer, 'median_seconds') else kt
+    kt_add, n_pairs_add = (timer.mean_seconds_add(), len(timer.pairs_add)) if hasattr(timer, 'pairs_add') else (None, 0)
 
     n_pairs, dom_kernel = len(timer.pairs), timer.kernel
     flops_per_launch = 2.0 * n * (s // 4) * (s // 4) * (4 * args.ngf) * (4 * args.ngf) * 9
@@ -585,7 +612,7 @@ def main():
     if want_strict:
         ssteps, swarm = args.steps, args.warmup            # same schedule as the headline (r03 timed 8 steps / 1 warm-up: VERDICT r3 #9)
         if hasattr(timer, '_orig'):
-            timer.pairs, timer.kernel = [], '?'
+            timer.pairs, timer.pairs_add, timer.kernel = [], [], '?'
         sdt = timed(sstep, swarm, ssteps, timer if hasattr(timer, '_orig') else None)
         strict.update({'value': round(ssteps * n * world / sdt, 3), 'unit': 'tiles/s', 'ms_per_step': round(sdt / ssteps * 1e3, 3), 'steps': ssteps, 'warmup': swarm,
                        'model_tflops': round(ssteps * n * world / sdt * gf_per_tile / 1e3, 1)})
@@ -670,7 +697,7 @@ def main():
             same = (n, s, args.precision, args.ngf) == (8, 512, 'bf16', 64) and dom_kernel != '?' and dom_kernel.split('<')[0] in pmc.get('kernel', '')
             traffic = pmc['traffic_bytes'] if same else None
             traffic_note = (f'NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over the same kernel and shape '
-                            f'(profiles/{PMC_FILE}, collected with tools/gpu_r05_pmc.sh on forward launches only)') if same else None
+                            f'(profiles/{PMC_FILE}, collected with tools/gpu_r06_pmc.sh on forward launches only)') if same else None
     except Exception:
         traffic = None
     if kt:
@@ -679,6 +706,15 @@ def main():
                     'traffic': traffic, 'traffic_note': traffic_note,
                     'kernel': f'{dom_kernel}: 3x3 256->256 @ {n}x{s // 4}x{s // 4}, ResnetBlock conv ' + ('fwd + dgrad' if args.workload not in ('infer', 'wsi') else 'fwd only') + '; timed by events around the host call',
                     'launches_timed': n_pairs, 'avg_launch_us': round(kt * 1e6, 2), 'median_launch_us': round(kt_median * 1e6, 2)}
+        if kt_add:
+            # a quarter of the block's conv launches (the first conv's data gradient) also add the skip-connection gradient in their store pass (dl_conv_forward_add,
+            # r06): the same 154.6 GF but 67 MB more algorithmic bytes -- a different launch, kept out of `avg_launch_us` (whose definition did not change) and shown here
+            ach_add = flops_per_launch / kt_add / 1e12
+            roofline['with_skip_add'] = {'launches_timed': n_pairs_add, 'avg_launch_us': round(kt_add * 1e6, 2), 'achieved': round(ach_add, 1), 'frac': round(ach_add / PEAK_BF16_TFLOPS, 4),
+                                         'algorithmic_bytes': 3 * n * (s // 4) * (s // 4) * 4 * args.ngf * 2 + (4 * args.ngf) ** 2 * 9 * 2,
+                                         'all_block_conv_launches_avg_us': round((kt * n_pairs + kt_add * n_pairs_add) / max(n_pairs + n_pairs_add, 1) * 1e6, 2),
+                                         'what': 'the data gradient of a ResnetBlock\'s first conv + the gradient that came down the skip connection, one pass (replaces a separate '
+                                                 'axpby over 3 x 67 MB per block)'}
         if not dry and rank == 0 and args.workload == 'train':
             try:
                 sus = mfma_sustained(dev)

@@ -140,11 +140,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// ---- runtime switches (include/deepliif_hip.h, "Runtime switches").  The shipped library looks at EIGHT documented environment variables, all of them
+// ---- runtime switches (include/deepliif_hip.h, "Runtime switches").  The shipped library looks at NINE documented environment variables, all of them
 // choices between two correct code paths, read ONCE when the library is loaded (error.cpp; dl_switches_reload() re-reads them for tests): no getenv on a
 // launch path, nothing that changes while threads are launching.  Everything else -- kernel variants kept for A/B measurements and the timing-only
 // ablations whose results are WRONG by construction -- exists only in a build with -DDL_DEV_SWITCHES (make dev -> libdeepliif_hip_dev.so, used by tools/).
-enum { DL_SW_CONV_S2F = 0, DL_SW_CONV_S2FX3, DL_SW_CONV_W4X3, DL_SW_PACK_TILED, DL_SW_NO_X3_GLDS, DL_SW_NO_WGRAD_C4, DL_SW_NO_C4_X3, DL_SW_CONV_S2D, DL_SW_COUNT };
+enum { DL_SW_CONV_S2F = 0, DL_SW_CONV_S2FX3, DL_SW_CONV_W4X3, DL_SW_PACK_TILED, DL_SW_NO_X3_GLDS, DL_SW_NO_WGRAD_C4, DL_SW_NO_C4_X3, DL_SW_CONV_S2D, DL_SW_CONV_DOT, DL_SW_COUNT };
 const char *dl_switch(int id);                 // the variable's value at load time, nullptr when unset
 static inline bool dl_switch_is_one(int id) { const char *v = dl_switch(id); return v && v[0] == '1' && v[1] == 0; }      // same parse as os.environ.get(name) == '1'
 #ifdef DL_DEV_SWITCHES

@@ -25,6 +25,9 @@ bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
 int launch_conv_s2f(const ConvArgs &a0, hipStream_t stream);
 // conv_s2f_x3.hip: the same tile under the strict policy (split-copy input, three products)
+bool dot_fwd_eligible(const ConvArgs &a);
+bool dot_dgrad_eligible(const ConvArgs &a);
+int launch_conv_dot(const ConvArgs &a, bool fwd, hipStream_t stream);
 bool s2u_eligible(const ConvArgs &a);
 int s2u_stats_chunks(const ConvArgs &a);
 int launch_conv_s2u(const ConvArgs &a0, hipStream_t stream);
@@ -1683,6 +1686,21 @@ static bool s2f_applies(const dl_conv_desc *d) {
     return s2f_eligible(a);
 }
 
+// does dl_conv_forward send this descriptor to the one-channel dot-product kernels (conv_dot.hip: the PatchGAN's prediction layer)?  0 = no, 1 = forward,
+// 2 = data gradient.  DL_CONV_DOT=0: keep the gather GEMM (A/B)
+static int dot_applies(const dl_conv_desc *d) {
+    const char *env = dl_switch(DL_SW_CONV_DOT);
+    if ((env && env[0] == '0') || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE || d->n_phase != 1 || d->raw_out) return 0;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_conv_geometry(a, d);
+    a.bias = d->bias_n == 1 ? reinterpret_cast<const float *>(&a) : nullptr;        // (only its presence is tested)
+    if (dot_fwd_eligible(a)) return 1;
+    a.bias = nullptr;
+    if (d->ci_real == 1 && d->bias_n == 0 && dot_dgrad_eligible(a)) return 2;
+    return 0;
+}
+
 // does dl_conv_forward send this descriptor to the register-stationary stride-2 kernel (conv_s2d.hip: down1 forward, up2 data gradient)?
 // DL_CONV_S2D=0: keep the gather GEMM (A/B)
 static bool s2d_applies(const dl_conv_desc *d) {
@@ -1742,6 +1760,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (!d) return "(null)";
     if (c4_bf16_eligible(d)) return "conv_c4_patch_kernel";
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
+    if (const int k = dot_applies(d)) return k == 1 ? "conv_dot_fwd_kernel" : "conv_dot_dgrad_kernel";
     if (s2u_applies(d)) return "conv_s2u_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
     if (s2d_applies(d)) return "conv_s2d_kernel";
@@ -1779,6 +1798,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
+    if (dot_applies(d)) return 0;
     if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
     if (s2u_applies(d)) {                                            // one chunk per workgroup (row segment x strip of input rows)
         ConvArgs a;
@@ -1903,6 +1923,11 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
 
     int rc;
     static const bool no_glds = DL_DEV_ENV("DL_NO_GLDS") != nullptr;      // A/B switch for profiling the two staging paths
+    if (!bn && !stats_part && !add) {
+        if (const int k = dot_applies(d)) {
+            if (k == 1 ? dot_fwd_eligible(a) : dot_dgrad_eligible(a)) return launch_conv_dot(a, k == 1, stream);     // (no split-K, whatever the descriptor says: nothing to reduce)
+        }
+    }
     if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
     else if (!bn && s2u_applies(d)) rc = launch_conv_s2u(a, stream);

@@ -261,7 +261,9 @@ __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
         __builtin_amdgcn_sched_barrier(0);       // the row's MFMAs stay in front of the epilogue that reads their accumulators
         epilogue(cur, ho);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // vmcnt(8): everything but this row's 8 stores per thread -- i.e. every DMA piece of the two rows staged during the row (issued before the stores; gfx9
+        // VMEM operations complete in issue order) -- has landed; the stores drain behind the next row's MFMAs instead of in front of the barrier
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (int t = 0; t < R; t += 2) {         // R is even (s2d_strip_rows)
         out_row(t, 0, accA, accB);

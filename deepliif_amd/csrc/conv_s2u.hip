@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
         __builtin_amdgcn_sched_barrier(0);                   // the step's MFMAs stay in front of the epilogue that reads their accumulators
         epilogue(h);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // vmcnt(8): everything but this step's 8 stores per thread -- i.e. every DMA piece of the row staged during the step (issued before the stores; gfx9
+        // VMEM operations complete in issue order) -- has landed; the stores drain behind the next step's MFMAs instead of in front of the barrier
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int t3 = sA; sA = sB; sB = sC; sC = t3;
     }
 

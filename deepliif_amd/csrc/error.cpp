@@ -18,9 +18,9 @@ extern "C" const char *dl_last_error(void) { return g_err; }
 extern "C" int dl_version(void) { return DL_VERSION; }
 
 // ---- runtime switches: the variables below are copied out of the environment when the library is loaded; launches only read the copies
-enum { DL_SW_COUNT_ = 8, DL_SW_LEN = 16 };
+enum { DL_SW_COUNT_ = 9, DL_SW_LEN = 16 };
 static const char *const g_sw_names[DL_SW_COUNT_] = {"DL_CONV_S2F", "DL_CONV_S2FX3", "DL_CONV_W4X3", "DL_PACK_TILED", "DL_NO_X3_GLDS", "DL_NO_WGRAD_C4",
-                                                     "DL_NO_C4_X3", "DL_CONV_S2D"};
+                                                     "DL_NO_C4_X3", "DL_CONV_S2D", "DL_CONV_DOT"};
 static char g_sw_val[DL_SW_COUNT_][DL_SW_LEN];
 static bool g_sw_set[DL_SW_COUNT_];
 

@@ -48,19 +48,21 @@ int dl_version(void);
 const char *dl_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Runtime switches.  The shipped library looks at EIGHT environment variables, each a choice between two CORRECT code paths (kept for same-box A/B
+ * Runtime switches.  The shipped library looks at NINE environment variables, each a choice between two CORRECT code paths (kept for same-box A/B
  * measurements and for tests that must reach a kernel at small sizes).  They are copied out of the environment ONCE, when the library is loaded; no entry
  * point calls getenv.  Anything that can change RESULTS (timing-only ablations) or selects superseded kernel variants exists only in the dev build
  * (`make -C deepliif_amd/csrc dev` -> libdeepliif_hip_dev.so, compiled with -DDL_DEV_SWITCHES; dl_dev_build() == 1), which tools/ load explicitly.
  *   DL_CONV_S2F=0      stride-2 transposed convs / stride-2 data gradients on the 4-phase gather GEMM instead of conv_s2f_kernel; =2 lifts its size rule
  *   DL_CONV_S2FX3=0    the same for the strict policy's conv_s2f_x3_kernel
- *   DL_CONV_S2D=0      ResnetGenerator down1 forward / up2 data gradient on the gather GEMM instead of conv_s2d_kernel
+ *   DL_CONV_S2D=0      ResnetGenerator down1 forward / up2 data gradient on the gather GEMM instead of conv_s2d_kernel, up2 forward / down1 data
+ *                      gradient on conv_s2f_kernel instead of conv_s2u_kernel
+ *   DL_CONV_DOT=0      the PatchGAN's one-channel prediction layer (forward / data gradient) on the gather GEMM instead of conv_dot_*_kernel
  *   DL_CONV_W4X3=1     strict ResnetBlock conv on conv_gemm_w4x3_kernel (opt-in; a measured tie with the default 8-phase strict kernel)
  *   DL_PACK_TILED=0    dl_pack_weights_batch with every image in the chunk-per-thread form
  *   DL_NO_X3_GLDS      (set) strict policy on the register-staged round-1 kernels           -- deepliif_amd/ops.py reads the same variable
  *   DL_NO_WGRAD_C4=1   7x7 stem / head weight gradient on the general kernels               -- deepliif_amd/ops.py reads the same variable
  *   DL_NO_C4_X3        (set) strict 7x7 stem / head on the general strict kernels           -- deepliif_amd/ops.py reads the same variable
- * dl_switches_reload() re-reads the eight variables (tests that flip one inside a process); NOT thread-safe against concurrent launches.
+ * dl_switches_reload() re-reads the nine variables (tests that flip one inside a process); NOT thread-safe against concurrent launches.
  * ---------------------------------------------------------------------------------------------------------- */
 int dl_switch_count(void);
 const char *dl_switch_name(int id);          /* 0 <= id < dl_switch_count() */

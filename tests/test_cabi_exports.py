@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_shipped_library_has_no_result_changing_switches():
     """the default build carries no timing-only ablation (results wrong by construction) and no getenv on a launch path -- the only
-    environment variables it knows are the eight documented A/B switches of include/deepliif_hip.h, copied once at load time."""
+    environment variables it knows are the nine documented A/B switches of include/deepliif_hip.h, copied once at load time."""
     lib = L.load()
     if os.environ.get('DEEPLIIF_AMD_LIB'):
         pytest.skip('a non-default library was selected')
     assert lib.dl_dev_build() == 0
     names = [lib.dl_switch_name(i).decode() for i in range(lib.dl_switch_count())]
-    assert len(names) == 8 and len(set(names)) == 8
+    assert len(names) == 9 and len(set(names)) == 9
     header = open(HEADER).read()
     for n in names:
         assert n in header, f'{n} is not documented in include/deepliif_hip.h'

@@ -1,0 +1,50 @@
+"""conv_dot_fwd_kernel / conv_dot_dgrad_kernel (csrc/conv_dot.hip): the PatchGAN's one-channel prediction layer Conv2d(512, 1, k4, s1, p1)
+(NLayerDiscriminator, networks.py:655-660), forward and data gradient through dl_conv_forward against the CPU emulation; the dispatch must take
+the new kernels (dl_conv_kernel_name) whatever split-K the host asked for."""
+import ctypes as C
+
+import pytest
+import torch
+
+import fake_backend
+from deepliif_amd import _lib as L
+from deepliif_amd.engine import Precision
+from deepliif_amd.geometry import ConvSpec, cpad, fill_conv_desc
+
+from test_gpu_kernels import DEV, DRY, _run_conv, hip, rel, rnd, sync, tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _name(plan, n, hi, wi, cin_p, ho, wo, cop, bias_n):
+    d = fill_conv_desc(plan, n, hi, wi, cin_p, ho, wo, cop, cop, ho, wo, L.DL_BF16, L.PREC_BF16, L.ACT_NONE, L.ACT_NONE, bias_n, 1)
+    return L.load().dl_conv_kernel_name(C.byref(d)).decode()
+
+
+@pytest.mark.parametrize('shape', [(8, 31, 31), (2, 8, 8), (3, 17, 9), (1, 4, 4)], ids=lambda s: 'n%d-%dx%d' % s)
+@pytest.mark.parametrize('splitk', [None, 1, 3])
+def test_patchgan_prediction_layer_forward_and_data_gradient(shape, splitk):
+    N, H, W_ = shape
+    prec = Precision.get('bf16')
+    spec = ConvSpec('conv', 512, 1, 4, 1, 1, L.PAD_ZERO, 0)
+    w = rnd((1, 512, 4, 4), 1, prec, 0.05)
+    bias = rnd((1,), 2, Precision.get('fp32'), 0.1)
+    x = rnd((N, H, W_, 512), 3, prec).to(prec.dtype)
+    ho, wo = spec.out_hw(H, W_)
+    assert _name(spec.forward_plan(), N, H, W_, 512, ho, wo, 8, 1) == 'conv_dot_fwd_kernel'
+    assert _name(spec.dgrad_plan(), N, ho, wo, 8, H, W_, 512, 0) == 'conv_dot_dgrad_kernel'
+    fake, real = fake_backend.FakeBackend(), hip()
+    for act in (L.ACT_NONE, L.ACT_LRELU):
+        exp = _run_conv(fake, 'fwd', spec, prec, x, w, bias, act, L.ACT_NONE, H, W_)
+        got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), bias.to(DEV), act, L.ACT_NONE, H, W_, splitk=splitk)
+        sync()
+        assert DRY or real.last_conv_kernel == 'conv_dot_fwd_kernel'
+        assert rel(got, exp) < tol(prec), ('fwd', act)
+        assert float(got[..., 1:].float().abs().max()) == 0.0, 'the padding channels of the one-channel prediction stay zero'
+    dy = torch.zeros(N, ho, wo, cpad(1))
+    dy[..., :1] = rnd((N, ho, wo, 1), 4, prec)
+    exp = _run_conv(fake, 'dgrad', spec, prec, dy.to(prec.dtype), w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+    got = _run_conv(real, 'dgrad', spec, prec, dy.to(prec.dtype).to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_, splitk=splitk)
+    sync()
+    assert DRY or real.last_conv_kernel == 'conv_dot_dgrad_kernel'
+    assert rel(got, exp) < tol(prec), 'dgrad'
