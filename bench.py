@@ -549,7 +549,8 @@ def main():
                                        'GradExchanger.finish(), mean over the timed steps',
                                'd_ms_exposed': round(exposed.get('D', 0.0), 3) if exposed else None, 'g_ms_exposed': round(exposed.get('G', 0.0), 3) if exposed else None,
                                'bytes': {k: v['bytes'] for k, v in last.items()}, 'buckets': {k: v['calls'] for k, v in last.items()},
-                               'early_ranges': {k: v['early_ranges'] for k, v in last.items()}}
+                               'early_ranges': {k: v['early_ranges'] for k, v in last.items()},
+                               'wire_dtype': 'bf16 (DL_DP_GRAD_BF16=1: round, sum, widen)' if D.GRAD_BF16 else 'fp32'}
 
     tiles_total = args.steps * n * world
     value = tiles_total / dt

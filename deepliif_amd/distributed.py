@@ -31,6 +31,11 @@ SPLIT_ELEMS = 16 * 1024 * 1024       # network slices above 64 MB (the 67 M-para
                                      # registered with an optimizer: reverse mode reaches it last -- is progressive too, in two halves, whatever its
                                      # size: as one message it would start only when the pass is over and be exposed in full (VERDICT r3 #8a)
 OVERLAP = os.environ.get('DL_DP_OVERLAP', '1') != '0'        # A/B switch: 0 = one blocking exchange after the whole backward (round 1)
+GRAD_BF16 = os.environ.get('DL_DP_GRAD_BF16', '0') == '1'    # opt-in: the gradients go on the wire as bf16 -- every rank rounds its fp32 slice to bf16 (nearest even), the
+                                                             # collective sums the bf16 values, the sum is widened back into the fp32 gradient buffer: half the bytes
+                                                             # per step (5 G + 5 D: 368 -> 184 MB) for one extra rounding of the SUMMED gradient (2^-9 relative, the
+                                                             # size of the bf16 policy's own activation rounding).  Deterministic; off by default: the fp32 exchange
+                                                             # is the one held bit-identical to the single-process run (tests/test_distributed_gloo.py)
 FORCE = os.environ.get('DL_DP_FORCE', '0') == '1'            # run the exchange path with ONE rank too (all-reduce over a 1-rank group = identity):
                                                              # exercises RCCL's stream ordering against the ctypes launches on a single GPU
 
@@ -88,6 +93,7 @@ class GradExchanger:
         self.pass_log: List[dict] = []                       # per finish(): bytes and all-reduce calls of the pass
         self._param_range: Dict[int, Tuple[int, int]] = {}   # id(param) -> its own (start, end) in the flat buffer
         self._progress: Dict[Tuple[int, int], dict] = {}     # per big slice and pass: final-but-unsent intervals, send watermark
+        self._wire: List = []                                # DL_DP_GRAD_BF16: (bf16 wire copy, fp32 destination) of every message of the pass
 
     def register_net(self, optimizer, params):
         """tell the exchanger which contiguous run of `optimizer`'s flat parameters is one network (models call this once per network)"""
@@ -128,6 +134,7 @@ class GradExchanger:
         self.handles, self.done, self.launch_log = [], [], []
         self._progress = {}
         self._calls, self._elems = 0, 0
+        self._wire = []
 
     def param_final(self, p):
         """Tape.on_final: the gradient of `p` is complete for this pass.  Inside a network above SPLIT_ELEMS the flat order of the parameters
@@ -171,7 +178,12 @@ class GradExchanger:
             if flush is not None:
                 flush()                        # pending split-K slabs (ops.HipBackend: deferred reduction) become gradients before anything goes on the wire
         for b in range(s, e, MSG_ELEMS):
-            self.handles.append(dist.all_reduce(g[b:min(b + MSG_ELEMS, e)], op=dist.ReduceOp.SUM, async_op=True))
+            piece = g[b:min(b + MSG_ELEMS, e)]
+            if GRAD_BF16:
+                wire = piece.to(torch.bfloat16)              # round-to-nearest-even copy on the compute stream; kept alive until finish() has widened it back
+                self._wire.append((wire, piece))
+                piece = wire
+            self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
             self._calls = getattr(self, '_calls', 0) + 1
         self._elems = getattr(self, '_elems', 0) + (e - s)
         self.done.append((s, e))
@@ -200,10 +212,13 @@ class GradExchanger:
             ev[0].record()
         for h in self.handles:
             h.wait()
+        for wire, piece in getattr(self, '_wire', []):       # DL_DP_GRAD_BF16: the summed bf16 values back into the fp32 gradient buffer (behind the waits, stream-ordered)
+            piece.copy_(wire)
+        self._wire = []
         if ev is not None:
             ev[1].record()
             self.exposed.append((getattr(optimizer, 'dp_tag', 'opt'), ev[0], ev[1]))
-        self.pass_log.append({'tag': getattr(optimizer, 'dp_tag', 'opt'), 'bytes': 4 * getattr(self, '_elems', 0), 'calls': getattr(self, '_calls', 0),
+        self.pass_log.append({'tag': getattr(optimizer, 'dp_tag', 'opt'), 'bytes': (2 if GRAD_BF16 else 4) * getattr(self, '_elems', 0), 'calls': getattr(self, '_calls', 0),
                               'early_ranges': len(self.launch_log)})
         if len(self.pass_log) > 64:
             del self.pass_log[:-64]

@@ -168,3 +168,37 @@ def test_tile_parallel_inference_bands_concatenate_to_the_single_process_result(
     assert band == (0, img.shape[0]) and set(single) == set(got)
     for k, v in single.items():
         assert torch.equal(v, got[k]), k        # per-sample normalisation: a tile's output does not depend on its batch mates
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# DL_DP_GRAD_BF16: the gradients on the wire as bf16 -- bit-exact to "every rank rounds, then the rounded values are summed"
+# ---------------------------------------------------------------------------------------------------------------------------
+def _bf16_worker(rank, world, port, out):
+    for p in (os.path.dirname(HERE), HERE):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DL_DP_GRAD_BF16='1')
+    import types
+    from deepliif_amd import distributed as D
+    assert D.GRAD_BF16
+    D.init_process_group_from_env('gloo')
+    n = 100_003
+    g = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)) * (10.0 ** torch.randint(-6, 3, (n,), generator=torch.Generator().manual_seed(7)).float())
+    flat = types.SimpleNamespace(grad=g.clone(), numel=n, data=torch.zeros(n))
+    opt = types.SimpleNamespace(flat=flat, dp_tag='G')
+    ex = D.GradExchanger()
+    ex.begin(opt)
+    ex._launch(flat.grad, 5000, 60_000)          # one range announced early (as a network marker would), the rest by finish()
+    ex.finish(opt)
+    assert opt.dp_scale == 1.0 / world and ex.pass_log[-1]['bytes'] == 2 * n
+    torch.save({'sum': flat.grad.clone(), 'mine': g}, os.path.join(out, f'g{rank}.pt'))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_gradient_exchange_is_round_then_sum(tmp_path):
+    port = _free_port()
+    mp.spawn(_bf16_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    assert torch.equal(r0['sum'], r1['sum']), 'ranks hold different sums'
+    expect = (r0['mine'].to(torch.bfloat16) + r1['mine'].to(torch.bfloat16)).float()        # round each rank's gradient, sum the rounded values (one bf16 rounding of the sum)
+    assert torch.equal(r0['sum'], expect)

@@ -71,3 +71,33 @@ def test_one_rank_rccl_exchange_is_bit_identical_to_no_exchange(monkeypatch, pre
         assert model.optimizer_G.dp_scale == 1.0 and model.optimizer_D.dp_scale == 1.0
     finally:
         dist.destroy_process_group()
+
+
+def test_one_rank_rccl_exchange_with_bf16_gradients_on_the_wire(monkeypatch):
+    """DL_DP_GRAD_BF16 on RCCL with one rank: the collective is the identity, so the step equals the plain step with every gradient rounded to bf16 right
+    before Adam -- checked against exactly that (the flat gradient buffers of a plain model rounded by hand), stream ordering of the rounding copy, the
+    all-reduce on RCCL's stream and the widening copy included."""
+    import torch.distributed as dist
+    from deepliif_amd import distributed as D
+    from deepliif_amd import optim
+    # reference: plain model, gradients rounded to bf16 in front of every optimizer step
+    orig_step = optim.FusedAdam.step
+
+    def rounding_step(self, *a, **k):
+        self.flat.grad.copy_(self.flat.grad.to(torch.bfloat16))
+        return orig_step(self, *a, **k)
+    monkeypatch.setattr(optim.FusedAdam, 'step', rounding_step)
+    ref_flat, ref_losses, _, _ = _run(3, 'bf16')
+    monkeypatch.setattr(optim.FusedAdam, 'step', orig_step)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(D, 'FORCE', True)
+        monkeypatch.setattr(D, 'GRAD_BF16', True)
+        flat, losses, logs, model = _run(3, 'bf16')
+        assert torch.equal(flat, ref_flat), 'bf16 wire format: the step differs from "round every gradient, then step"'
+        assert losses == ref_losses
+        assert model.exchange.pass_log[-1]['bytes'] == 2 * model.optimizer_G.flat.numel
+    finally:
+        dist.destroy_process_group()

@@ -48,3 +48,31 @@ def test_patchgan_prediction_layer_forward_and_data_gradient(shape, splitk):
     sync()
     assert DRY or real.last_conv_kernel == 'conv_dot_dgrad_kernel'
     assert rel(got, exp) < tol(prec), 'dgrad'
+
+
+@pytest.mark.parametrize('shape', [(8, 512, 512), (2, 8, 512), (3, 20, 512), (1, 4, 512)], ids=lambda s: 'n%d-%dx%d' % s)
+def test_patchgan_first_layer_forward(shape):
+    """conv_d1_kernel (csrc/conv_d1.hip): Conv2d(6, 64, k4, s2, p1) + LeakyReLU(0.2) (networks.py:638-641) on 512-pixel-wide inputs"""
+    N, H, W_ = shape
+    prec = Precision.get('bf16')
+    spec = ConvSpec('conv', 6, 64, 4, 2, 1, L.PAD_ZERO, 0)
+    w = rnd((64, 6, 4, 4), 1, prec, 0.05)
+    bias = rnd((64,), 2, Precision.get('fp32'), 0.1)
+    x = torch.zeros(N, H, W_, cpad(6))
+    x[..., :6] = rnd((N, H, W_, 6), 3, prec)
+    x = x.to(prec.dtype)
+    ho, wo = spec.out_hw(H, W_)
+    assert _name(spec.forward_plan(), N, H, W_, 8, ho, wo, 64, 64) == 'conv_d1_kernel'
+    fake, real = fake_backend.FakeBackend(), hip()
+    for act, b in ((L.ACT_LRELU, bias), (L.ACT_NONE, bias), (L.ACT_LRELU, None)):
+        exp = _run_conv(fake, 'fwd', spec, prec, x, w, b, act, L.ACT_NONE, H, W_)
+        first = None
+        for rep in range(2):
+            got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), act, L.ACT_NONE, H, W_, splitk=1)
+            sync()
+            assert DRY or real.last_conv_kernel == 'conv_d1_kernel'
+            assert rel(got, exp) < tol(prec), ('fwd', act, rep)
+            if first is None:
+                first = got.clone()
+            else:
+                assert torch.equal(got, first), 'run-to-run difference'
