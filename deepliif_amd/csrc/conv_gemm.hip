@@ -25,6 +25,8 @@ bool s2f_eligible(const ConvArgs &a);
 int s2f_stats_chunks(const ConvArgs &a);
 int launch_conv_s2f(const ConvArgs &a0, hipStream_t stream);
 // conv_s2f_x3.hip: the same tile under the strict policy (split-copy input, three products)
+bool d1g_eligible(const ConvArgs &a);
+int launch_conv_d1g(const ConvArgs &a0, hipStream_t stream);
 bool d1_eligible(const ConvArgs &a);
 int launch_conv_d1(const ConvArgs &a0, hipStream_t stream);
 bool dot_fwd_eligible(const ConvArgs &a);
@@ -1716,6 +1718,18 @@ static bool d1_applies(const dl_conv_desc *d) {
     return d1_eligible(a);
 }
 
+// ... or to that layer's data-gradient kernel (conv_d1g.hip: four phases as the M dimension, 64 contracted and 8 output channels)?  DL_CONV_DOT=0: off (A/B)
+static bool d1g_applies(const dl_conv_desc *d) {
+    const char *env = dl_switch(DL_SW_CONV_DOT);
+    if ((env && env[0] == '0') || d->in_dtype != DL_BF16 || d->prec != DL_PREC_BF16 || d->in_act != DL_ACT_NONE || d->n_phase != 4 || d->Ci != 64 || d->Co != 8 || d->splitk != 1 ||
+        d->bias_n != 0)
+        return false;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_conv_geometry(a, d);
+    return d1g_eligible(a);
+}
+
 // does dl_conv_forward send this descriptor to the register-stationary stride-2 kernel (conv_s2d.hip: down1 forward, up2 data gradient)?
 // DL_CONV_S2D=0: keep the gather GEMM (A/B)
 static bool s2d_applies(const dl_conv_desc *d) {
@@ -1777,6 +1791,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
     if (c4_x3_eligible(d)) return "conv_c4_patch_x3_kernel";
     if (const int k = dot_applies(d)) return k == 1 ? "conv_dot_fwd_kernel" : "conv_dot_dgrad_kernel";
     if (d1_applies(d)) return "conv_d1_kernel";
+    if (d1g_applies(d)) return "conv_d1g_kernel";
     if (s2u_applies(d)) return "conv_s2u_kernel";
     if (s2f_applies(d)) return "conv_s2f_kernel";
     if (s2d_applies(d)) return "conv_s2d_kernel";
@@ -1814,7 +1829,7 @@ extern "C" const char *dl_conv_kernel_name(const dl_conv_desc *d) {
 
 extern "C" int dl_conv_stats_chunks(const dl_conv_desc *d) {
     if (!d || d->splitk != 1 || d->raw_out || d->act != DL_ACT_NONE) return 0;
-    if (dot_applies(d) || d1_applies(d)) return 0;
+    if (dot_applies(d) || d1_applies(d) || d1g_applies(d)) return 0;
     if (c4_eligible(d)) return (d->Ho / 4) * (d->Wo / 64);          // one chunk per 4 x 64 tile
     if (s2u_applies(d)) {                                            // one chunk per workgroup (row segment x strip of input rows)
         ConvArgs a;
@@ -1946,6 +1961,7 @@ static int conv_forward_impl(const dl_conv_desc *d, const void *in, const void *
     }
     if (c4_bf16_eligible(d)) rc = launch_conv_c4(a, d, stream);
     else if (!bn && !stats_part && !add && d1_applies(d)) rc = launch_conv_d1(a, stream);
+    else if (!bn && !stats_part && !add && !bias && d1g_applies(d)) rc = launch_conv_d1g(a, stream);
     else if (c4_x3_eligible(d)) rc = launch_conv_c4_x3(a, d, stream);
     else if (!bn && s2u_applies(d)) rc = launch_conv_s2u(a, stream);
     else if (!bn && s2f_applies(d)) rc = launch_conv_s2f(a, stream);

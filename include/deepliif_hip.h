@@ -56,8 +56,8 @@ const char *dl_last_error(void);
  *   DL_CONV_S2FX3=0    the same for the strict policy's conv_s2f_x3_kernel
  *   DL_CONV_S2D=0      ResnetGenerator down1 forward / up2 data gradient on the gather GEMM instead of conv_s2d_kernel, up2 forward / down1 data
  *                      gradient on conv_s2f_kernel instead of conv_s2u_kernel
- *   DL_CONV_DOT=0      the PatchGAN's one-channel prediction layer (forward / data gradient) and its first layer (forward) on the gather GEMM instead of
- *                      conv_dot_*_kernel / conv_d1_kernel
+ *   DL_CONV_DOT=0      the PatchGAN's one-channel prediction layer (forward / data gradient) and its first layer (forward / data gradient) on the gather GEMM
+ *                      instead of conv_dot_*_kernel / conv_d1_kernel / conv_d1g_kernel
  *   DL_CONV_W4X3=1     strict ResnetBlock conv on conv_gemm_w4x3_kernel (opt-in; a measured tie with the default 8-phase strict kernel)
  *   DL_PACK_TILED=0    dl_pack_weights_batch with every image in the chunk-per-thread form
  *   DL_NO_X3_GLDS      (set) strict policy on the register-staged round-1 kernels           -- deepliif_amd/ops.py reads the same variable

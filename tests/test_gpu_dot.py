@@ -76,3 +76,29 @@ def test_patchgan_first_layer_forward(shape):
                 first = got.clone()
             else:
                 assert torch.equal(got, first), 'run-to-run difference'
+
+
+@pytest.mark.parametrize('shape', [(8, 512, 512), (2, 8, 256), (1, 6, 512), (3, 20, 256)], ids=lambda s: 'n%d-%dx%d' % s)
+def test_patchgan_first_layer_data_gradient(shape):
+    """conv_d1g_kernel (csrc/conv_d1g.hip): the data gradient of Conv2d(6, 64, k4, s2, p1) -- the four sub-pixel phases as the M dimension of one MFMA tile"""
+    N, H, W_ = shape
+    prec = Precision.get('bf16')
+    spec = ConvSpec('conv', 6, 64, 4, 2, 1, L.PAD_ZERO, 0)
+    w = rnd((64, 6, 4, 4), 1, prec, 0.05)
+    ho, wo = spec.out_hw(H, W_)
+    dy = rnd((N, ho, wo, 64), 4, prec).to(prec.dtype)
+    d = fill_conv_desc(spec.dgrad_plan(), N, ho, wo, 64, H, W_, 8, 8, ho, wo, L.DL_BF16, L.PREC_BF16, L.ACT_NONE, L.ACT_NONE, 0, 1)
+    assert L.load().dl_conv_kernel_name(C.byref(d)).decode() == 'conv_d1g_kernel'
+    fake, real = fake_backend.FakeBackend(), hip()
+    exp = _run_conv(fake, 'dgrad', spec, prec, dy, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
+    first = None
+    for rep in range(3):
+        got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_, splitk=1)
+        sync()
+        assert DRY or real.last_conv_kernel == 'conv_d1g_kernel'
+        assert rel(got, exp) < tol(prec), ('dgrad', rep)
+        assert float(got[..., 6:].float().abs().max()) == 0.0, 'the padding channels of the gradient stay zero'
+        if first is None:
+            first = got.clone()
+        else:
+            assert torch.equal(got, first), 'run-to-run difference'
