@@ -1548,16 +1548,6 @@ static bool w4_enabled() {
     return !(w4 && w4[0] == '0');
 }
 
-// EXPERIMENT (dev build, DL_CONV_T256X128=1): 256 x 128 tiles (8 waves of 64 px x 64 ch, 85 flop per staged byte instead of 64) where they fill the chip
-static bool t256x128_applies(int mtot, int Co, int n_phase, int splitk) {
-#ifdef DL_DEV_SWITCHES
-    static const char *e = DL_DEV_ENV("DL_CONV_T256X128");
-    return e && e[0] == '1' && Co >= 128 && (Co % 128) == 0 && (size_t)((mtot + 255) / 256) * (Co / 128) * n_phase * splitk >= 224;
-#else
-    return false;
-#endif
-}
-
 static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
     if (a.Co <= 16) return launch_conv_glds<256, 16, 32, 4, 1>(a, stream);
     if (a.Co <= 64) return launch_conv_glds<128, 64, 64, 2, 2>(a, stream);
@@ -1602,9 +1592,8 @@ static int dispatch_tile_glds(const ConvArgs &a, hipStream_t stream) {
 #endif
         return launch_conv_glds<256, 256, 64, 2, 4>(a, stream);
     }
-#ifdef DL_DEV_SWITCHES
-    if (t256x128_applies(a.Mtot, a.Co, a.n_phase, a.splitk)) return launch_conv_glds<256, 128, 64, 4, 2>(a, stream);
-#endif
+    // (r06 experiment, dev build: a 256 x 128 tile -- 8 waves of 64 px x 64 ch, 85 flop per staged byte instead of 64 -- on the PatchGAN's c2 / c3 layers:
+    // 84.3 -> 82.6 us, 64.8 -> 63.9 us: the 128 x 128 tile is not bound by the bytes it stages; removed)
     return launch_conv_glds<128, 128, 64, 2, 2>(a, stream);
 }
 
@@ -1779,7 +1768,6 @@ static int glds_tile_bm(const dl_conv_desc *d) {
     static const bool no_big = DL_DEV_ENV("DL_NO_BIGTILE") != nullptr;
     const int mtot = d->N * d->Hq * d->Wq;
     if (!no_big && big_tile_fills_gpu(mtot, d->Co, d->n_phase, d->splitk)) return 256;
-    if (t256x128_applies(mtot, d->Co, d->n_phase, d->splitk)) return 256;
     return 128;
 }
 
