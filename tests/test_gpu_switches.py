@@ -29,16 +29,21 @@ def test_the_dispatch_names_the_fused_tile_for_the_generator_layers():
     from deepliif_amd.geometry import ConvSpec
     be = ops.impl()
     prec = Precision.get('bf16')
-    spec = ConvSpec('convT', 128, 64, 3, 2, 1, L.PAD_ZERO, 1)
-    w = torch.randn(128, 64, 3, 3, device='cuda') * 0.02
-    pf = ops.PackedWeights(spec.forward_plan(), 'cuda', False)
-    be.pack_weights(pf, w)
-    x = torch.randn(1, 256, 256, 128, device='cuda').to(prec.dtype)
-    out = torch.empty(1, 512, 512, 64, device='cuda', dtype=prec.dtype)
-    be.conv_forward(pf, x, out, 256, 256, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
-    torch.cuda.synchronize()
-    expect = 'conv_gemm_glds_kernel<128,64,64>' if os.environ.get('DL_CONV_S2F') == '0' else 'conv_s2f_kernel'
-    assert be.last_conv_kernel == expect
+    # up1 (256 -> 128 at 128 x 128, batch 8): the fused four-phase tile; up2 (128 -> 64): since r06 the register-resident-weights kernel (csrc/conv_s2u.hip)
+    for cin, cout, n, hw, fused, plain in ((256, 128, 8, 128, 'conv_s2f_kernel', 'conv_gemm_glds_kernel<128,128,64>'), (128, 64, 1, 256, 'conv_s2u_kernel', None)):
+        spec = ConvSpec('convT', cin, cout, 3, 2, 1, L.PAD_ZERO, 1)
+        w = torch.randn(cin, cout, 3, 3, device='cuda') * 0.02
+        pf = ops.PackedWeights(spec.forward_plan(), 'cuda', False)
+        be.pack_weights(pf, w)
+        x = torch.randn(n, hw, hw, cin, device='cuda').to(prec.dtype)
+        out = torch.empty(n, 2 * hw, 2 * hw, cout, device='cuda', dtype=prec.dtype)
+        be.conv_forward(pf, x, out, hw, hw, None, L.ACT_NONE, L.ACT_NONE, prec.prec)
+        torch.cuda.synchronize()
+        if fused == 'conv_s2u_kernel':
+            expect = fused if os.environ.get('DL_CONV_S2D') != '0' else ('conv_s2f_kernel' if os.environ.get('DL_CONV_S2F') != '0' else 'conv_gemm_glds_kernel<128,64,64>')
+        else:
+            expect = plain if os.environ.get('DL_CONV_S2F') == '0' else fused
+        assert be.last_conv_kernel == expect, (cin, cout, be.last_conv_kernel, expect)
 
 
 def test_strict_w4_kernel_under_its_switch():
