@@ -67,6 +67,17 @@ template <> struct Vec8<float> {
         *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
+    // non-temporal variants (streaming passes: the line is not wanted in L2 again)
+    static __device__ __forceinline__ void load_nt(const float *p, float (&v)[8]) {
+        const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+        const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    static __device__ __forceinline__ void store_nt(float *p, const float (&v)[8]) {
+        __builtin_nontemporal_store(f32x4_t{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4_t *>(p));
+        __builtin_nontemporal_store(f32x4_t{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4_t *>(p + 4));
+    }
 };
 template <> struct Vec8<bf16_t> {
     static __device__ __forceinline__ void load(const bf16_t *p, float (&v)[8]) {
@@ -82,6 +93,20 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<u32x4_t *>(p) = a;
+    }
+    static __device__ __forceinline__ void load_nt(const bf16_t *p, float (&v)[8]) {
+        const u32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(a[i] << 16);
+            v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store_nt(bf16_t *p, const float (&v)[8]) {
+        u32x4_t a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
+        __builtin_nontemporal_store(a, reinterpret_cast<u32x4_t *>(p));
     }
 };
 // SPLIT COPY of 8 fp32 values (strict policy, see conv_x3.h / wgrad_x3.h): the same 32 bytes an fp32 group of 8 channels occupies, holding

@@ -51,7 +51,7 @@ __device__ __forceinline__ float s2d_row16_sum(float v) {
 }
 
 // STATS: fused norm statistics (a compile-time flag: as a runtime branch inside the store loop it cost accumulator-sized PHI copies per row)
-template <bool STATS>
+template <bool STATS, bool RELU>
 __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
     const ConvArgs &a = sa.a;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
     const int opb = a.out_pstride * 2;                                            // bytes per output pixel
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.out) + (size_t)n * a.Ho * a.Wo * opb, 0, 0x7fffffff, 0x00020000);
     const unsigned st_off = (unsigned)((tid >> 4) * opb + (tn * 128 + (tid & 15) * 8) * 2);      // pixel (tid >> 4) + 16 it of a half tile, 16-byte chunk tid & 15
-    const bool relu = a.act == DL_ACT_RELU;
+    constexpr bool relu = RELU;                 // (a compile-time flag: as a run-time one it cost a v_max + v_cndmask per stored value)
     __attribute__((address_space(3))) float *bias_l = reinterpret_cast<__attribute__((address_space(3))) float *>(lds + S2D_BIAS);
     if (tid < 128) {
         const int co = tn * 128 + tid;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[j][q * 4 + e];
-                        if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        if constexpr (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
                     u32x2_t pk;
                     pk[0] = pack2_bf16(v[0], v[1]);
@@ -342,14 +342,22 @@ int launch_conv_s2d(const ConvArgs &a0, hipStream_t stream) {
     if (a.stats_part && a.stats_nchunks != sa.segs * sa.nstrips) DL_FAIL("dl_conv_forward(s2d): statistics chunks %d != %d", a.stats_nchunks, sa.segs * sa.nstrips);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2D_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2D_LDS);
+        hipError_t e = hipSuccess;
+        const void *fns[4] = {reinterpret_cast<const void *>(conv_s2d_kernel<false, false>), reinterpret_cast<const void *>(conv_s2d_kernel<false, true>),
+                              reinterpret_cast<const void *>(conv_s2d_kernel<true, false>), reinterpret_cast<const void *>(conv_s2d_kernel<true, true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2D_LDS);
         if (e != hipSuccess) DL_FAIL("dl_conv_forward(s2d): hipFuncSetAttribute(%zu): %s", S2D_LDS, hipGetErrorString(e));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1);
-    if (a.stats_part) hipLaunchKernelGGL(conv_s2d_kernel<true>, grid, dim3(256), S2D_LDS, stream, sa);
-    else hipLaunchKernelGGL(conv_s2d_kernel<false>, grid, dim3(256), S2D_LDS, stream, sa);
+    const bool relu = a.act == DL_ACT_RELU;
+    if (a.stats_part) {
+        if (relu) hipLaunchKernelGGL((conv_s2d_kernel<true, true>), grid, dim3(256), S2D_LDS, stream, sa);
+        else hipLaunchKernelGGL((conv_s2d_kernel<true, false>), grid, dim3(256), S2D_LDS, stream, sa);
+    } else {
+        if (relu) hipLaunchKernelGGL((conv_s2d_kernel<false, true>), grid, dim3(256), S2D_LDS, stream, sa);
+        else hipLaunchKernelGGL((conv_s2d_kernel<false, false>), grid, dim3(256), S2D_LDS, stream, sa);
+    }
     DL_CHECK_LAUNCH("dl_conv_forward(s2d)");
     return 0;
 }

@@ -35,7 +35,7 @@ constexpr int S2U_BIAS = S2U_TILE + 2 * 128 * 128;    // the channel tile's bias
 constexpr size_t S2U_LDS = (size_t)S2U_BIAS + 256;
 static_assert(S2U_LDS <= 160 * 1024, "LDS of one CU");
 
-template <bool STATS>
+template <bool STATS, bool RELU>
 __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
     const ConvArgs &a = sa.a;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
         bias_l[tid] = (a.bias && co < a.bias_n) ? a.bias[co] : 0.f;
     }
     __syncthreads();
-    const bool relu = a.act == DL_ACT_RELU;
+    constexpr bool relu = RELU;                 // (a compile-time flag: as a run-time one it cost a v_max + v_cndmask per stored value)
     const int opb = a.out_pstride * 2;
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(a.out) + (size_t)n * a.Ho * a.Wo * opb, 0, 0x7fffffff, 0x00020000);
     // store pass: thread t owns 16-byte chunk t & 7 (channels (t & 7) * 8 ..) of tile pixels (t >> 3) + 32 it, it = 0..7: tile pixel q = output row q >> 7, pixel q & 127
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = ac[j][q * 4 + e];
-                    if (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if constexpr (relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
                 u32x2_t pk;
                 pk[0] = pack2_bf16(v[0], v[1]);
@@ -336,14 +336,22 @@ int launch_conv_s2u(const ConvArgs &a0, hipStream_t stream) {
     if (a.stats_part && a.stats_nchunks != sa.segs * sa.nstrips) DL_FAIL("dl_conv_forward(s2u): statistics chunks %d != %d", a.stats_nchunks, sa.segs * sa.nstrips);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2u_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2U_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2u_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2U_LDS);
+        hipError_t e = hipSuccess;
+        const void *fns[4] = {reinterpret_cast<const void *>(conv_s2u_kernel<false, false>), reinterpret_cast<const void *>(conv_s2u_kernel<false, true>),
+                              reinterpret_cast<const void *>(conv_s2u_kernel<true, false>), reinterpret_cast<const void *>(conv_s2u_kernel<true, true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2U_LDS);
         if (e != hipSuccess) DL_FAIL("dl_conv_forward(s2u): hipFuncSetAttribute(%zu): %s", S2U_LDS, hipGetErrorString(e));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1);
-    if (a.stats_part) hipLaunchKernelGGL(conv_s2u_kernel<true>, grid, dim3(256), S2U_LDS, stream, sa);
-    else hipLaunchKernelGGL(conv_s2u_kernel<false>, grid, dim3(256), S2U_LDS, stream, sa);
+    const bool relu = a.act == DL_ACT_RELU;
+    if (a.stats_part) {
+        if (relu) hipLaunchKernelGGL((conv_s2u_kernel<true, true>), grid, dim3(256), S2U_LDS, stream, sa);
+        else hipLaunchKernelGGL((conv_s2u_kernel<true, false>), grid, dim3(256), S2U_LDS, stream, sa);
+    } else {
+        if (relu) hipLaunchKernelGGL((conv_s2u_kernel<false, true>), grid, dim3(256), S2U_LDS, stream, sa);
+        else hipLaunchKernelGGL((conv_s2u_kernel<false, false>), grid, dim3(256), S2U_LDS, stream, sa);
+    }
     DL_CHECK_LAUNCH("dl_conv_forward(s2u)");
     return 0;
 }

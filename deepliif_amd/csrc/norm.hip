@@ -34,6 +34,20 @@ extern "C" size_t dl_norm_ws_floats(const dl_norm_desc *d) {
     return (size_t)g.N * g.nchunks * 2 * g.Cp + (size_t)4 * g.N * g.Cp + (size_t)2048 * g.Cp + 64;    // partials | chunk sums | c1 | c2 | dy channel-sum partials
 }
 
+// Non-temporal accesses (compile-time knob; round-6 A/B of six settings under rocprofv3, tools/gpu_r06_nt.sh, profiles/r06/norm_nt_r06.txt):
+//   bit 0 = non-temporal STORES in the apply passes (z / dy are consumed by a conv that starts after the whole tensor is written),
+//   bit 1 = non-temporal LOADS in the apply passes (the last read of y / dz in that direction),
+//   bit 2 / bit 3 = non-temporal loads of y / dz in the partial-sum passes (faster there, 52 -> 42 us, but the apply pass that re-reads the same
+//   tensors right after loses its cache hits, 65 -> 67 us: a wash).
+// 3 is the measured best: norm family 82.0 -> 78.3 ms per 4 steps on one stream, whole step +1.5 %.
+#ifndef DL_NORM_NT
+#define DL_NORM_NT 3
+#endif
+template <typename T> __device__ __forceinline__ void nld_p(const T *p, float (&v)[8]) { if constexpr ((DL_NORM_NT & 4) != 0) Vec8<T>::load_nt(p, v); else Vec8<T>::load(p, v); }
+template <typename T> __device__ __forceinline__ void nld_pd(const T *p, float (&v)[8]) { if constexpr ((DL_NORM_NT & 8) != 0) Vec8<T>::load_nt(p, v); else Vec8<T>::load(p, v); }
+template <typename T> __device__ __forceinline__ void nld_a(const T *p, float (&v)[8]) { if constexpr ((DL_NORM_NT & 2) != 0) Vec8<T>::load_nt(p, v); else Vec8<T>::load(p, v); }
+template <typename T> __device__ __forceinline__ void nst_a(T *p, const float (&v)[8]) { if constexpr ((DL_NORM_NT & 1) != 0) Vec8<T>::store_nt(p, v); else Vec8<T>::store(p, v); }
+
 // MODE 0: forward statistics  (s1 = sum y, s2 = sum y^2)
 // MODE 1: backward reductions (s1 = sum dn, s2 = sum dn * xhat), dn = dz * act'(y*scale+shift)
 // ACT (the activation fused behind the norm) is a TEMPLATE parameter of the three streaming kernels: as a runtime argument its
@@ -69,13 +83,13 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const T *y, int y_ps,
             for (int p = p0 + row; p < p1; p += rows) {
                 const size_t pix = (size_t)n * g.HW + p;
                 float v[8];
-                Vec8<T>::load(y + pix * y_ps + c0, v);
+                nld_p<T>(y + pix * y_ps + c0, v);
                 if (MODE == 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
                 } else {
                     float d[8];
-                    Vec8<T>::load(dz + pix * dz_ps + c0, d);
+                    nld_pd<T>(dz + pix * dz_ps + c0, d);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float nv = v[i] * sc[i] + sh[i];
@@ -225,10 +239,10 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
         for (; p + (U - 1) * pstep < g.HW; p += U * pstep) {
             float v[U][8], r[U][8];
 #pragma unroll
-            for (int u = 0; u < U; ++u) Vec8<T>::load(y + ((size_t)n * g.HW + p + u * pstep) * y_ps + c0, v[u]);
+            for (int u = 0; u < U; ++u) nld_a<T>(y + ((size_t)n * g.HW + p + u * pstep) * y_ps + c0, v[u]);
             if (res) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) Vec8<T>::load(res + ((size_t)n * g.HW + p + u * pstep) * r_ps + c0, r[u]);
+                for (int u = 0; u < U; ++u) nld_a<T>(res + ((size_t)n * g.HW + p + u * pstep) * r_ps + c0, r[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -238,23 +252,23 @@ __global__ void __launch_bounds__(256) norm_apply_kernel(const T *y, int y_ps, c
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[u][k] += r[u][k];
                 }
-                if (z) Vec8<T>::store(z + ((size_t)n * g.HW + p + u * pstep) * z_ps + c0, v[u]);       // z == NULL: only the split copy is wanted
+                if (z) nst_a<T>(z + ((size_t)n * g.HW + p + u * pstep) * z_ps + c0, v[u]);       // z == NULL: only the split copy is wanted
                 if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, v[u]);
             }
         }
         for (; p < g.HW; p += pstep) {
             const size_t pix = (size_t)n * g.HW + p;
             float v[8];
-            Vec8<T>::load(y + pix * y_ps + c0, v);
+            nld_a<T>(y + pix * y_ps + c0, v);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = apply_act(act, v[k] * sc[k] + sh[k]);
             if (res) {
                 float r[8];
-                Vec8<T>::load(res + pix * r_ps + c0, r);
+                nld_a<T>(res + pix * r_ps + c0, r);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
-            if (z) Vec8<T>::store(z + pix * z_ps + c0, v);
+            if (z) nst_a<T>(z + pix * z_ps + c0, v);
             if (split) store_split8(split + pix * split_ps + c0, v);
         }
     }
@@ -317,8 +331,8 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t pix = (size_t)n * g.HW + p + u * pstep;
-                Vec8<T>::load(y + pix * y_ps + c0, v[u]);
-                Vec8<T>::load(dz + pix * dz_ps + c0, d[u]);
+                nld_a<T>(y + pix * y_ps + c0, v[u]);
+                nld_a<T>(dz + pix * dz_ps + c0, d[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -336,15 +350,15 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                     o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
                     bs[k] += o[k];
                 }
-                if (dy) Vec8<T>::store(dy + ((size_t)n * g.HW + p + u * pstep) * dy_ps + c0, o);       // dy == NULL: only the split copy is wanted
+                if (dy) nst_a<T>(dy + ((size_t)n * g.HW + p + u * pstep) * dy_ps + c0, o);       // dy == NULL: only the split copy is wanted
                 if (split) store_split8(split + ((size_t)n * g.HW + p + u * pstep) * split_ps + c0, o);
             }
         }
         for (; p < g.HW; p += pstep) {
             const size_t pix = (size_t)n * g.HW + p;
             float V[8], D[8], o[8];
-            Vec8<T>::load(y + pix * y_ps + c0, V);
-            Vec8<T>::load(dz + pix * dz_ps + c0, D);
+            nld_a<T>(y + pix * y_ps + c0, V);
+            nld_a<T>(dz + pix * dz_ps + c0, D);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float nv = V[k] * sc[k] + sh[k];
@@ -356,7 +370,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T *dz, int dz
                 o[k] = gr[k] * (dn - k1[k] - xh * k2[k]);
                 bs[k] += o[k];
             }
-            if (dy) Vec8<T>::store(dy + pix * dy_ps + c0, o);
+            if (dy) nst_a<T>(dy + pix * dy_ps + c0, o);
             if (split) store_split8(split + pix * split_ps + c0, o);
         }
         }
