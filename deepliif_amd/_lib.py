@@ -8,6 +8,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DEEPLIIF_AMD_LIB: another build of the same ABI (tools/ load libdeepliif_hip_dev.so, the -DDL_DEV_SWITCHES build with every A/B variant)
 LIB_PATH = os.environ.get('DEEPLIIF_AMD_LIB') or os.path.join(_HERE, 'libdeepliif_hip.so')
+# the same sources built with IEEE half as the 16-bit type (csrc/common.h, csrc/Makefile): the fp16 INFERENCE policy (engine.Precision 'fp16')
+LIB_PATH_F16 = os.environ.get('DEEPLIIF_AMD_LIB_F16') or os.path.join(_HERE, 'libdeepliif_hip_f16.so')
+HALF_BF16, HALF_FP16 = 0, 1
 
 DL_F32, DL_BF16 = 0, 1
 PREC_BF16, PREC_BF16X3 = 1, 3
@@ -17,7 +20,7 @@ NORM_INSTANCE, NORM_BATCH = 0, 1
 LOSS_BCE_LOGITS, LOSS_MSE, LOSS_SMOOTH_L1, LOSS_L1, LOSS_LINEAR = 0, 1, 2, 3, 4
 MAX_TAPS, MAX_PHASES = 64, 4
 WGRAD_MULTI_MAX = 24
-DL_VERSION = 113
+DL_VERSION = 114
 
 i32 = C.c_int32
 
@@ -74,6 +77,7 @@ SIGNATURES = {
     'dl_switch_count': (_i, []),
     'dl_switch_name': (C.c_char_p, [_i]),
     'dl_switches_reload': (None, []),
+    'dl_half_format': (_i, []),
     'dl_dev_build': (_i, []),
     'dl_conv_forward': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'dl_conv_stats_chunks': (_i, [C.POINTER(ConvDesc)]),
@@ -138,34 +142,40 @@ SIGNATURES = {
     'dl_probe_mfma_sustained': (_i, [_vp, _i, _i, _vp, _vp]),
 }
 
-_lib = None
+_libs = {}
 
 
 class HipLibraryError(RuntimeError):
     pass
 
 
-def load():
-    """Load (once) and return the ctypes library; raises HipLibraryError if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(half: str = 'bf16'):
+    """Load (once) and return the ctypes library of one 16-bit format ('bf16': libdeepliif_hip.so, 'fp16': libdeepliif_hip_f16.so);
+    raises HipLibraryError if it has not been built."""
+    lib = _libs.get(half)
+    if lib is not None:
+        return lib
+    if half not in ('bf16', 'fp16'):
+        raise ValueError(f'unknown 16-bit format {half!r} (bf16 | fp16)')
+    path = LIB_PATH if half == 'bf16' else LIB_PATH_F16
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'{path} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'(or `make -C deepliif_amd/csrc`). deepliif_amd has no CPU / PyTorch fallback.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     if lib.dl_version() != DL_VERSION:
-        raise HipLibraryError(f'libdeepliif_hip.so version {lib.dl_version()} != {DL_VERSION} (stale build)')
-    _lib = lib
+        raise HipLibraryError(f'{os.path.basename(path)} version {lib.dl_version()} != {DL_VERSION} (stale build)')
+    if lib.dl_half_format() != (HALF_BF16 if half == 'bf16' else HALF_FP16):
+        raise HipLibraryError(f'{path} was built for the other 16-bit format (dl_half_format() = {lib.dl_half_format()})')
+    _libs[half] = lib
     return lib
 
 
-def check(rc, what):
+def check(rc, what, lib=None):
     if rc != 0:
-        msg = load().dl_last_error().decode('utf-8', 'replace')
+        msg = (lib or load()).dl_last_error().decode('utf-8', 'replace')
         raise HipLibraryError(f'{what} failed (rc={rc}): {msg}')

@@ -18,8 +18,50 @@ void dl_set_error(const char *fmt, ...);
 #define DL_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     dl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return -2; } } while (0)
 
-// ---- bf16 <-> fp32 (round to nearest even; NaN handling not needed on this path)
+// ---- the library's 16-bit format.  The same sources build two libraries (Makefile): libdeepliif_hip.so with bfloat16 (training + inference; the
+// reference's fp32 range, 8 bits of precision) and libdeepliif_hip_f16.so (-DDL_H16_FP16) with IEEE half as the storage AND MFMA operand type: 11 bits of
+// precision at the same matrix rate, INFERENCE ONLY (the gradients of this model sit below half's normal range: 89-100 % of dy under 6.1e-5,
+// profiles/r05/fp16_policy_experiment.json).  Everything that depends on the format goes through the helpers of this block -- the names keep "bf16" because
+// that is the format of the product build; in the f16 build `bf16_t`, DL_BF16 and DL_PREC_BF16 mean "the 16-bit type of this library" (dl_half_format()).
+#ifdef DL_H16_FP16
+#define DL_H16_FORMAT 1
+#else
+#define DL_H16_FORMAT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 dl_bf16x2_native __attribute__((ext_vector_type(2)));
+typedef _Float16 dl_f16x2_native __attribute__((ext_vector_type(2)));
+typedef _Float16 dl_f16x8_native __attribute__((ext_vector_type(8)));
+typedef float dl_f32x2_native __attribute__((ext_vector_type(2)));
+#endif
+// the low / high half of a packed 32-bit word as fp32 (bf16: a shift / a mask; half: v_cvt_f32_f16)
+__device__ __forceinline__ float h16_lo_f32(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef DL_H16_FP16
+    return (float)__builtin_bit_cast(dl_f16x2_native, w)[0];
+#else
+    return __uint_as_float(w << 16);
+#endif
+#else
+    return 0.f;
+#endif
+}
+__device__ __forceinline__ float h16_hi_f32(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef DL_H16_FP16
+    return (float)__builtin_bit_cast(dl_f16x2_native, w)[1];
+#else
+    return __uint_as_float(w & 0xffff0000u);
+#endif
+#else
+    return 0.f;
+#endif
+}
+// ---- 16-bit <-> fp32 (round to nearest even; NaN handling not needed on this path)
 __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+#ifdef DL_H16_FP16
+    return (float)__builtin_bit_cast(_Float16, h);
+#else
     uint32_t u = ((uint32_t)h) << 16;
     float f;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -28,23 +70,27 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
     memcpy(&f, &u, 4);
 #endif
     return f;
+#endif
 }
-// Device code converts with the native gfx950 instruction (v_cvt_pk_bf16_f32: round to nearest even, ONE VALU op per pair); the
+// Device code converts with the native gfx950 instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32: round to nearest even, ONE VALU op per pair); the
 // integer emulation below (5-7 ops per pair, a dependent chain) is what every bf16 store used to pay -- the PMC passes of round 1
 // showed the norm apply kernels waiting on instruction issue for ~46 % of their wave cycles.  Identical results for finite values.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __bf16 dl_bf16x2_native __attribute__((ext_vector_type(2)));
-typedef float dl_f32x2_native __attribute__((ext_vector_type(2)));
-#endif
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const dl_f32x2_native f = {lo, hi};
+#ifdef DL_H16_FP16
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, dl_f16x2_native));
+#else
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, dl_bf16x2_native));
+#endif
 #else
     return 0;
 #endif
 }
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+#ifdef DL_H16_FP16
+    return __builtin_bit_cast(bf16_t, (_Float16)f);
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
     return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu);
 #else
@@ -52,6 +98,30 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     memcpy(&u, &f, 4);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
+#endif
+}
+// ---- the matrix instructions on 16-bit operands (A / B fragments are 8 packed values = 4 VGPRs whatever the format)
+template <typename V, typename A> __device__ __forceinline__ A dl_mfma32(V a, V b, A c) {        // v_mfma_f32_32x32x16_{bf16,f16}
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef DL_H16_FP16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dl_f16x8_native, a), __builtin_bit_cast(dl_f16x8_native, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+#else
+    return c;
+#endif
+}
+template <typename V, typename A> __device__ __forceinline__ A dl_mfma16(V a, V b, A c) {        // v_mfma_f32_16x16x32_{bf16,f16}
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef DL_H16_FP16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dl_f16x8_native, a), __builtin_bit_cast(dl_f16x8_native, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+#else
+    return c;
 #endif
 }
 
@@ -84,8 +154,8 @@ template <> struct Vec8<bf16_t> {
         const u32x4_t a = *reinterpret_cast<const u32x4_t *>(p);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(a[i] << 16);
-            v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+            v[2 * i] = h16_lo_f32(a[i]);
+            v[2 * i + 1] = h16_hi_f32(a[i]);
         }
     }
     static __device__ __forceinline__ void store(bf16_t *p, const float (&v)[8]) {
@@ -98,8 +168,8 @@ template <> struct Vec8<bf16_t> {
         const u32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(a[i] << 16);
-            v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+            v[2 * i] = h16_lo_f32(a[i]);
+            v[2 * i + 1] = h16_hi_f32(a[i]);
         }
     }
     static __device__ __forceinline__ void store_nt(bf16_t *p, const float (&v)[8]) {
@@ -118,7 +188,7 @@ __device__ __forceinline__ void store_split8(float *p, const float (&v)[8]) {
     for (int i = 0; i < 4; ++i) {
         const uint32_t h = pack2_bf16(v[2 * i], v[2 * i + 1]);
         hi[i] = h;
-        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        lo[i] = pack2_bf16(v[2 * i] - h16_lo_f32(h), v[2 * i + 1] - h16_hi_f32(h));
     }
     *reinterpret_cast<u32x4_t *>(p) = hi;
     *reinterpret_cast<u32x4_t *>(p + 4) = lo;

@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(256, 2) conv_c4_patch_kernel(const C4Args ca) 
                 xf[j] = *reinterpret_cast<const bf16x8_t *>(base + ((((jb + j) >> 2) + kk) * PW + ((jb + j) & 3) * 16) * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][kk], xf[j], acc[0][jb + j], 0, 0, 0);
-                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][kk], xf[j], acc[1][jb + j], 0, 0, 0);
+                acc[0][jb + j] = dl_mfma16(wf[0][kk], xf[j], acc[0][jb + j]);
+                acc[1][jb + j] = dl_mfma16(wf[1][kk], xf[j], acc[1][jb + j]);
             }
         }
     }
@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(256, 2) conv_c4_patch_kernel(const C4Args ca) 
             // pixel & 7 == fr & 7 for every fragment, so the swizzled chunk is a per-lane constant and the fragment offset an immediate
             if (!(ca.abl & 8)) *reinterpret_cast<u32x2_t *>(ob[cf] + ((j >> 2) * TC + (j & 3) * 16) * 128) = p;
             if (want_stats) {
-                const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                const float q0 = h16_lo_f32(p[0]), q1 = h16_hi_f32(p[0]);
+                const float q2 = h16_lo_f32(p[1]), q3 = h16_hi_f32(p[1]);
                 st1[cf][0] += q0; st2[cf][0] += q0 * q0; st1[cf][1] += q1; st2[cf][1] += q1 * q1;
                 st1[cf][2] += q2; st2[cf][2] += q2 * q2; st1[cf][3] += q3; st2[cf][3] += q3 * q3;
             }

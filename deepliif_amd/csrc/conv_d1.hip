@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256, 2) conv_d1_kernel(const D1Args sa) {
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (khc >= 0) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[(khc < 0 ? 0 : khc) * 2 + p], F[p][j], cur[j], 0, 0, 0);
-                if constexpr (khn >= 0) nxt[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[(khn < 0 ? 0 : khn) * 2 + p], F[p][j], nxt[j], 0, 0, 0);
+                if constexpr (khc >= 0) cur[j] = dl_mfma32(W[(khc < 0 ? 0 : khc) * 2 + p], F[p][j], cur[j]);
+                if constexpr (khn >= 0) nxt[j] = dl_mfma32(W[(khn < 0 ? 0 : khn) * 2 + p], F[p][j], nxt[j]);
             }
     };
 

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) conv_d1g_kernel(const D1gArgs sa) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8_t f = *reinterpret_cast<lds_frag_t *>(lds + slot * D1G_SLOT + (a_dw[o % 3] ^ (s << 5)));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[o][s], f, acc, 0, 0, 0);
+                acc = dl_mfma32(W[o][s], f, acc);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256) conv_dot_fwd_kernel(const DotArgs a) {
         for (int t = 0; t < 16; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc += __uint_as_float(x[t][e] << 16) * w[t][2 * e];
-                acc += __uint_as_float(x[t][e] & 0xffff0000u) * w[t][2 * e + 1];
+                acc += h16_lo_f32(x[t][e]) * w[t][2 * e];
+                acc += h16_hi_f32(x[t][e]) * w[t][2 * e + 1];
             }
         acc = wave_sum(acc);
         if (lane == 0) {

@@ -62,7 +62,7 @@ template <> __device__ __forceinline__ void raw_load<float>(Raw8<float> &r, cons
 }
 __device__ __forceinline__ void raw_to_f32(const Raw8<bf16_t> &r, float (&f)[8]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r.v[i] << 16); f[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { f[2 * i] = h16_lo_f32(r.v[i]); f[2 * i + 1] = h16_hi_f32(r.v[i]); }
 }
 __device__ __forceinline__ void raw_to_f32(const Raw8<float> &r, float (&f)[8]) {
     f[0] = r.a[0]; f[1] = r.a[1]; f[2] = r.a[2]; f[3] = r.a[3]; f[4] = r.b[0]; f[5] = r.b[1]; f[6] = r.b[2]; f[7] = r.b[3];
@@ -258,10 +258,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
                     if constexpr (PREC == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = dl_mfma16(wf[1][i], xf[0][j], acc[i][j]);
+                        acc[i][j] = dl_mfma16(wf[0][i], xf[1][j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = dl_mfma16(wf[0][i], xf[0][j], acc[i][j]);
                 }
         }
         if (more) store_tile(cur ^ 1);
@@ -407,8 +407,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
             p[1] = pack2_bf16(v[2], v[3]);
             *reinterpret_cast<u32x2_t *>(dst + (size_t)j * 16 * (BN * 2)) = p;
             if (want_stats && live[j]) {       // statistics of exactly what is stored (bf16-rounded), like the stand-alone kernel sees
-                const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                const float q0 = h16_lo_f32(p[0]), q1 = h16_hi_f32(p[0]);
+                const float q2 = h16_lo_f32(p[1]), q3 = h16_hi_f32(p[1]);
                 s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
                 s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
             }
@@ -477,8 +477,8 @@ __device__ __forceinline__ void tile_epilogue_lds(const ConvArgs &a, f32x4_t (&a
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const unsigned dw = v[i >> 1], yw = yv[it][i >> 1];
-                float dn = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
-                const float yy = __uint_as_float((i & 1) ? (yw & 0xffff0000u) : (yw << 16));
+                float dn = (i & 1) ? h16_hi_f32(dw) : h16_lo_f32(dw);
+                const float yy = (i & 1) ? h16_hi_f32(yw) : h16_lo_f32(yw);
                 const float nv = yy * sc[i] + sh[i];
                 if (a.bn_act == DL_ACT_RELU) dn = nv > 0.f ? dn : 0.f;
                 else if (a.bn_act == DL_ACT_LRELU) dn = nv > 0.f ? dn : 0.2f * dn;
@@ -581,8 +581,8 @@ __device__ __forceinline__ void glds_epilogue(const ConvArgs &a, f32x4_t (&acc)[
                 p[1] = pack2_bf16(v[2], v[3]);
                 *reinterpret_cast<u32x2_t *>(dst) = p;
                 if (want_stats) {      // statistics of exactly what was stored (bf16-rounded), like the stand-alone kernel sees
-                    const float q0 = __uint_as_float(p[0] << 16), q1 = __uint_as_float(p[0] & 0xffff0000u);
-                    const float q2 = __uint_as_float(p[1] << 16), q3 = __uint_as_float(p[1] & 0xffff0000u);
+                    const float q0 = h16_lo_f32(p[0]), q1 = h16_hi_f32(p[0]);
+                    const float q2 = h16_lo_f32(p[1]), q3 = h16_hi_f32(p[1]);
                     st1[i][0] += q0; st2[i][0] += q0 * q0; st1[i][1] += q1; st2[i][1] += q1 * q1;
                     st1[i][2] += q2; st2[i][2] += q2 * q2; st1[i][3] += q3; st2[i][3] += q3 * q3;
                 }
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = dl_mfma16(wf[i], xf[j], acc[i][j]);
     };
 
     if constexpr (STAG && NW == 8 && BK == 64) {
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_kernel(const ConvArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[ib + i][ja + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[ib + i][ja + j], 0, 0, 0);
+                    acc[ib + i][ja + j] = dl_mfma16(wf[kk][i], xf[kk][j], acc[ib + i][ja + j]);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -1316,7 +1316,7 @@ __global__ void __launch_bounds__(512) conv_gemm_p32_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = dl_mfma32(f[i], f[2 + j], acc[i][j]);
     };
     auto tile_bufs = [&](int u, const char *&xbuf, const char *&wbuf, int &axs) __attribute__((always_inline)) {
         wbuf = ws + (u & 1) * WB;
@@ -1416,8 +1416,8 @@ __global__ void __launch_bounds__(512) conv_gemm_p32_kernel(const ConvArgs a) {
                     pk[1] = pack2_bf16(v[2], v[3]);
                     *reinterpret_cast<u32x2_t *>(dst) = pk;
                     if (want_stats) {
-                        const float q0 = __uint_as_float(pk[0] << 16), q1 = __uint_as_float(pk[0] & 0xffff0000u);
-                        const float q2 = __uint_as_float(pk[1] << 16), q3 = __uint_as_float(pk[1] & 0xffff0000u);
+                        const float q0 = h16_lo_f32(pk[0]), q1 = h16_hi_f32(pk[0]);
+                        const float q2 = h16_lo_f32(pk[1]), q3 = h16_hi_f32(pk[1]);
                         s1[i][q][0] += q0; s2[i][q][0] += q0 * q0; s1[i][q][1] += q1; s2[i][q][1] += q1 * q1;
                         s1[i][q][2] += q2; s2[i][q][2] += q2 * q2; s1[i][q][3] += q3; s2[i][q][3] += q3 * q3;
                     }

@@ -152,8 +152,8 @@ __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
             if constexpr (g < 9) stage_piece(S2DIC<(g < 9 ? g : 0)>{}, soff_dma, slot_dma, rsrc_dma);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (khc >= 0) cur[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[khc < 0 ? 0 : khc][kw][sx], Fc[j], cur[j], 0, 0, 0);
-                if constexpr (khn >= 0) nxt[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[khn < 0 ? 0 : khn][kw][sx], Fc[j], nxt[j], 0, 0, 0);
+                if constexpr (khc >= 0) cur[j] = dl_mfma32(W[khc < 0 ? 0 : khc][kw][sx], Fc[j], cur[j]);
+                if constexpr (khn >= 0) nxt[j] = dl_mfma32(W[khn < 0 ? 0 : khn][kw][sx], Fc[j], nxt[j]);
             }
         };
         group(S2DIC<0>{}, F0, F1); group(S2DIC<1>{}, F1, F0); group(S2DIC<2>{}, F0, F1); group(S2DIC<3>{}, F1, F0);
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) conv_s2d_kernel(const S2dArgs sa) {
                 if constexpr (STATS) {                 // statistics of exactly what is stored (bf16-rounded)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        const float lo = h16_lo_f32(v[e]), hi = h16_hi_f32(v[e]);
                         s1[2 * e] += lo; s2[2 * e] += lo * lo; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
                     }
                 }

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2fArgs sa) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], xf[s][j], acc[p][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[p][j] = dl_mfma32(wf[s], xf[s][j], acc[p][j]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2fArgs sa) {
                 pk[1] = pack2_bf16(v[2], v[3]);
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2_t *>(tile + (wm * 64 + j * 32 + lr) * 512 + unit * 8) = pk;
                 if (want_stats && live[j]) {          // statistics of exactly what is stored (bf16-rounded)
-                    const float q0 = __uint_as_float(pk[0] << 16), q1 = __uint_as_float(pk[0] & 0xffff0000u);
-                    const float q2 = __uint_as_float(pk[1] << 16), q3 = __uint_as_float(pk[1] & 0xffff0000u);
+                    const float q0 = h16_lo_f32(pk[0]), q1 = h16_hi_f32(pk[0]);
+                    const float q2 = h16_lo_f32(pk[1]), q3 = h16_hi_f32(pk[1]);
                     s1[0] += q0; s2[0] += q0 * q0; s1[1] += q1; s2[1] += q1 * q1;
                     s1[2] += q2; s2[2] += q2 * q2; s1[3] += q3; s2[3] += q3 * q3;
                 }

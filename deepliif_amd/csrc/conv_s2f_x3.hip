@@ -153,15 +153,15 @@ __global__ void __launch_bounds__(512) conv_s2f_x3_kernel(const S2fX3Args sa) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], xh[s][j], acc[p][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[p][j] = dl_mfma32(wl[s], xh[s][j], acc[p][j]);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], xl[s][j], acc[p][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[p][j] = dl_mfma32(wh[s], xl[s][j], acc[p][j]);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], xh[s][j], acc[p][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[p][j] = dl_mfma32(wh[s], xh[s][j], acc[p][j]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
             if constexpr (STATS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                    const float lo = h16_lo_f32(v[e]), hi = h16_hi_f32(v[e]);
                     s1[2 * e] += lo; s2[2 * e] += lo * lo; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
                 }
             }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[u][s], Fc[u * 2 + j], acc[0][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[0][j] = dl_mfma32(W[u][s], Fc[u * 2 + j], acc[0][j]);
             };
             sub(S2UIC<0>{}, FA, FB); sub(S2UIC<1>{}, FB, FA); sub(S2UIC<2>{}, FA, FB); sub(S2UIC<3>{}, FB, FA);
             sub(S2UIC<4>{}, FA, FB); sub(S2UIC<5>{}, FB, FA); sub(S2UIC<6>{}, FA, FB); sub(S2UIC<7>{}, FB, FA);
@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(256) conv_s2u_kernel(const S2uArgs sa) {
                 if constexpr (s < 5) stage_piece(S2UIC<(s < 5 ? s : 0)>{}, soff_dma, slot_dma, rs);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0][s], Fc[0 + j], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1][s], Fc[0 + j], acc[1][j], 0, 0, 0);
-                    acc[2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[3][s], Fc[0 + j], acc[2][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2][s], Fc[2 + j], acc[1][j], 0, 0, 0);
-                    acc[2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[4][s], Fc[4 + j], acc[2][j], 0, 0, 0);
+                    acc[0][j] = dl_mfma32(W[0][s], Fc[0 + j], acc[0][j]);
+                    acc[1][j] = dl_mfma32(W[1][s], Fc[0 + j], acc[1][j]);
+                    acc[2][j] = dl_mfma32(W[3][s], Fc[0 + j], acc[2][j]);
+                    acc[1][j] = dl_mfma32(W[2][s], Fc[2 + j], acc[1][j]);
+                    acc[2][j] = dl_mfma32(W[4][s], Fc[4 + j], acc[2][j]);
                 }
             };
             sub(S2UIC<0>{}, FA, FB); sub(S2UIC<1>{}, FB, FA); sub(S2UIC<2>{}, FA, FB); sub(S2UIC<3>{}, FB, FA);

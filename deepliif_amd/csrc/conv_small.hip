@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(640) conv_narrow_roll_kernel(const NarrowArgs 
 #pragma unroll
                     for (int kh = 0; kh < KH; ++kh) {
                         const int p = (S0 + (KH / 2) - kh + 2 * KH) % KH;          // block of output row h = r + pad - kh  (pad == KH/2)
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], kf == 0 ? a0 : a1, acc[p], 0, 0, 0);
+                        acc[p] = dl_mfma16(wf[kh][kf], kf == 0 ? a0 : a1, acc[p]);
                     }
             } else {
                 asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(640) conv_narrow_roll_kernel(const NarrowArgs 
 #pragma unroll
                     for (int kh = 0; kh < KH; ++kh) {
                         const int p = (S1 + (KH / 2) - kh + 2 * KH) % KH;
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], kf == 0 ? b0 : b1, acc[p], 0, 0, 0);
+                        acc[p] = dl_mfma16(wf[kh][kf], kf == 0 ? b0 : b1, acc[p]);
                     }
             }
             if (!(a.abl & 8)) {
@@ -232,8 +232,8 @@ __device__ __forceinline__ void narrow_split8(f32x4_t a, f32x4_t b, bf16x8_t &hi
         const uint32_t hb = pack2_bf16(b[2 * i], b[2 * i + 1]);
         h[i] = ha;
         h[2 + i] = hb;
-        l[i] = pack2_bf16(a[2 * i] - __uint_as_float(ha << 16), a[2 * i + 1] - __uint_as_float(ha & 0xffff0000u));
-        l[2 + i] = pack2_bf16(b[2 * i] - __uint_as_float(hb << 16), b[2 * i + 1] - __uint_as_float(hb & 0xffff0000u));
+        l[i] = pack2_bf16(a[2 * i] - h16_lo_f32(ha), a[2 * i + 1] - h16_hi_f32(ha));
+        l[2 + i] = pack2_bf16(b[2 * i] - h16_lo_f32(hb), b[2 * i + 1] - h16_hi_f32(hb));
     }
     hi = __builtin_bit_cast(bf16x8_t, h);
     lo = __builtin_bit_cast(bf16x8_t, l);
@@ -359,12 +359,12 @@ __global__ void __launch_bounds__(640) conv_narrow_roll_x3_kernel(const NarrowX3
                     const int pb = (S0 + 1 + (KH / 2) - kh + 2 * NBLK) % NBLK;               // the same for row q + 1
                     const bf16x8_t lw = lw_next;                                             // read one kernel row ahead: six MFMAs cover the LDS latency
                     if (kh + 1 < KH) lw_next = wl_me[((kh + 1) * 2 + kf) * 64];
-                    acc[pa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lw, ah, acc[pa], 0, 0, 0);
-                    acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lw, bh, acc[pb], 0, 0, 0);
-                    acc[pa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], al, acc[pa], 0, 0, 0);
-                    acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], bl, acc[pb], 0, 0, 0);
-                    acc[pa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], ah, acc[pa], 0, 0, 0);
-                    acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][kf], bh, acc[pb], 0, 0, 0);
+                    acc[pa] = dl_mfma16(lw, ah, acc[pa]);
+                    acc[pb] = dl_mfma16(lw, bh, acc[pb]);
+                    acc[pa] = dl_mfma16(wf[kh][kf], al, acc[pa]);
+                    acc[pb] = dl_mfma16(wf[kh][kf], bl, acc[pb]);
+                    acc[pa] = dl_mfma16(wf[kh][kf], ah, acc[pa]);
+                    acc[pb] = dl_mfma16(wf[kh][kf], bh, acc[pb]);
                 }
             }
             constexpr int pc0 = (S0 - (KH / 2) + 2 * NBLK) % NBLK;                            // block completed by row q     (output row r - pad)

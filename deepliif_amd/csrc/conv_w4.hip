@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
         // natural order hipcc put an s_waitcnt lgkmcnt(0) BEHIND the first two fresh reads of every sub-step (a full LDS round trip, 4 x per step)
         constexpr int m = decltype(MI)::value, i = 3 - (m >> 2), j = 3 - (m & 3);
         if constexpr (ABL == 2) return;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[4 + j], acc[i][j], 0, 0, 0);
+        acc[i][j] = dl_mfma32(F[i], F[4 + j], acc[i][j]);
     };
     // the fragment lane that fell off the image row reads a neighbouring buffer: zero it (SH = slab shift of the step the fragments belong to)
     auto fix_edge = [&](auto SHc, bf16x8_t (&F)[8]) __attribute__((always_inline)) {
@@ -454,14 +454,14 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
             if constexpr (ADD) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = pack2_bf16(__uint_as_float(v[e] << 16) + __uint_as_float(r[e] << 16), __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(r[e] & 0xffff0000u));
+                    v[e] = pack2_bf16(h16_lo_f32(v[e]) + h16_lo_f32(r[e]), h16_hi_f32(v[e]) + h16_hi_f32(r[e]));
             }
             {       // (w4 shapes: whole image rows of 128 pixels, an even number of them -- every tile row is a pixel of the tensor)
                 *reinterpret_cast<u32x4_t *>(out + (size_t)(m0 + row) * a.out_pstride + co_t) = v;
                 if constexpr (STATS) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        const float lo = h16_lo_f32(v[e]), hi = h16_hi_f32(v[e]);
                         s1[2 * e] += lo; s2[2 * e] += lo * lo; s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
                     }
                 }
@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256) conv_gemm_w4_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const unsigned dw = v[i >> 1], yw = r[i >> 1];
-                        float dn = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
-                        const float yy = __uint_as_float((i & 1) ? (yw & 0xffff0000u) : (yw << 16));
+                        float dn = (i & 1) ? h16_hi_f32(dw) : h16_lo_f32(dw);
+                        const float yy = (i & 1) ? h16_hi_f32(yw) : h16_lo_f32(yw);
                         const float nv = yy * sc[i] + sh[i];
                         dn = nv > 0.f ? dn : dn * bn_slope;          // act'(nv): 1 above zero; below: 0 (ReLU), 0.2 (LeakyReLU), 1 (no activation) -- no branch per element
                         s1[i] += dn;
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(256) probe_mfma_sustained_kernel(const bf16_t 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i + 4 * (s & 1)], F[8 + j + 4 * (s >> 1)], acc[i][j], 0, 0, 0);
+                    acc[i][j] = dl_mfma32(F[i + 4 * (s & 1)], F[8 + j + 4 * (s >> 1)], acc[i][j]);
     }
     float t = 0.f;
 #pragma unroll

@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(256) conv_gemm_w4x3_kernel(const ConvArgs a) {
     // the 48 MFMAs of a sub-step, term-major; MFMA m of a term works on (i, j) = (3 - (m >> 2), 3 - (m & 3))
     auto mma3 = [&](auto Mc, const bf16x8_t (&F)[16]) __attribute__((always_inline)) {
         constexpr int m = decltype(Mc)::value, term = m >> 4, q = m & 15, i = 3 - (q >> 2), j = 3 - (q & 3);
-        if constexpr (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[4 + i], F[8 + j], acc[i][j], 0, 0, 0);          // lo_w hi_x
-        else if constexpr (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[12 + j], acc[i][j], 0, 0, 0);        // hi_w lo_x
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[8 + j], acc[i][j], 0, 0, 0);                                  // hi_w hi_x
+        if constexpr (term == 0) acc[i][j] = dl_mfma32(F[4 + i], F[8 + j], acc[i][j]);          // lo_w hi_x
+        else if constexpr (term == 1) acc[i][j] = dl_mfma32(F[i], F[12 + j], acc[i][j]);        // hi_w lo_x
+        else acc[i][j] = dl_mfma32(F[i], F[8 + j], acc[i][j]);                                  // hi_w hi_x
     };
     auto fix_edge = [&](auto SHc, bf16x8_t (&F)[16]) __attribute__((always_inline)) {
         constexpr int SH = decltype(SHc)::value;

@@ -41,8 +41,8 @@ __device__ __forceinline__ void x3_split8(f32x4_t a, f32x4_t b, bf16x8_t &hi, bf
         const uint32_t hb = pack2_bf16(b[2 * i], b[2 * i + 1]);
         h[i] = ha;
         h[2 + i] = hb;
-        l[i] = pack2_bf16(a[2 * i] - __uint_as_float(ha << 16), a[2 * i + 1] - __uint_as_float(ha & 0xffff0000u));
-        l[2 + i] = pack2_bf16(b[2 * i] - __uint_as_float(hb << 16), b[2 * i + 1] - __uint_as_float(hb & 0xffff0000u));
+        l[i] = pack2_bf16(a[2 * i] - h16_lo_f32(ha), a[2 * i + 1] - h16_hi_f32(ha));
+        l[2 + i] = pack2_bf16(b[2 * i] - h16_lo_f32(hb), b[2 * i + 1] - h16_hi_f32(hb));
     }
     hi = __builtin_bit_cast(bf16x8_t, h);
     lo = __builtin_bit_cast(bf16x8_t, l);
@@ -62,7 +62,7 @@ __device__ __forceinline__ void x3_split4(f32x4_t v, u32x2_t &hi, u32x2_t &lo) {
     for (int i = 0; i < 2; ++i) {
         const uint32_t h = pack2_bf16(v[2 * i], v[2 * i + 1]);
         hi[i] = h;
-        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        lo[i] = pack2_bf16(v[2 * i] - h16_lo_f32(h), v[2 * i + 1] - h16_hi_f32(h));
     }
 }
 
@@ -404,17 +404,17 @@ __global__ void __launch_bounds__(512) conv_gemm_8ph_x3_kernel(const ConvArgs a)
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[ib + i][ja + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xh[j], acc[ib + i][ja + j], 0, 0, 0);
+                acc[ib + i][ja + j] = dl_mfma16(wf[1][i], xh[j], acc[ib + i][ja + j]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[ib + i][ja + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xl[j], acc[ib + i][ja + j], 0, 0, 0);
+                acc[ib + i][ja + j] = dl_mfma16(wf[0][i], xl[j], acc[ib + i][ja + j]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[ib + i][ja + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xh[j], acc[ib + i][ja + j], 0, 0, 0);
+                acc[ib + i][ja + j] = dl_mfma16(wf[0][i], xh[j], acc[ib + i][ja + j]);
     };
     auto mma_q = [&](auto IB, auto JA, const bf16x8_t (&wf)[2][2]) __attribute__((always_inline)) {
         if (ABL == 2) return;
@@ -735,15 +735,15 @@ __global__ void __launch_bounds__(WM * WN * 64) conv_gemm_glds_x3_kernel(const C
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = dl_mfma16(wl[i], xh[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = dl_mfma16(wh[i], xl[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j) acc[i][j] = dl_mfma16(wh[i], xh[j], acc[i][j]);
         __syncthreads();
     }
 
@@ -961,18 +961,18 @@ __global__ void __launch_bounds__(256, 2) conv_c4_patch_x3_kernel(const C4Args c
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[0][kk], xh[j], acc[0][jb + j], 0, 0, 0);
-                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[1][kk], xh[j], acc[1][jb + j], 0, 0, 0);
+                acc[0][jb + j] = dl_mfma16(wl[0][kk], xh[j], acc[0][jb + j]);
+                acc[1][jb + j] = dl_mfma16(wl[1][kk], xh[j], acc[1][jb + j]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0][kk], xl[j], acc[0][jb + j], 0, 0, 0);
-                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1][kk], xl[j], acc[1][jb + j], 0, 0, 0);
+                acc[0][jb + j] = dl_mfma16(wh[0][kk], xl[j], acc[0][jb + j]);
+                acc[1][jb + j] = dl_mfma16(wh[1][kk], xl[j], acc[1][jb + j]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0][kk], xh[j], acc[0][jb + j], 0, 0, 0);
-                acc[1][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1][kk], xh[j], acc[1][jb + j], 0, 0, 0);
+                acc[0][jb + j] = dl_mfma16(wh[0][kk], xh[j], acc[0][jb + j]);
+                acc[1][jb + j] = dl_mfma16(wh[1][kk], xh[j], acc[1][jb + j]);
             }
         }
     }

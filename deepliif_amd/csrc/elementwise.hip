@@ -783,7 +783,7 @@ __global__ void probe_mfma16_kernel(const bf16_t *A, const bf16_t *B, float *D) 
         b[j] = (short)B[(g * 8 + j) * 16 + r];        // B[k = 8g + j][col = r]
     }
     f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    c = dl_mfma16(a, b, c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) D[(g * 4 + i) * 16 + r] = c[i];   // row = 4g + i, col = r
 }

@@ -40,6 +40,13 @@ const char *dl_switch(int id) { return (id >= 0 && id < DL_SW_COUNT_ && g_sw_set
 
 extern "C" int dl_switch_count(void) { return DL_SW_COUNT_; }
 extern "C" const char *dl_switch_name(int id) { return (id >= 0 && id < DL_SW_COUNT_) ? g_sw_names[id] : nullptr; }
+extern "C" int dl_half_format(void) {
+#ifdef DL_H16_FP16
+    return DL_HALF_FP16;
+#else
+    return DL_HALF_BF16;
+#endif
+}
 extern "C" int dl_dev_build(void) {
 #ifdef DL_DEV_SWITCHES
     return 1;

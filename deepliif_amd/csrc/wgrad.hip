@@ -57,7 +57,7 @@ __device__ __forceinline__ void raww_to_planes(const RawW<T> &r, int act, u32x4_
     if constexpr (sizeof(T) == 2) {
         if (PREC == 1 && act == DL_ACT_NONE) { hi = r.v; return; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r.v[i] << 16); f[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { f[2 * i] = h16_lo_f32(r.v[i]); f[2 * i + 1] = h16_hi_f32(r.v[i]); }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { f[i] = r.a[i]; f[4 + i] = r.b[i]; }
@@ -241,10 +241,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
                 if constexpr (PREC == 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = dl_mfma16(af[1][i], bf[0][j], acc[i][j]);
+                    acc[i][j] = dl_mfma16(af[0][i], bf[1][j], acc[i][j]);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = dl_mfma16(af[0][i], bf[0][j], acc[i][j]);
             }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(512) wgrad_glds_kernel(const WgradArgs a, cons
 #pragma unroll
             for (int i = 0; i < FA; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[i][j] = dl_mfma16(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(512) wgrad_8ph_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[i], bq[j], acc[i0 + i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = dl_mfma16(ap[i], bq[j], acc[i0 + i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
     // first barrier, the 16 MFMAs of this phase (+ PREP: next half's addresses, independent VALU work issued between them), second barrier

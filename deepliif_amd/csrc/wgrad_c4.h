@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_c4_kernel(const WgradC4Args a) {
                     // rows of this [32][16] matrix = pixels c .. c+31 of patch row r + (f >> 1), starting at slot 4*(f & 1): row pitch 4 elements
                     const bf16x8_t bf = tr_fragment_rows<4>(pt + ((r + (f >> 1)) * PW + c + 4 * (f & 1)) * 4, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = dl_mfma16(af[i], bf, acc[i][j]);
                 }
             }
         }

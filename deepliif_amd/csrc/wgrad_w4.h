@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) wgrad_w4_kernel(const WgradW4Args a, cons
     };
     auto mma_one = [&](auto Qc, const bf16x8_t (&F)[7]) __attribute__((always_inline)) {
         constexpr int q = decltype(Qc)::value, i = 3 - q / 3, k = 2 - q % 3;
-        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[i], F[4 + k], acc[i][k], 0, 0, 0);
+        acc[i][k] = dl_mfma32(F[i], F[4 + k], acc[i][k]);
     };
     // one 16-pixel sub-step: wait for Fc (read during the previous sub-step), then 12 MFMAs on it; in the shadows of MFMAs 0..6 the fragment reads
     // of the next sub-step (into Fn), in the shadows of MFMAs 7..10 DMA pieces D0 .. D0+3 of the NEXT row (when D0 >= 0)

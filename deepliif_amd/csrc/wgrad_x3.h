@@ -61,7 +61,7 @@ __device__ __forceinline__ void x3w_split4(f32x4_t v, int act, u32x2_t &hi, u32x
     for (int i = 0; i < 2; ++i) {
         const uint32_t h = pack2_bf16(v[2 * i], v[2 * i + 1]);
         hi[i] = h;
-        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        lo[i] = pack2_bf16(v[2 * i] - h16_lo_f32(h), v[2 * i + 1] - h16_hi_f32(h));
     }
 }
 
@@ -268,15 +268,15 @@ __global__ void __launch_bounds__(512) wgrad_glds_x3_kernel(const WgradArgs a, c
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = dl_mfma16(al[i], bh[j], acc[half * 4 + i][j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = dl_mfma16(ah[i], bl[j], acc[half * 4 + i][j]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[half * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[half * 4 + i][j] = dl_mfma16(ah[i], bh[j], acc[half * 4 + i][j]);
         }
         if (kt + 1 < nk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's own rows of step kt+1 have landed
@@ -447,15 +447,15 @@ __global__ void __launch_bounds__(512) wgrad_4ph_x3_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = dl_mfma16(al[i], bh[j], acc[i0 + i][j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = dl_mfma16(ah[i], bl[j], acc[i0 + i][j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i0 + i][j] = dl_mfma16(ah[i], bh[j], acc[i0 + i][j]);
         if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -654,11 +654,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_c4_x3_kernel(const WgradC4X3Args
                     const bf16x8_t bh = tr_fragment_rows<4>(pth + po, lane);
                     const bf16x8_t bl = tr_fragment_rows<4>(ptl + po, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = dl_mfma16(al[i], bh, acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = dl_mfma16(ah[i], bl, acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) acc[i][j] = dl_mfma16(ah[i], bh, acc[i][j]);
                 }
             }
         }

@@ -27,15 +27,30 @@ class Precision:
     dtype: torch.dtype
     prec: int
 
+    @property
+    def is16(self) -> bool:
+        """activations stored in the library's 16-bit type, one MFMA pass"""
+        return self.dtype in (torch.bfloat16, torch.float16)
+
+    @property
+    def half(self) -> str:
+        """which library serves this policy (ops.half_mode): 'fp16' -> libdeepliif_hip_f16.so, everything else -> libdeepliif_hip.so"""
+        return 'fp16' if self.dtype == torch.float16 else 'bf16'
+
     @staticmethod
     def get(name: str) -> 'Precision':
         if name in ('bf16', 'bfloat16'):
             return Precision('bf16', torch.bfloat16, L.PREC_BF16)
+        if name in ('fp16', 'float16', 'half'):
+            # INFERENCE ONLY (Ctx refuses a tape): IEEE half storage + MFMA operands, 11 significand bits instead of bf16's 8 at the same matrix rate --
+            # a generator's forward lands 7x nearer to the fp32 reference (profiles/r05/fp16_policy_experiment.json).  Not for training: 89-100 % of this
+            # model's conv-output gradients are below half's smallest normal number.
+            return Precision('fp16', torch.float16, L.PREC_BF16)
         if name in ('fp32', 'float32'):
             return Precision('fp32', torch.float32, L.PREC_BF16X3)
         if name == 'fp32_bf16mma':
             return Precision('fp32_bf16mma', torch.float32, L.PREC_BF16)
-        raise ValueError(f'unknown precision {name!r} (bf16 | fp32 | fp32_bf16mma)')
+        raise ValueError(f'unknown precision {name!r} (bf16 | fp16 | fp32 | fp32_bf16mma)')
 
 
 class Act:
@@ -225,7 +240,7 @@ class ConvLayer:
         """(Re)build the bf16 GEMM images when the fp32 master weights changed: torch-side in-place updates bump
         `_version`; the fused Adam kernel writes through raw pointers and bumps `_dl_epoch` instead (optim.py)."""
         w = self.weight
-        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device))
+        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device), prec.half)
         with_lo = prec.prec == L.PREC_BF16X3
         be = ops.impl()
         if self.fwd_key != key:
@@ -243,7 +258,7 @@ class ConvLayer:
         """Narrow-Cout ConvTranspose2d(k=4, s=2, p=1) at inference (conv() below): the weights as ONE 1x1 GEMM image with a row per
         (ky, kx, co) -- W'[(ky*4+kx)*Cout + co][ci] = W[ci][co][ky][kx] -- so the input is staged once instead of once per (phase, tap)."""
         w = self.weight
-        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device))
+        key = (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), prec.prec, str(w.device), prec.half)
         if getattr(self, 'taps_key', None) != key:
             spec = self.spec
             if getattr(self, 'packed_taps', None) is None or self.packed_taps.hi.device != w.device:
@@ -274,7 +289,7 @@ class PackBatch:
                 if packed is None or key is None or key[1] != w.data_ptr() or packed.hi.device != w.device:
                     continue            # never packed / storage moved: the lazy path handles it
                 jobs.append((packed, w.detach()))
-                stamps.append((layer, attr, (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), key[3], key[4])))
+                stamps.append((layer, attr, (w._version, w.data_ptr(), getattr(w, '_dl_epoch', 0), key[3], key[4], key[5])))
         if not jobs:
             return 0
         sig = tuple((pk.hi.data_ptr(), pk.lo.data_ptr() if pk.lo is not None else 0, w.data_ptr()) for pk, w in jobs)
@@ -306,6 +321,11 @@ class Ctx:
     """Per-call execution context."""
 
     def __init__(self, prec: Precision, tape: Optional[Tape], training: bool, per_sample_norm: bool = False):
+        if prec.half == 'fp16' and (tape is not None or training):
+            raise ValueError("precision 'fp16' is an inference policy: gradients of this model underflow IEEE half (train with 'bf16' or 'fp32')")
+        if prec.half != ops.half_format():
+            raise RuntimeError(f"precision {prec.name!r} needs the {prec.half} library: run the forward inside ops.half_mode({prec.half!r}) "
+                               f"(the networks' forward() and inference.py do)")
         self.prec = prec
         self.tape = tape
         self.training = training            # BatchNorm running-stat updates (module.training and tracking enabled)
@@ -350,13 +370,13 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     if spec.kind == 'convT':
         assert (ho, wo) == (2 * hi, 2 * wi)
     assert x.values_stored or not layer.narrow, 'a split-only activation reached the narrow-Cout path'
-    if layer.narrow and in_act == L.ACT_NONE and ((ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16) or (ctx.prec.prec == L.PREC_BF16X3 and x.t.dtype == torch.float32)) and \
+    if layer.narrow and in_act == L.ACT_NONE and ((ctx.prec.prec == L.PREC_BF16 and ctx.prec.is16 and x.t.dtype == ctx.prec.dtype) or (ctx.prec.prec == L.PREC_BF16X3 and x.t.dtype == torch.float32)) and \
             be.conv_narrow_supported(x.t, x.t.shape[3], spec.cout, spec.k, spec.pad, spec.pad_mode, act):
         # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
         be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
         nch = 0
     elif (_CONVT4 and spec.kind == 'convT' and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and spec.cout <= 4 and not (x_needs or w_needs)
-          and ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16 and getattr(be, 'convt4_gather', None) is not None):
+          and ctx.prec.prec == L.PREC_BF16 and ctx.prec.is16 and x.t.dtype == ctx.prec.dtype and getattr(be, 'convt4_gather', None) is not None):
         # UnetGenerator's outermost up-convolution to 3 channels (networks.py:573-576), inference: one 1x1 GEMM over the input with a row per
         # (ky, kx, co), then the 2x2 gather-sum + bias + tanh (dl_convt4_gather).  The 4-phase gather GEMM stages every input pixel 16 times for
         # 3 useful columns: 327 us at 8 x 256^2 x 128, 5.9 % of the inference batch.
@@ -378,7 +398,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
         nch = 0
     else:
         xin, fwd_in_act = x.t, in_act
-        if in_act != L.ACT_NONE and _PREACT and ctx.prec.prec == L.PREC_BF16 and x.t.dtype == torch.bfloat16:
+        if in_act != L.ACT_NONE and _PREACT and ctx.prec.prec == L.PREC_BF16 and ctx.prec.is16 and x.t.dtype == ctx.prec.dtype:
             # The direct-to-LDS conv kernels cannot transform while staging (the DMA bypasses the registers), so a conv with an
             # input activation falls back to the register-staged kernel.  Materialise in_act(x) once instead (one elementwise
             # pass over the input) and run the fast kernel on it; backward still masks with the raw x (kept as it is).

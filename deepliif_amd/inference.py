@@ -391,8 +391,10 @@ def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, 
     """run_generators_engine on a [N, C, H, W] fp32 tensor; returns name -> [N, 3, H, W] fp32 tensors (run_dask(output_tensor=True))."""
     first = next(iter(nets.values()))
     device = next(first.parameters()).device
-    x = E.to_engine(ts.to(device), E.Precision.get(first.precision))
-    return OrderedDict((k, E.from_engine(v)) for k, v in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items())
+    prec = E.Precision.get(first.precision)
+    with ops.half_mode(prec.half):
+        x = E.to_engine(ts.to(device), prec)
+        return OrderedDict((k, E.from_engine(v)) for k, v in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items())
 
 
 def run_dask(img, model_path=None, nets=None, eager_mode=False, opt=None, seg_only=False, mod_only=False, seg_weights=None, use_dask=True,
@@ -468,26 +470,27 @@ def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod
     prec = E.Precision.get(first.precision)
     h, w = int(images[0].shape[0]), int(images[0].shape[1])
     n_rows = len(TilePlan(w, h, tile_size, overlap_size).ys)
-    tiler = RegionTiler(images, tile_size, overlap_size, rows=split_rows(n_rows, world)[rank])
-    if len(tiler) == 0:
-        return {}, tiler.band
-    empty = tiler.empty_mask()
-    ids = np.array(tiler.tile_ids)
-    seg_only, mod_only = _wrapper_flags(opt, seg_only, mod_only)
-    colors = empty_tile_colors(opt, seg_only, mod_only)
-    if empty.any():
-        for k, c in colors.items():
-            tiler.paste(k, None, ids[empty].tolist(), const_rgb=c)
-    work = ids[~empty].tolist()
-    if limit_tiles is not None:
-        work = work[:limit_tiles]
-    cp = E.cpad(3 * len(images))
-    for s in range(0, len(work), batch_size):
-        chunk = work[s:s + batch_size]
-        x = E.Act(tiler.gather(chunk, prec.dtype, cp), 3 * len(images))
-        for k, a in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items():
-            tiler.paste(k, a.t, chunk)
-    return tiler.results(), tiler.band
+    with ops.half_mode(prec.half):
+        tiler = RegionTiler(images, tile_size, overlap_size, rows=split_rows(n_rows, world)[rank])
+        if len(tiler) == 0:
+            return {}, tiler.band
+        empty = tiler.empty_mask()
+        ids = np.array(tiler.tile_ids)
+        seg_only, mod_only = _wrapper_flags(opt, seg_only, mod_only)
+        colors = empty_tile_colors(opt, seg_only, mod_only)
+        if empty.any():
+            for k, c in colors.items():
+                tiler.paste(k, None, ids[empty].tolist(), const_rgb=c)
+        work = ids[~empty].tolist()
+        if limit_tiles is not None:
+            work = work[:limit_tiles]
+        cp = E.cpad(3 * len(images))
+        for s in range(0, len(work), batch_size):
+            chunk = work[s:s + batch_size]
+            x = E.Act(tiler.gather(chunk, prec.dtype, cp), 3 * len(images))
+            for k, a in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items():
+                tiler.paste(k, a.t, chunk)
+        return tiler.results(), tiler.band
 
 
 def gather_bands(local: Dict[str, torch.Tensor], band, height: int, width: int, keys: List[str], rank: int, world: int):

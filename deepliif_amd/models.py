@@ -223,6 +223,11 @@ class BaseModel:
         self.image_paths = []
         self.metric = 0
         self.precision = E.Precision.get(_get(opt, 'precision', networks.DEFAULT_PRECISION))
+        if self.precision.half == 'fp16':
+            # the model classes are the TRAINING surface (set_input / optimize_parameters); the fp16 policy is served by init_nets() / run_dask() /
+            # inference() / infer_region() (deepliif_amd/inference.py)
+            raise ValueError("precision 'fp16' is an inference policy (gradients of this model underflow IEEE half): build the model with "
+                             "'bf16' or 'fp32', serve fp16 through deepliif_amd.inference")
 
     def _device_from_opt(self, opt) -> torch.device:
         dev = torch.device('cuda:{}'.format(pick_gpu(opt.gpu_ids, self.is_train)))

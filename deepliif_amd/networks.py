@@ -89,8 +89,9 @@ class EngineNet(nn.Module):
         (momentum 0.1) where the module still tracks them, Dropout(0.5) active."""
         prec = E.Precision.get(self.precision)
         train = self.training
-        ctx = E.Ctx(prec, None, training=train, per_sample_norm=self.batched_per_sample_norm and not train)
-        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+        with E.ops.half_mode(prec.half):
+            ctx = E.Ctx(prec, None, training=train, per_sample_norm=self.batched_per_sample_norm and not train)
+            return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
 
 
 def _norm_binding(kind: str, C: int, module: nn.Module) -> Optional[E.NormLayer]:
@@ -551,8 +552,9 @@ class NLayerDiscriminator(EngineNet):
 
     def forward(self, x):
         prec = E.Precision.get(self.precision)
-        ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
-        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+        with E.ops.half_mode(prec.half):
+            ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
+            return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
 
 
 class PixelDiscriminator(EngineNet):
@@ -582,8 +584,9 @@ class PixelDiscriminator(EngineNet):
 
     def forward(self, x):
         prec = E.Precision.get(self.precision)
-        ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
-        return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
+        with E.ops.half_mode(prec.half):
+            ctx = E.Ctx(prec, None, training=False, per_sample_norm=False)
+            return E.from_engine(self.run(ctx, E.to_engine(x, prec)))
 
 
 # -------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import contextlib
 import threading
 from typing import Optional
 
@@ -27,9 +28,9 @@ from .geometry import (GatherPlan, NUM_CUS, WGRAD_C4_PARTS, choose_splitk, choos
 def dl_dtype(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return L.DL_F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:      # "the 16-bit type of the library": HipBackend._need_cuda checks that it is THIS library's
         return L.DL_BF16
-    raise TypeError(f'engine tensors are fp32 or bf16, got {t.dtype}')
+    raise TypeError(f'engine tensors are fp32 or bf16 / fp16, got {t.dtype}')
 
 
 def pstride(t: torch.Tensor) -> int:
@@ -158,8 +159,9 @@ class PackedWeights:
     def __init__(self, plan: GatherPlan, device, with_lo: bool):
         n = plan.rows_pad * plan.kstride
         self.plan = plan
-        self.hi = torch.empty(n, dtype=torch.bfloat16, device=device)
-        self.lo = torch.empty(n, dtype=torch.bfloat16, device=device) if with_lo else None
+        # raw 16-bit words: bfloat16 or IEEE half, whichever library packs them (dl_pack_weights of libdeepliif_hip.so / libdeepliif_hip_f16.so)
+        self.hi = torch.empty(n, dtype=torch.int16, device=device)
+        self.lo = torch.empty(n, dtype=torch.int16, device=device) if with_lo else None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -182,13 +184,40 @@ def _stream(t: Optional[torch.Tensor] = None):
     return C.c_void_p(_current_stream_handle(dev.index))
 
 
+# ---- the 16-bit format of the calling thread's engine work: 'bf16' (libdeepliif_hip.so) unless an fp16 inference forward is running (half_mode);
+# impl() hands out the backend bound to that library, _need_cuda refuses 16-bit tensors of the OTHER format (their bits would be misread silently)
+_HALF = threading.local()
+H16_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+
+def half_format() -> str:
+    return getattr(_HALF, 'name', 'bf16')
+
+
+@contextlib.contextmanager
+def half_mode(name: str):
+    """engine work of this thread inside the block runs on the library of that 16-bit format (engine.Precision.half)"""
+    if name not in H16_DTYPE:
+        raise ValueError(f'unknown 16-bit format {name!r} (bf16 | fp16)')
+    prev = half_format()
+    _HALF.name = name
+    try:
+        yield
+    finally:
+        _HALF.name = prev
+
+
 def _need_cuda(*ts):
     dev = None
+    other = torch.float16 if half_format() == 'bf16' else torch.bfloat16
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise L.HipLibraryError('deepliif_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback')
+        if t.dtype == other:
+            raise L.HipLibraryError(f'a {t.dtype} tensor reached the {half_format()} library: engine tensors of the two 16-bit formats cannot be mixed '
+                                    f'(ops.half_mode / engine.Precision)')
         if dev is None:
             dev = t.device
         elif t.device != dev:
@@ -197,11 +226,15 @@ def _need_cuda(*ts):
 
 
 class HipBackend:
-    """The product path: ctypes calls into libdeepliif_hip.so."""
+    """The product path: ctypes calls into libdeepliif_hip.so (half = 'bf16') or libdeepliif_hip_f16.so (half = 'fp16', inference only)."""
 
-    def __init__(self):
-        self.lib = L.load()
+    def __init__(self, half: str = 'bf16'):
+        self.half = half
+        self.lib = L.load(half)
         self._last_conv_desc = None
+
+    def check(self, rc, what):
+        L.check(rc, what, self.lib)
 
     @property
     def last_conv_kernel(self) -> str:
@@ -218,7 +251,7 @@ class HipBackend:
         assert src.dtype == torch.float32 and src.is_contiguous()
         d = fill_pack_desc(packed.plan, src.shape[0], src.shape[1], src.shape[2])
         d.KH = src.shape[2]
-        L.check(self.lib.dl_pack_weights(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), _stream()), 'dl_pack_weights')
+        self.check(self.lib.dl_pack_weights(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), _stream()), 'dl_pack_weights')
 
     def pack_batch_build(self, jobs):
         """jobs: [(PackedWeights, fp32 master weight)] -> device table of dl_pack_job records (built once, see dl_pack_weights_batch)"""
@@ -230,20 +263,20 @@ class HipBackend:
             assert src.dtype == torch.float32 and src.is_contiguous()
             d = fill_pack_desc(packed.plan, src.shape[0], src.shape[1], src.shape[2])
             d.KH = src.shape[2]
-            L.check(self.lib.dl_pack_job_fill(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), C.c_void_p(base + i * jb)),
+            self.check(self.lib.dl_pack_job_fill(C.byref(d), _ptr(src), _ptr(packed.hi), _ptr(packed.lo), C.c_void_p(base + i * jb)),
                     'dl_pack_job_fill')
         nblocks = int(self.lib.dl_pack_batch_blocks(C.c_void_p(base), len(jobs), None))
         if nblocks < 0:
-            L.check(nblocks, 'dl_pack_batch_blocks')
+            self.check(nblocks, 'dl_pack_batch_blocks')
         tab = (C.c_int32 * (2 * max(nblocks, 1)))()
-        L.check(min(int(self.lib.dl_pack_batch_blocks(C.c_void_p(base), len(jobs), C.c_void_p(C.addressof(tab)))), 0), 'dl_pack_batch_blocks')
+        self.check(min(int(self.lib.dl_pack_batch_blocks(C.c_void_p(base), len(jobs), C.c_void_p(C.addressof(tab)))), 0), 'dl_pack_batch_blocks')
         dev = jobs[0][1].device
         return (torch.frombuffer(host, dtype=torch.uint8).clone().to(dev), torch.frombuffer(tab, dtype=torch.int32).clone().to(dev), nblocks)
 
     def pack_batch_run(self, table, count: int):
         jobs_dev, tab_dev, nblocks = table
         _need_cuda(jobs_dev, tab_dev)
-        L.check(self.lib.dl_pack_weights_batch(_ptr(jobs_dev), _ptr(tab_dev), nblocks, _stream()), 'dl_pack_weights_batch')
+        self.check(self.lib.dl_pack_weights_batch(_ptr(jobs_dev), _ptr(tab_dev), nblocks, _stream()), 'dl_pack_weights_batch')
 
     # ---- convolution forward / data-gradient (gather GEMM)
     def conv_forward(self, packed: PackedWeights, x: torch.Tensor, out: torch.Tensor, hq: int, wq: int, bias: Optional[torch.Tensor],
@@ -263,7 +296,7 @@ class HipBackend:
             _, ho, wo, cop = out.shape
             assert out.dtype == torch.float32 and out.is_contiguous()
             d = fill_conv_desc(plan, n, hi, wi, pstride(x), ho, wo, cop, cop, hq, wq, dl_dtype(x), prec, L.ACT_NONE, in_act, 0, 1, 1)
-            L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), None, None, _ptr(out), None, _stream()),
+            self.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), None, None, _ptr(out), None, _stream()),
                     'dl_conv_forward(raw)')
             return 0
         plan = packed.plan
@@ -305,11 +338,11 @@ class HipBackend:
                 WS.bump_norm_token()
                 b = L.ConvBnStats(by.data_ptr(), pstride(by), bact, bstats[0].data_ptr(), bstats[1].data_ptr(), bstats[2].data_ptr(),
                                   bstats[3].data_ptr())
-                L.check(self.lib.dl_conv_forward_bnstats(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(out), _ptr(part),
+                self.check(self.lib.dl_conv_forward_bnstats(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(out), _ptr(part),
                                                          C.byref(b), _stream()), 'dl_conv_forward_bnstats')
                 return nch
             nch = 0
-        L.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
+        self.check(self.lib.dl_conv_forward(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(bias), _ptr(out), _ptr(slab),
                                          _ptr(part), _stream()), 'dl_conv_forward')
         return nch
 
@@ -326,7 +359,7 @@ class HipBackend:
         if not self.lib.dl_conv_add_supported(C.byref(d)):
             return False
         self._last_conv_desc = d
-        L.check(self.lib.dl_conv_forward_add(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(addend), pstride(addend), _ptr(out), _stream()),
+        self.check(self.lib.dl_conv_forward_add(C.byref(d), _ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(addend), pstride(addend), _ptr(out), _stream()),
                 'dl_conv_forward_add')
         return True
 
@@ -361,7 +394,7 @@ class HipBackend:
         tiles, ksteps, kname = L.i32(), L.i32(), C.c_char_p()
         multi = int(self.lib.dl_wgrad_plan(C.byref(d), C.byref(tiles), C.byref(ksteps), C.byref(kname)))
         if multi < 0:
-            L.check(multi, 'dl_wgrad_plan')
+            self.check(multi, 'dl_wgrad_plan')
         w4 = kname.value == b'wgrad_w4_kernel'
         deferring = _WGRAD_DEFER and WS._thread_state().get('defer_depth', 0) > 0
         # batched: the w4 kernel's layers only.  Measured r05 (profiles/r05/wgrad_first_look.txt, 18 layers): bf16 w4 129.6 -> 114.3 us per layer; the strict
@@ -382,7 +415,7 @@ class HipBackend:
             self._wgrad_deferred(WS._state(), d, P, Q, grad, nslab)
             return
         slab = WS.get('wgrad_slab', nslab, P.device)
-        L.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
+        self.check(self.lib.dl_conv_wgrad(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), _stream()), 'dl_conv_wgrad')
 
     # ---- deferred slab reduction (include/deepliif_hip.h: dl_conv_wgrad_slabs / dl_wgrad_reduce_batch)
     # Inside Tape.backward() every general-path weight gradient only writes its split-K slabs, each into its own region of a per-thread arena;
@@ -468,7 +501,7 @@ class HipBackend:
                 Ps, Qs, Gs = arr(*[it[2].data_ptr() for it in chunk]), arr(*[it[3].data_ptr() for it in chunk]), arr(*[it[4].data_ptr() for it in chunk])
                 ents = (L.WgradReduceEntry * n)()
                 _LAUNCH.dev = chunk[0][2].device
-                L.check(self.lib.dl_conv_wgrad_multi(C.byref(d), n, Ps, Qs, Gs, _ptr(slab), ents, _stream()), 'dl_conv_wgrad_multi')
+                self.check(self.lib.dl_conv_wgrad_multi(C.byref(d), n, Ps, Qs, Gs, _ptr(slab), ents, _stream()), 'dl_conv_wgrad_multi')
                 pend = st.setdefault('defer_pending', [])
                 for l in range(n):
                     e = L.WgradReduceEntry.from_buffer_copy(ents[l])
@@ -483,7 +516,7 @@ class HipBackend:
             self.wgrad_flush()
         slab = self._arena_region(st, need, P.device)
         e = L.WgradReduceEntry()
-        L.check(self.lib.dl_conv_wgrad_slabs(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), C.byref(e), _stream()), 'dl_conv_wgrad_slabs')
+        self.check(self.lib.dl_conv_wgrad_slabs(C.byref(d), _ptr(P), _ptr(Q), _ptr(grad), _ptr(slab), C.byref(e), _stream()), 'dl_conv_wgrad_slabs')
         e.block0 = st.get('defer_blocks', 0)
         st['defer_blocks'] = e.block0 + e.nblocks
         st['defer_grads'].add(gp)
@@ -516,7 +549,7 @@ class HipBackend:
         total = st['defer_blocks']
         st['defer_pending'], st['defer_blocks'], st['defer_off'] = [], 0, 0
         _LAUNCH.dev = arena.device
-        L.check(self.lib.dl_wgrad_reduce_batch(_ptr(dev_tab), len(pend), total, _stream()), 'dl_wgrad_reduce_batch')
+        self.check(self.lib.dl_wgrad_reduce_batch(_ptr(dev_tab), len(pend), total, _stream()), 'dl_wgrad_reduce_batch')
 
     supports_split = os.environ.get('DL_NO_SPLIT_COPY') is None          # A/B switch: DL_NO_SPLIT_COPY=1 keeps every hi / lo split inside the conv kernels
 
@@ -559,7 +592,7 @@ class HipBackend:
             WS.bump_norm_token()            # the stand-alone statistics pass overwrites the shared workspace
         stats = torch.empty(4, y.shape[0], y.shape[3], dtype=torch.float32, device=y.device)   # mean, rstd, scale, shift
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
-        L.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+        self.check(self.lib.dl_norm_forward(C.byref(d), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                          _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(z) if store_z else None,
                                          _ptr(ws), _ptr(z_split), _stream()), 'dl_norm_forward')
         return stats
@@ -574,7 +607,7 @@ class HipBackend:
         d.ext_nchunks = ext_nchunks
         WS.bump_norm_token()
         ws = WS.get('norm_ws', self.lib.dl_norm_ws_floats(C.byref(d)), y.device)
-        L.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
+        self.check(self.lib.dl_norm_backward(C.byref(d), _ptr(dz), _ptr(y), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
                                           _ptr(stats[3]), _ptr(dy) if store_dy else None, _ptr(dgamma), _ptr(dbeta), 1, _ptr(dy_chansum), _ptr(ws), _ptr(dy_split),
                                           _stream()),
                 'dl_norm_backward')
@@ -583,65 +616,65 @@ class HipBackend:
     def act_forward(self, act, x, y):
         _need_cuda(x, y)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
-        L.check(self.lib.dl_act_forward(act, dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], _stream()), 'dl_act_forward')
+        self.check(self.lib.dl_act_forward(act, dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], _stream()), 'dl_act_forward')
 
     def act_backward(self, act, dy, y, dx):
         _need_cuda(dy, y, dx)
         npix = y.shape[0] * y.shape[1] * y.shape[2]
-        L.check(self.lib.dl_act_backward(act, dl_dtype(y), _ptr(dy), pstride(dy), _ptr(y), pstride(y), _ptr(dx), pstride(dx), npix,
+        self.check(self.lib.dl_act_backward(act, dl_dtype(y), _ptr(dy), pstride(dy), _ptr(y), pstride(y), _ptr(dx), pstride(dx), npix,
                                          y.shape[3], _stream()), 'dl_act_backward')
 
     def dropout(self, x, y, p, seed):
         _need_cuda(x, y)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
-        L.check(self.lib.dl_dropout(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], float(p), int(seed) & (2 ** 64 - 1),
+        self.check(self.lib.dl_dropout(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), npix, x.shape[3], float(p), int(seed) & (2 ** 64 - 1),
                                     _stream()), 'dl_dropout')
 
     def axpby(self, alpha, a, beta, b, out):
         _need_cuda(a, b, out)
         npix = a.shape[0] * a.shape[1] * a.shape[2]
-        L.check(self.lib.dl_axpby(dl_dtype(a), float(alpha), _ptr(a), pstride(a), float(beta), _ptr(b), pstride(b) if b is not None else 8,
+        self.check(self.lib.dl_axpby(dl_dtype(a), float(alpha), _ptr(a), pstride(a), float(beta), _ptr(b), pstride(b) if b is not None else 8,
                                   _ptr(out), pstride(out), npix, a.shape[3], _stream()), 'dl_axpby')
 
     def gate_forward(self, x, psi, out):
         """out = x * psi[..., :1] (attention gate, att_unet.py:108-115)"""
         _need_cuda(x, psi, out)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
-        L.check(self.lib.dl_gate_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(out), pstride(out), npix, x.shape[3], _stream()),
+        self.check(self.lib.dl_gate_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(out), pstride(out), npix, x.shape[3], _stream()),
                 'dl_gate_forward')
 
     def gate_backward(self, g, x, psi, dx, dpsi):
         """dx = g * psi[..., :1] (dx may be None); dpsi[..., 0] = sum_c g * x, dpsi[..., 1:] = 0"""
         _need_cuda(g, x, psi, dx, dpsi)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
-        L.check(self.lib.dl_gate_backward(dl_dtype(x), _ptr(g), pstride(g), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(dx),
+        self.check(self.lib.dl_gate_backward(dl_dtype(x), _ptr(g), pstride(g), _ptr(x), pstride(x), _ptr(psi), pstride(psi), _ptr(dx),
                                           pstride(dx) if dx is not None else 8, _ptr(dpsi), pstride(dpsi), npix, x.shape[3], _stream()), 'dl_gate_backward')
 
     def copy_channels(self, src, s_c0, dst, d_c0, nch, accumulate=False):
         _need_cuda(src, dst)
         npix = src.shape[0] * src.shape[1] * src.shape[2]
-        L.check(self.lib.dl_copy_channels(dl_dtype(src), _ptr(src), pstride(src), s_c0, _ptr(dst), pstride(dst), d_c0, npix, nch,
+        self.check(self.lib.dl_copy_channels(dl_dtype(src), _ptr(src), pstride(src), s_c0, _ptr(dst), pstride(dst), d_c0, npix, nch,
                                           1 if accumulate else 0, _stream()), 'dl_copy_channels')
 
     def channel_sum(self, x, C_real, out, accumulate):
         _need_cuda(x, out)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         ws = WS.get('csum_ws', 256 * x.shape[3], x.device)
-        L.check(self.lib.dl_channel_sum(dl_dtype(x), _ptr(x), pstride(x), npix, x.shape[3], C_real, _ptr(out), 1 if accumulate else 0,
+        self.check(self.lib.dl_channel_sum(dl_dtype(x), _ptr(x), pstride(x), npix, x.shape[3], C_real, _ptr(out), 1 if accumulate else 0,
                                         _ptr(ws), _stream()), 'dl_channel_sum')
 
     def nchw_to_nhwc(self, src, dst, c0, zero_pad_to):
         _need_cuda(src, dst)
         assert src.dtype == torch.float32 and src.is_contiguous()
         n, c, h, w = src.shape
-        L.check(self.lib.dl_nchw_to_nhwc(_ptr(src), n, c, h, w, dl_dtype(dst), _ptr(dst), pstride(dst), c0, zero_pad_to, _stream()),
+        self.check(self.lib.dl_nchw_to_nhwc(_ptr(src), n, c, h, w, dl_dtype(dst), _ptr(dst), pstride(dst), c0, zero_pad_to, _stream()),
                 'dl_nchw_to_nhwc')
 
     def nhwc_to_nchw(self, src, c0, dst):
         _need_cuda(src, dst)
         assert dst.dtype == torch.float32 and dst.is_contiguous()
         n, c, h, w = dst.shape
-        L.check(self.lib.dl_nhwc_to_nchw(dl_dtype(src), _ptr(src), pstride(src), c0, _ptr(dst), n, c, h, w, _stream()), 'dl_nhwc_to_nchw')
+        self.check(self.lib.dl_nhwc_to_nchw(dl_dtype(src), _ptr(src), pstride(src), c0, _ptr(dst), n, c, h, w, _stream()), 'dl_nhwc_to_nchw')
 
     # ---- narrow-Cout forward in one kernel (rolling input rows, csrc/conv_small.hip)
     def conv_narrow_supported(self, x, cin_p, cout, k, pad, pad_mode, act=L.ACT_NONE) -> bool:
@@ -652,10 +685,10 @@ class HipBackend:
         n, h, w, cp = x.shape
         if x.dtype == torch.float32:            # strict policy: fp32 rows split while the fragments are read, hi weights in registers, lo weights in LDS
             assert packed.lo is not None and out.dtype == torch.float32
-            L.check(self.lib.dl_conv_narrow_forward_x3(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), _ptr(packed.lo), packed.plan.kstride, cout, k, k, pad,
+            self.check(self.lib.dl_conv_narrow_forward_x3(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), _ptr(packed.lo), packed.plan.kstride, cout, k, k, pad,
                                                        _ptr(bias), act, _ptr(out), pstride(out), out.shape[3], _stream()), 'dl_conv_narrow_forward_x3')
             return
-        L.check(self.lib.dl_conv_narrow_forward(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), packed.plan.kstride, cout, k, k, pad, _ptr(bias), act,
+        self.check(self.lib.dl_conv_narrow_forward(_ptr(x), n, h, w, cp, pstride(x), _ptr(packed.hi), packed.plan.kstride, cout, k, k, pad, _ptr(bias), act,
                                                 _ptr(out), pstride(out), out.shape[3], _stream()), 'dl_conv_narrow_forward')
 
     # ---- narrow-Cout helpers
@@ -663,7 +696,7 @@ class HipBackend:
         _need_cuda(T, out, bias)
         n, h, w, tc = T.shape
         assert T.dtype == torch.float32 and T.is_contiguous()
-        L.check(self.lib.dl_shift_sum(_ptr(T), n, h, w, tc, cout, kw, pad, pad_mode, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out),
+        self.check(self.lib.dl_shift_sum(_ptr(T), n, h, w, tc, cout, kw, pad, pad_mode, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out),
                                       out.shape[3], _stream()), 'dl_shift_sum')
 
     def convt4_gather(self, T, cout, bias, act, out):
@@ -671,14 +704,14 @@ class HipBackend:
         _need_cuda(T, out, bias)
         n, h, w, tc = T.shape
         assert T.dtype == torch.float32 and T.is_contiguous() and tuple(out.shape[:3]) == (n, 2 * h, 2 * w)
-        L.check(self.lib.dl_convt4_gather(_ptr(T), n, h, w, tc, cout, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out), out.shape[3], _stream()),
+        self.check(self.lib.dl_convt4_gather(_ptr(T), n, h, w, tc, cout, _ptr(bias), act, dl_dtype(out), _ptr(out), pstride(out), out.shape[3], _stream()),
                 'dl_convt4_gather')
 
     def shift_stack(self, dy, cout, kw, pad, D):
         _need_cuda(dy, D)
         n, h, w, _ = dy.shape
         assert D.is_contiguous() and D.dtype == dy.dtype
-        L.check(self.lib.dl_shift_stack(dl_dtype(dy), _ptr(dy), pstride(dy), n, h, w, cout, kw, pad, L.PAD_ZERO, _ptr(D), D.shape[3], _stream()),
+        self.check(self.lib.dl_shift_stack(dl_dtype(dy), _ptr(dy), pstride(dy), n, h, w, cout, kw, pad, L.PAD_ZERO, _ptr(D), D.shape[3], _stream()),
                 'dl_shift_stack')
 
     def reflect_fold(self, src, dst, pad):
@@ -686,7 +719,7 @@ class HipBackend:
         _need_cuda(src, dst)
         n, h, w, cp = dst.shape
         assert src.shape == (n, h + 2 * pad, w + 2 * pad, cp) and src.dtype == dst.dtype
-        L.check(self.lib.dl_reflect_fold(dl_dtype(src), _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, pad, cp, _stream()), 'dl_reflect_fold')
+        self.check(self.lib.dl_reflect_fold(dl_dtype(src), _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, pad, cp, _stream()), 'dl_reflect_fold')
 
     # ---- tiles: uint8 [H, W, 3] images <-> engine tile batches (crop + transform, is_empty statistic, tensor2im + stitch)
     def tile_gather(self, images, H0, W0, origins, tile, pad, pad_rgb, lut, out):
@@ -695,13 +728,13 @@ class HipBackend:
         n = len(images)
         ptrs = (C.c_void_p * n)(*[im.data_ptr() for im in images])
         strides = (C.c_int64 * n)(*[im.stride(0) for im in images])
-        L.check(self.lib.dl_tile_gather_u8(ptrs, strides, n, H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(lut), dl_dtype(out),
+        self.check(self.lib.dl_tile_gather_u8(ptrs, strides, n, H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(lut), dl_dtype(out),
                                            _ptr(out), pstride(out), out.shape[3], _stream(out)), 'dl_tile_gather_u8')
 
     def tile_gray_stats(self, image, H0, W0, origins, tile, pad, pad_rgb, stats):
         _need_cuda(image, origins, stats)
         assert stats.dtype == torch.int64 and stats.is_contiguous() and stats.shape == (origins.shape[0], 3)
-        L.check(self.lib.dl_tile_gray_stats_u8(_ptr(image), image.stride(0), H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(stats),
+        self.check(self.lib.dl_tile_gray_stats_u8(_ptr(image), image.stride(0), H0, W0, _ptr(origins), origins.shape[0], tile, pad, pad_rgb, _ptr(stats),
                                                _stream(image)), 'dl_tile_gray_stats_u8')
 
     def tile_paste(self, tiles, tile, rects, dst):
@@ -712,7 +745,7 @@ class HipBackend:
             dt, tp, ps = L.DL_F32, None, 8
         else:
             dt, tp, ps = dl_dtype(tiles), _ptr(tiles), pstride(tiles)
-        L.check(self.lib.dl_tile_paste_u8(dt, tp, ps, tile, _ptr(rects), rects.shape[0], _ptr(dst), dst.stride(0), _stream(dst)), 'dl_tile_paste_u8')
+        self.check(self.lib.dl_tile_paste_u8(dt, tp, ps, tile, _ptr(rects), rects.shape[0], _ptr(dst), dst.stride(0), _stream(dst)), 'dl_tile_paste_u8')
 
     # ---- losses
     def loss(self, kind, x, target, target_const, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
@@ -720,7 +753,7 @@ class HipBackend:
         _need_cuda(x, target, loss_out, grad)
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         ws = WS.get('loss_ws', self.lib.dl_loss_ws_floats(), x.device)
-        L.check(self.lib.dl_loss_acc(kind, dl_dtype(x), _ptr(x), pstride(x), _ptr(target), pstride(target) if target is not None else 8,
+        self.check(self.lib.dl_loss_acc(kind, dl_dtype(x), _ptr(x), pstride(x), _ptr(target), pstride(target) if target is not None else 8,
                                      float(target_const), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale), 1 if accumulate else 0, _ptr(grad),
                                      pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_loss_acc')
 
@@ -731,7 +764,7 @@ class HipBackend:
         n, h, w, cp = small.shape
         big = src if backward else dst
         assert tuple(big.shape) == (n, 2 * h, 2 * w, cp), (big.shape, small.shape)
-        L.check(self.lib.dl_upsample2_nearest(dl_dtype(src), 1 if backward else 0, _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, cp, _stream()),
+        self.check(self.lib.dl_upsample2_nearest(dl_dtype(src), 1 if backward else 0, _ptr(src), pstride(src), _ptr(dst), pstride(dst), n, h, w, cp, _stream()),
                 'dl_upsample2_nearest')
 
     def kldiv(self, x, t, C_real, loss_out, grad, grad_scale, out_scale=1.0, accumulate=False):
@@ -740,7 +773,7 @@ class HipBackend:
         assert x.shape == t.shape and x.dtype == t.dtype
         npix = x.shape[0] * x.shape[1] * x.shape[2]
         ws = WS.get('kldiv_ws', self.lib.dl_kldiv_ws_floats(), x.device)
-        L.check(self.lib.dl_kldiv(dl_dtype(x), _ptr(x), pstride(x), _ptr(t), pstride(t), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale),
+        self.check(self.lib.dl_kldiv(dl_dtype(x), _ptr(x), pstride(x), _ptr(t), pstride(t), npix, C_real, x.shape[3], _ptr(loss_out), float(out_scale),
                                   1 if accumulate else 0, _ptr(grad), pstride(grad) if grad is not None else 8, float(grad_scale), _ptr(ws), _stream()), 'dl_kldiv')
 
     # ---- 2x2 max pooling (VGG19 features)
@@ -748,36 +781,41 @@ class HipBackend:
         _need_cuda(x, y)
         n, h, w, cp = x.shape
         assert tuple(y.shape) == (n, h // 2, w // 2, cp)
-        L.check(self.lib.dl_maxpool2_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), n, h, w, cp, _stream()), 'dl_maxpool2_forward')
+        self.check(self.lib.dl_maxpool2_forward(dl_dtype(x), _ptr(x), pstride(x), _ptr(y), pstride(y), n, h, w, cp, _stream()), 'dl_maxpool2_forward')
 
     def maxpool2_backward(self, x, dy, dx):
         _need_cuda(x, dy, dx)
         n, h, w, cp = x.shape
-        L.check(self.lib.dl_maxpool2_backward(dl_dtype(x), _ptr(x), pstride(x), _ptr(dy), pstride(dy), _ptr(dx), pstride(dx), n, h, w, cp, _stream()),
+        self.check(self.lib.dl_maxpool2_backward(dl_dtype(x), _ptr(x), pstride(x), _ptr(dy), pstride(dy), _ptr(dx), pstride(dx), n, h, w, cp, _stream()),
                 'dl_maxpool2_backward')
 
     # ---- optimiser
     def adam_step(self, p, g, m, v, lr, b1, b2, eps, step, gscale):
         _need_cuda(p, g, m, v)
-        L.check(self.lib.dl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+        self.check(self.lib.dl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
                                       float(gscale), _stream()), 'dl_adam_step')
 
 
     def adam_hyper(self, lr, b1, b2, eps, step, gscale, hyper_host: torch.Tensor):
         """fill the (pinned) host tensor with the scalars dl_adam_step would use at this step (graph mode, optim.FusedAdam.prepare_step)"""
         assert hyper_host.device.type == 'cpu' and hyper_host.dtype == torch.float32 and hyper_host.numel() >= 8
-        L.check(self.lib.dl_adam_hyper(float(lr), float(b1), float(b2), float(eps), int(step), float(gscale), C.c_void_p(hyper_host.data_ptr())), 'dl_adam_hyper')
+        self.check(self.lib.dl_adam_hyper(float(lr), float(b1), float(b2), float(eps), int(step), float(gscale), C.c_void_p(hyper_host.data_ptr())), 'dl_adam_hyper')
 
     def adam_step_dev(self, p, g, m, v, hyper_dev):
         _need_cuda(p, g, m, v, hyper_dev)
-        L.check(self.lib.dl_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), 'dl_adam_step_dev')
+        self.check(self.lib.dl_adam_step_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), 'dl_adam_step_dev')
 
 
-_impl = None
+_impl = None          # the bf16 backend (tests replace it with the CPU emulation, which serves both formats)
+_impl_f16 = None
 
 
 def impl():
-    global _impl
+    global _impl, _impl_f16
+    if half_format() == 'fp16' and not getattr(_impl, 'emulates_any_half', False):
+        if _impl_f16 is None:
+            _impl_f16 = HipBackend('fp16')        # raises if libdeepliif_hip_f16.so is missing
+        return _impl_f16
     if _impl is None:
         _impl = HipBackend()        # raises if the .so is missing
     return _impl

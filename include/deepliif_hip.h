@@ -18,6 +18,12 @@
  *   precision    DL_PREC_BF16  : one bf16 MFMA pass, fp32 accumulate.
  *                DL_PREC_BF16X3: operands split a = hi + lo (two bf16), three MFMA passes (hi*hi + hi*lo + lo*hi),
  *                                fp32-class accuracy (~2^-16 relative per product); activations are stored fp32.
+ *
+ * Two libraries, one ABI.  libdeepliif_hip.so uses bfloat16 as its 16-bit type (training and inference).  libdeepliif_hip_f16.so is the SAME sources
+ * compiled with -DDL_H16_FP16: every DL_BF16 tensor, every packed weight image and every MFMA operand is IEEE half instead (11 significand bits
+ * instead of 8 at the same matrix rate: 7x nearer to the fp32 reference on a generator's forward).  It is for INFERENCE: the gradients of this model sit
+ * below half's normal range, so the host side refuses to build a training model on it (deepliif_amd/engine.py, Precision 'fp16').  Same symbols, same
+ * structs, same switches; dl_half_format() tells the two apart.
  */
 #ifndef DEEPLIIF_HIP_H
 #define DEEPLIIF_HIP_H
@@ -29,9 +35,10 @@
 extern "C" {
 #endif
 
-#define DL_VERSION 113
+#define DL_VERSION 114
 
-enum { DL_F32 = 0, DL_BF16 = 1 };
+enum { DL_F32 = 0, DL_BF16 = 1 };           /* DL_BF16 = "the 16-bit type of this library": bfloat16, or IEEE half in libdeepliif_hip_f16.so (below) */
+enum { DL_HALF_BF16 = 0, DL_HALF_FP16 = 1 };   /* dl_half_format() */
 enum { DL_PREC_BF16 = 1, DL_PREC_BF16X3 = 3 };
 enum { DL_ACT_NONE = 0, DL_ACT_RELU = 1, DL_ACT_LRELU = 2, DL_ACT_TANH = 3,       /* LRELU slope 0.2 (networks.py:578,639) */
        DL_ACT_SIGMOID = 4 };   /* nn.Sigmoid of the attention gate (att_unet.py:100-104): elementwise entry points only (dl_act_forward / _backward) */
@@ -68,6 +75,7 @@ const char *dl_last_error(void);
 int dl_switch_count(void);
 const char *dl_switch_name(int id);          /* 0 <= id < dl_switch_count() */
 void dl_switches_reload(void);
+int dl_half_format(void);                    /* DL_HALF_BF16: libdeepliif_hip.so; DL_HALF_FP16: libdeepliif_hip_f16.so */
 int dl_dev_build(void);                      /* 1: compiled with -DDL_DEV_SWITCHES (A/B variants and timing-only ablations reachable); 0: the shipped library */
 /* number of bytes of fp32 scratch a call needs; see each function */
 

@@ -53,6 +53,8 @@ def _gather(x, hq, wq, step, dh, dw, reflect):
 
 
 class FakeBackend:
+    emulates_any_half = True        # storage rounding follows the tensors' dtype (bf16 or fp16): ops.impl() returns this object in either half mode
+
     def __init__(self):
         self.calls = {}
 

@@ -19,22 +19,35 @@ def declared_symbols():
     return sorted(set(re.findall(r'\b(dl_[a-z0-9_]+)\s*\(', src)))
 
 
-def test_library_exports_every_declared_symbol():
-    lib = L.load()
+@pytest.mark.parametrize('half', ['bf16', 'fp16'])
+def test_library_exports_every_declared_symbol(half):
+    """both builds of the sources: libdeepliif_hip.so (bfloat16) and libdeepliif_hip_f16.so (IEEE half, the fp16 inference policy) -- one ABI"""
+    lib = L.load(half)
     names = declared_symbols()
     assert len(names) >= 19
     for n in names:
-        assert hasattr(lib, n), f'{n} is declared in include/deepliif_hip.h but not exported by libdeepliif_hip.so'
+        assert hasattr(lib, n), f'{n} is declared in include/deepliif_hip.h but not exported by the {half} library'
         assert n in L.SIGNATURES, f'{n} has no ctypes signature in deepliif_amd/_lib.py'
     assert lib.dl_version() == L.DL_VERSION
+    assert lib.dl_half_format() == (L.HALF_FP16 if half == 'fp16' else L.HALF_BF16)
     assert isinstance(lib.dl_last_error(), bytes)
 
 
-def test_shipped_library_has_no_result_changing_switches():
+def test_a_library_of_the_wrong_format_is_refused(monkeypatch):
+    monkeypatch.setattr(L, 'LIB_PATH_F16', L.LIB_PATH)
+    monkeypatch.setattr(L, '_libs', {})
+    with pytest.raises(L.HipLibraryError, match='other 16-bit format'):
+        L.load('fp16')
+    with pytest.raises(ValueError):
+        L.load('fp8')
+
+
+@pytest.mark.parametrize('half', ['bf16', 'fp16'])
+def test_shipped_library_has_no_result_changing_switches(half):
     """the default build carries no timing-only ablation (results wrong by construction) and no getenv on a launch path -- the only
     environment variables it knows are the nine documented A/B switches of include/deepliif_hip.h, copied once at load time."""
-    lib = L.load()
-    if os.environ.get('DEEPLIIF_AMD_LIB'):
+    lib = L.load(half)
+    if os.environ.get('DEEPLIIF_AMD_LIB') or os.environ.get('DEEPLIIF_AMD_LIB_F16'):
         pytest.skip('a non-default library was selected')
     assert lib.dl_dev_build() == 0
     names = [lib.dl_switch_name(i).decode() for i in range(lib.dl_switch_count())]
@@ -42,7 +55,7 @@ def test_shipped_library_has_no_result_changing_switches():
     header = open(HEADER).read()
     for n in names:
         assert n in header, f'{n} is not documented in include/deepliif_hip.h'
-    blob = open(L.LIB_PATH, 'rb').read()
+    blob = open(L.LIB_PATH if half == 'bf16' else L.LIB_PATH_F16, 'rb').read()
     found = sorted(set(m.decode() for m in re.findall(rb'DL_[A-Z0-9_]{3,}', blob)))
     assert not [f for f in found if 'ABL' in f], found           # DL_CONV_ABLATE, DL_W4_ABLATE, DL_C4_ABL ... are gone
     assert sorted(f for f in found if f in names) == sorted(names)

@@ -1,0 +1,261 @@
+"""GPU parity of the fp16 INFERENCE policy (engine.Precision 'fp16' -> libdeepliif_hip_f16.so: the library's sources compiled with IEEE half as the
+16-bit storage and MFMA operand type, csrc/common.h "the library's 16-bit format").
+
+  * kernel by kernel: one shape per forward kernel family of the generators, through the C ABI of the f16 library, against the CPU formula emulation on
+    float16 tensors (tests/fake_backend.py) -- with the dispatch asserted, so that the fast kernels (not a fallback) are what is checked;
+  * network by network at fixture size and at the sizes BASELINE.json names (ngf 64, 512 x 512), against the CPU fp32 oracle: the fp16 policy must be
+    several times nearer to the oracle than the bf16 policy on the same weights and inputs (that is its reason to exist), and inside a fixed bound;
+  * the benched inference shape (batch 8, per-sample statistics) through the public surface (net(x) with set_precision('fp16'));
+  * the guards: no tape / no training model on fp16, no tensor of the other 16-bit format into a library.
+Measured errors go to gpurun_out/parity_errors_fp16.json (copied to profiles/r06/)."""
+import ctypes as C
+import json
+import os
+import types
+
+import pytest
+import torch
+
+import fake_backend
+from deepliif_amd import _lib as L
+from deepliif_amd import engine as E
+from deepliif_amd import networks as N
+from deepliif_amd import ops
+from deepliif_amd.engine import Precision
+from deepliif_amd.geometry import ConvSpec, cpad, fill_conv_desc
+from golden_util import seeded_uniform
+from oracle import deepliif_oracle as O
+
+from test_gpu_kernels import _run_conv
+
+pytestmark = pytest.mark.gpu
+DRY = os.environ.get('DL_TEST_DRYRUN') == '1'         # host plumbing on the CPU emulation (no GPU): python -m pytest tests/test_gpu_fp16.py -m gpu with DL_TEST_DRYRUN=1
+DEV = 'cpu' if DRY else 'cuda'
+ERRLOG = {}
+FP16 = Precision.get('fp16')
+KERNEL_TOL = 8e-4            # fp16 storage of the result: 2^-11 relative to the value, judged relative to the tensor's maximum (bf16: 6e-3, test_gpu_kernels.tol)
+
+
+@pytest.fixture(autouse=True)
+def _real_backend():
+    ops._impl = fake_backend.FakeBackend() if DRY else None
+    yield
+    ops._impl = None
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/parity_errors_fp16.json', 'w') as f:
+        json.dump(ERRLOG, f, indent=1, sort_keys=True)
+
+
+def sync():
+    if not DRY:
+        torch.cuda.synchronize()
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd16(shape, seed, scale=1.0):
+    """values exactly representable in half: packing / staging them is then exact and the test sees the kernel's arithmetic only"""
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).half().float()
+
+
+@pytest.mark.skipif(DRY, reason='needs the libraries on a GPU')
+def test_the_two_libraries_are_told_apart():
+    bf, hf = L.load('bf16'), L.load('fp16')
+    assert bf.dl_half_format() == L.HALF_BF16 and hf.dl_half_format() == L.HALF_FP16
+    assert bf.dl_version() == hf.dl_version() == L.DL_VERSION
+    assert hf.dl_dev_build() == 0
+    with ops.half_mode('fp16'):
+        assert ops.impl().half == 'fp16' and ops.impl().lib is hf
+    assert ops.impl().half == 'bf16' and ops.impl().lib is bf
+
+
+# one shape per forward kernel family of the two generators (ResnetGenerator-9block, UnetGenerator-512): kind, cin, cout, k, stride, pad, out_pad, N, H, W, kernel
+KERNEL_CASES = [
+    ('conv', 256, 256, 3, 1, 1, 0, 4, 128, 128, 'conv_gemm_w4_kernel'),          # ResnetBlock conv at batch 4: 256 tiles
+    ('conv', 64, 128, 3, 2, 1, 0, 2, 64, 256, 'conv_s2d_kernel'),                # down1
+    ('convT', 128, 64, 3, 2, 1, 1, 2, 16, 64, 'conv_s2u_kernel'),                # up2
+    ('convT', 256, 128, 3, 2, 1, 1, 4, 128, 128, 'conv_s2f_kernel'),             # up1 (the kernel's size rule: >= 65536 input pixels)
+    ('conv', 128, 256, 3, 2, 1, 0, 4, 256, 256, 'conv_gemm_8ph_kernel'),         # down2 at 256 tiles
+    ('conv', 3, 64, 7, 1, 3, 0, 1, 64, 64, 'conv_c4_patch_kernel'),              # 7x7 stem
+    ('conv', 128, 256, 4, 2, 1, 0, 2, 64, 64, None),                              # UNet down convolution (gather GEMM, whichever tile the size selects)
+    ('convT', 512, 256, 4, 2, 1, 0, 2, 16, 16, None),                             # UNet up convolution (4-phase gather GEMM)
+]
+
+
+@pytest.mark.parametrize('case', KERNEL_CASES, ids=lambda c: f'{c[0]}{c[1]}-{c[2]}k{c[3]}s{c[4]}')
+def test_forward_kernels_of_the_f16_library_against_the_emulation(case):
+    kind, cin, cout, k, s, p, op, n, H, W_, kernel = case
+    spec = ConvSpec(kind, cin, cout, k, s, p, L.PAD_ZERO, op)
+    wshape = (cout, cin, k, k) if kind == 'conv' else (cin, cout, k, k)
+    w = rnd16(wshape, 1, 0.05)
+    bias = torch.randn((cout,), generator=torch.Generator().manual_seed(2)) * 0.1
+    x = torch.zeros(n, H, W_, cpad(cin))
+    x[..., :cin] = rnd16((n, H, W_, cin), 3)
+    x = x.half()
+    fake = fake_backend.FakeBackend()
+    with ops.half_mode('fp16'):
+        real = ops.impl()
+        assert DRY or real.half == 'fp16'
+        for act in (L.ACT_NONE, L.ACT_RELU):
+            exp = _run_conv(fake, 'fwd', spec, FP16, x, w, bias, act, L.ACT_NONE, H, W_)
+            got = _run_conv(real, 'fwd', spec, FP16, x.to(DEV), w.to(DEV), bias.to(DEV), act, L.ACT_NONE, H, W_, splitk=1 if kernel is not None else None)
+            sync()
+            assert got.dtype == torch.float16
+            if kernel is not None and not DRY:
+                assert real.last_conv_kernel.startswith(kernel), real.last_conv_kernel
+            e = rel(got, exp)
+            ERRLOG[f'kernel/{kind}{cin}-{cout}k{k}s{s}/act{act}'] = e
+            assert e < KERNEL_TOL, (case, act, e, getattr(real, 'last_conv_kernel', ''))
+
+
+def test_norm_and_elementwise_kernels_of_the_f16_library():
+    """norm (partial sums + apply, with residual), activation, axpby, channel copy and the NCHW <-> NHWC seam on half tensors"""
+    fake = fake_backend.FakeBackend()
+    n, h, w, c = 2, 32, 48, 64
+    y = rnd16((n, h, w, c), 11, 3.0).half()
+    r = rnd16((n, h, w, c), 12).half()
+    with ops.half_mode('fp16'):
+        real = ops.impl()
+        for act, res in ((L.ACT_RELU, None), (L.ACT_NONE, r), (L.ACT_LRELU, None)):
+            outs = []
+            for be, dev in ((fake, 'cpu'), (real, DEV)):
+                z = torch.empty((n, h, w, c), dtype=torch.float16, device=dev)
+                be.norm_forward(y.to(dev), z, c, L.NORM_INSTANCE, act, None, None, None, None, 0.1, None if res is None else res.to(dev))
+                outs.append(z.float().cpu())
+            sync()
+            e = rel(outs[1], outs[0])
+            ERRLOG[f'norm/act{act}/res{res is not None}'] = e
+            assert e < 1.5e-3, (act, e)
+        # the seam: fp32 NCHW -> half NHWC -> fp32 NCHW reproduces the half rounding of the input exactly
+        x = seeded_uniform((2, 3, 40, 24), 5)
+        a = E.to_engine(x.to(DEV), FP16)
+        assert a.t.dtype == torch.float16
+        back = E.from_engine(a).cpu()
+        assert torch.equal(back, x.half().float())
+        t = torch.empty_like(a.t)
+        real.act_forward(L.ACT_TANH, a.t, t)
+        sync()
+        assert rel(t[..., :3].float().cpu(), torch.tanh(x.half().float()).permute(0, 2, 3, 1)) < 1e-3
+
+
+SMALL = [
+    ('resnet_9blocks', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
+    ('resnet_9blocks', 3, 16, 'instance', 'zero', (2, 3, 64, 48)),
+    ('resnet_9blocks', 3, 8, 'instance', 'reflect', (2, 3, 40, 24)),
+    ('resnet_9blocks', 3, 8, 'instance', 'zero', (1, 3, 72, 104)),
+    ('unet_32', 3, 8, 'batch', 'zero', (2, 3, 32, 32)),
+    ('unet_64', 9, 8, 'instance', 'zero', (1, 9, 64, 64)),
+    ('unet_512', 3, 8, 'batch', 'zero', (1, 3, 512, 512)),
+]
+
+
+def _forward(net, x, precname, per_sample_norm=False):
+    prec = Precision.get(precname)
+    with ops.half_mode(prec.half):
+        ctx = E.Ctx(prec, None, training=False, per_sample_norm=per_sample_norm)
+        y = E.from_engine(net.run(ctx, E.to_engine(x.to(DEV), prec)))
+    sync()
+    return y
+
+
+@pytest.mark.parametrize('arch,cin,nf,norm,pad,shape', SMALL, ids=lambda v: str(v).replace(' ', ''))
+def test_fixture_size_networks_fp16_against_the_oracle(arch, cin, nf, norm, pad, shape):
+    sd = O.random_state_dict(arch, cin, 3, nf, norm, pad, 4, generator=torch.Generator().manual_seed(5))
+    net = N.define_G(cin, 3, nf, arch, norm, False, 'normal', 0.02, [] if DRY else [0], pad)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = seeded_uniform(shape, 6)
+    with torch.no_grad():
+        exp = O.run_generator(arch, {k: v.clone() for k, v in sd.items()}, x.clone(), norm, pad)
+    e16, ebf = rel(_forward(net, x, 'fp16'), exp), rel(_forward(net, x, 'bf16'), exp)
+    tag = f'small/{arch}-{cin}-{nf}-{norm}-{pad}'
+    ERRLOG[tag + '/fp16'], ERRLOG[tag + '/bf16'] = e16, ebf
+    assert e16 < 1e-2, (e16, ebf)                 # bf16 bound of the same cases: 6e-2 (test_gpu_networks.TOL_OUT)
+    assert e16 < 0.5 * ebf, (e16, ebf)
+    # switching the same net object between the two formats repacks its weights (the packed images' cache key carries the format)
+    again = rel(_forward(net, x, 'fp16'), exp)
+    assert again == e16
+
+
+FULL = [('resnet_9blocks', 3, 'batch'), ('resnet_9blocks', 3, 'instance'), ('unet_512', 3, 'batch'), ('unet_512', 9, 'batch')]
+FULL_TOL = 2.5e-2            # bf16 at these sizes: 1.5e-1 asserted, 8.1e-2 measured (test_gpu_fullsize.TOL)
+
+
+@pytest.mark.parametrize('arch,cin,norm', FULL, ids=lambda v: str(v))
+def test_full_size_forward_fp16_against_the_oracle(arch, cin, norm):
+    sd = O.random_state_dict(arch, cin, 3, 64, norm, 'zero', 4, generator=torch.Generator().manual_seed(21))
+    x = seeded_uniform((1, cin, 512, 512), 22)
+    with torch.no_grad():
+        exp = O.run_generator(arch, {k: v.clone() for k, v in sd.items()}, x.clone(), norm, 'zero')
+    net = N.define_G(cin, 3, 64, arch, norm, False, 'normal', 0.02, [] if DRY else [0], 'zero')
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    e16, ebf = rel(_forward(net, x, 'fp16', True), exp), rel(_forward(net, x, 'bf16', True), exp)
+    ERRLOG[f'fullsize/forward/{arch}-{cin}-{norm}/fp16'], ERRLOG[f'fullsize/forward/{arch}-{cin}-{norm}/bf16'] = e16, ebf
+    assert e16 < FULL_TOL and e16 < 0.35 * ebf, (arch, cin, norm, e16, ebf)
+
+
+def test_batch8_generator_pair_fp16_through_the_public_surface():
+    """G1 -> GS1 at the benched inference shape (8 x 3 x 512 x 512, statistics of each tile) with set_precision('fp16'): net(x) enters the half mode by
+    itself; every tile against the oracle run on that tile alone; the dominant kernel of the batch is the ResnetBlock kernel of the f16 library"""
+    sd_g = O.random_state_dict('resnet_9blocks', 3, 3, 64, 'batch', 'zero', 4, generator=torch.Generator().manual_seed(31))
+    sd_s = O.random_state_dict('unet_512', 3, 3, 64, 'batch', 'zero', 4, generator=torch.Generator().manual_seed(32))
+    x = seeded_uniform((8, 3, 512, 512), 33)
+    x[3] *= 0.05
+    g = N.define_G(3, 3, 64, 'resnet_9blocks', 'batch', False, 'normal', 0.02, [] if DRY else [0], 'zero')
+    s = N.define_G(3, 3, 64, 'unet_512', 'batch', False, 'normal', 0.02, [] if DRY else [0], 'zero')
+    g.load_state_dict(sd_g, strict=True), s.load_state_dict(sd_s, strict=True)
+    g.eval(), s.eval()
+    outs = {}
+    for precname in ('fp16', 'bf16'):
+        g.set_precision(precname), s.set_precision(precname)
+        with torch.no_grad():
+            mid = g(x.to(DEV))
+            outs[precname] = (mid.float().cpu(), s(mid).float().cpu())
+    sync()
+    worst = {'fp16': [0.0, 0.0], 'bf16': [0.0, 0.0]}
+    with torch.no_grad():
+        for i in range(8):
+            m = O.run_generator('resnet_9blocks', {k: v.clone() for k, v in sd_g.items()}, x[i:i + 1].clone(), 'batch', 'zero')
+            o = O.run_generator('unet_512', {k: v.clone() for k, v in sd_s.items()}, m.clone(), 'batch', 'zero')
+            for p in worst:
+                worst[p][0] = max(worst[p][0], rel(outs[p][0][i:i + 1], m))
+                worst[p][1] = max(worst[p][1], rel(outs[p][1][i:i + 1], o))
+    for p in worst:
+        ERRLOG[f'fullsize/batch8_pair/{p}/G1'], ERRLOG[f'fullsize/batch8_pair/{p}/GS1_of_G1'] = worst[p]
+    assert worst['fp16'][0] < FULL_TOL and worst['fp16'][1] < FULL_TOL, worst
+    assert worst['fp16'][0] < 0.35 * worst['bf16'][0], worst
+    # the 8-bit images the reference writes (tensor2im, util.py:38-58): fraction of channel values that differ from the oracle's by more than one level
+    def u8(t):
+        return ((t.clamp(-1, 1) + 1) * 0.5 * 255.0).to(torch.int32)
+    with torch.no_grad():
+        m0 = O.run_generator('resnet_9blocks', {k: v.clone() for k, v in sd_g.items()}, x[0:1].clone(), 'batch', 'zero')
+    for p in ('fp16', 'bf16'):
+        d = (u8(outs[p][0][0:1]) - u8(m0)).abs()
+        ERRLOG[f'fullsize/batch8_pair/{p}/G1_u8_max_levels'] = int(d.max())
+        ERRLOG[f'fullsize/batch8_pair/{p}/G1_u8_fraction_off_by_more_than_1'] = float((d > 1).float().mean())
+
+
+def test_fp16_is_an_inference_policy():
+    if DRY:
+        pytest.skip('guards of the GPU backend')
+    with ops.half_mode('fp16'):
+        with pytest.raises(ValueError, match='inference policy'):
+            E.Ctx(FP16, E.Tape(), training=True)
+    with pytest.raises(RuntimeError, match='half_mode'):
+        E.Ctx(FP16, None, training=False)                      # outside the half mode: the bf16 library would misread the tensors
+    from deepliif_amd import models as M
+    opt = types.SimpleNamespace(precision='fp16', gpu_ids=[0], is_train=True, checkpoints_dir='/tmp', name='x', model='DeepLIIF')
+    with pytest.raises(ValueError, match='inference policy'):
+        M.BaseModel(opt)
+    # a half tensor handed to the bf16 library (and the other way round) is refused before anything is launched
+    a = torch.zeros((1, 8, 8, 8), dtype=torch.float16, device=DEV)
+    b = torch.zeros((1, 8, 8, 8), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.HipLibraryError, match='cannot be mixed'):
+        ops.impl().act_forward(L.ACT_RELU, a, a)
+    with ops.half_mode('fp16'):
+        with pytest.raises(L.HipLibraryError, match='cannot be mixed'):
+            ops.impl().act_forward(L.ACT_RELU, b, b)

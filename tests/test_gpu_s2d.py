@@ -55,7 +55,8 @@ def test_s2d_kernel_against_the_emulation(case):
             exp = _run_conv(fake, 'fwd', spec, prec, x, w, bias, act, L.ACT_NONE, H, W_)
             first = None
             for rep in range(3):         # repeated: a staging race would show up as run-to-run differences
-                got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), bias.to(DEV), act, L.ACT_NONE, H, W_)
+                got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), bias.to(DEV), act, L.ACT_NONE, H, W_, splitk=1)
+                assert DRY or real.last_conv_kernel.startswith('conv_s2d'), real.last_conv_kernel      # (split-K chosen by size would route small cases to the gather GEMM)
                 sync()
                 assert rel(got, exp) < tol(prec), ('fwd', act, rep)
                 if first is None:
@@ -64,7 +65,8 @@ def test_s2d_kernel_against_the_emulation(case):
                     assert torch.equal(got, first), 'run-to-run difference'
         # without a bias (the data-gradient form of the same descriptor)
         exp = _run_conv(fake, 'fwd', spec, prec, x, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
-        got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+        got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_, splitk=1)
+        assert DRY or real.last_conv_kernel.startswith('conv_s2d'), real.last_conv_kernel      # (split-K chosen by size would route small cases to the gather GEMM)
         sync()
         assert rel(got, exp) < tol(prec), 'no bias'
     else:
@@ -76,7 +78,8 @@ def test_s2d_kernel_against_the_emulation(case):
         exp = _run_conv(fake, 'dgrad', spec, prec, dy, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
         first = None
         for rep in range(3):
-            got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+            got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_, splitk=1)
+            assert DRY or real.last_conv_kernel.startswith('conv_s2d'), real.last_conv_kernel      # (split-K chosen by size would route small cases to the gather GEMM)
             sync()
             assert rel(got, exp) < tol(prec), ('dgrad', rep)
             if first is None:
@@ -174,7 +177,8 @@ def test_s2u_kernel_against_the_emulation(case):
             exp = _run_conv(fake, 'fwd', spec, prec, x, w, b, act, L.ACT_NONE, H, W_)
             first = None
             for rep in range(2):
-                got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), act, L.ACT_NONE, H, W_)
+                got = _run_conv(real, 'fwd', spec, prec, x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), act, L.ACT_NONE, H, W_, splitk=1)
+                assert DRY or real.last_conv_kernel.startswith('conv_s2u'), real.last_conv_kernel      # (split-K chosen by size would route small cases to the gather GEMM)
                 sync()
                 assert rel(got, exp) < tol(prec), ('fwd', act, rep)
                 if first is None:
@@ -189,7 +193,8 @@ def test_s2u_kernel_against_the_emulation(case):
         exp = _run_conv(fake, 'dgrad', spec, prec, dy, w, None, L.ACT_NONE, L.ACT_NONE, H, W_)
         first = None
         for rep in range(2):
-            got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_)
+            got = _run_conv(real, 'dgrad', spec, prec, dy.to(DEV), w.to(DEV), None, L.ACT_NONE, L.ACT_NONE, H, W_, splitk=1)
+            assert DRY or real.last_conv_kernel.startswith('conv_s2u'), real.last_conv_kernel      # (split-K chosen by size would route small cases to the gather GEMM)
             sync()
             assert rel(got, exp) < tol(prec), ('dgrad', rep)
             if first is None:
