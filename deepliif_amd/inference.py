@@ -272,7 +272,44 @@ def _wrapper_flags(opt, seg_only, mod_only):
     return seg_only, mod_only
 
 
+# ---- fp16 policy: IEEE half tops out at 65 504.  The forward values of these networks sit orders of magnitude below that (normalised activations), but
+# a checkpoint with unusually large weights could overflow a conv output; the following norm turns the inf into NaN for the rest of the net.  Every fp16 batch
+# therefore ORs "some output holds a NaN" into a device-side flag (no host sync on the launch path); the flag is read -- and the error raised -- where the host
+# waits for the GPU anyway: at the end of infer_region / inference(), in run_dask's PIL path, and at the start of the next run_generators call.
+_FP16_NAN: Dict[torch.device, torch.Tensor] = {}
+
+
+def _fp16_note(res):
+    for a in res.values():
+        t = a.t if isinstance(a, E.Act) else a
+        if t.dtype != torch.float16:
+            continue
+        bad = torch.isnan(t).any()
+        flag = _FP16_NAN.get(t.device)
+        if flag is None:
+            _FP16_NAN[t.device] = bad.clone()
+        else:
+            flag.logical_or_(bad)
+
+
+def fp16_check():
+    """Raise if any fp16 inference batch since the last call produced a NaN (half overflow).  One device-to-host read per device that ran fp16 batches."""
+    for dev, flag in list(_FP16_NAN.items()):
+        del _FP16_NAN[dev]
+        if bool(flag.item()):
+            raise FloatingPointError("precision 'fp16': an output of the generators holds NaN -- a value left IEEE half's range (65 504) inside a network. "
+                                     "Serve this checkpoint with precision='bf16' (same speed, fp32 range) or 'fp32'.")
+
+
 def run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None, per_sample_norm=True) -> 'OrderedDict[str, E.Act]':
+    """_run_generators_engine + the fp16 policy's overflow note (above)"""
+    res = _run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights, per_sample_norm)
+    if x.t.dtype == torch.float16:
+        _fp16_note(res)
+    return res
+
+
+def _run_generators_engine(x: E.Act, nets, opt, seg_only=False, mod_only=False, seg_weights=None, per_sample_norm=True) -> 'OrderedDict[str, E.Act]':
     """The generator DAG of run_dask (deepliif/models/__init__.py:293-388) on a batch of tiles in ENGINE layout, outputs in engine
     layout, keys and key ORDER as the reference's result dict.
       DeepLIIF / DeepLIIFKD (:293-361): G_i(tile); GS_0(tile); GS_i(G_i(tile)); seg = sum_k w_k * seg_k
@@ -392,6 +429,8 @@ def run_generators(ts: torch.Tensor, nets, opt, seg_only=False, mod_only=False, 
     first = next(iter(nets.values()))
     device = next(first.parameters()).device
     prec = E.Precision.get(first.precision)
+    if _FP16_NAN:
+        fp16_check()              # the batches of earlier calls have long finished: no stall
     with ops.half_mode(prec.half):
         x = E.to_engine(ts.to(device), prec)
         return OrderedDict((k, E.from_engine(v)) for k, v in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items())
@@ -416,6 +455,7 @@ def run_dask(img, model_path=None, nets=None, eager_mode=False, opt=None, seg_on
     res = run_generators(ts, nets, opt, seg_only, mod_only, seg_weights)
     if output_tensor:
         return res
+    fp16_check()
     return {k: tensor_to_pil(v) for k, v in res.items()}
 
 
@@ -490,6 +530,7 @@ def infer_region(images, tile_size, overlap_size, nets, opt, seg_only=False, mod
             x = E.Act(tiler.gather(chunk, prec.dtype, cp), 3 * len(images))
             for k, a in run_generators_engine(x, nets, opt, seg_only, mod_only, seg_weights).items():
                 tiler.paste(k, a.t, chunk)
+        fp16_check()
         return tiler.results(), tiler.band
 
 
@@ -657,6 +698,7 @@ def _inference_resampled(origs, tile_size, overlap_size, nets, opt, seg_only, mo
             for i, (t, _) in enumerate(chunk):
                 tile = tensor_to_pil(v[i:i + 1]).resize((tile_size, tile_size))
                 put(k, np.asarray(tile), t)
+    fp16_check()
     return {k: Image.fromarray(v[:h, :w]) for k, v in out.items()}
 
 

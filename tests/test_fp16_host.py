@@ -73,3 +73,22 @@ def test_guards():
         with ops.half_mode('fp8'):
             pass
     assert ops.half_format() == 'bf16'
+
+
+def test_fp16_overflow_is_reported_not_returned():
+    """a NaN in an fp16 result (a value that left half's range inside a net) raises at the next host-side wait instead of reaching the caller's images"""
+    from deepliif_amd import inference as I
+    I._FP16_NAN.clear()
+    ok = E.Act(torch.zeros((1, 4, 4, 8), dtype=torch.float16), 3)
+    I._fp16_note({'G1': ok})
+    I.fp16_check()                                   # clean batch: nothing raised, flag consumed
+    assert not I._FP16_NAN
+    bad = E.Act(torch.zeros((1, 4, 4, 8), dtype=torch.float16), 3)
+    bad.t[0, 1, 2, 0] = float('nan')
+    I._fp16_note({'G1': ok, 'G2': bad})
+    I._fp16_note({'G1': ok})                         # a later clean batch does not clear the flag
+    with pytest.raises(FloatingPointError, match="precision='bf16'"):
+        I.fp16_check()
+    I.fp16_check()                                   # consumed
+    I._fp16_note({'G1': E.Act(torch.full((1, 4, 4, 8), float('nan'), dtype=torch.bfloat16), 3)})      # other policies are not looked at
+    assert not I._FP16_NAN

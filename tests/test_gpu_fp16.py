@@ -259,3 +259,32 @@ def test_fp16_is_an_inference_policy():
     with ops.half_mode('fp16'):
         with pytest.raises(L.HipLibraryError, match='cannot be mixed'):
             ops.impl().act_forward(L.ACT_RELU, b, b)
+
+
+def test_half_overflow_inside_a_net_raises():
+    """weights scaled until a conv output leaves half's range: the NaN that follows is reported by fp16_check() (and by the next run_generators call), the same nets
+    served on bf16 stay finite"""
+    if DRY:
+        pytest.skip('needs the f16 library')
+    from deepliif_amd import inference as I
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_64', input_no=1,
+                                modalities_names=['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], gpu_ids=[0])
+    torch.manual_seed(3)
+    nets = I.build_generators(opt, torch.device('cuda', 0), 'fp16')
+    tiles = seeded_uniform((2, 3, 64, 64), 32).to(DEV)
+    I._FP16_NAN.clear()
+    res = I.run_dask(tiles, nets=nets, opt=opt, output_tensor=True)
+    I.fp16_check()                                             # random-init nets: finite
+    assert all(torch.isfinite(v).all() for v in res.values())
+    with torch.no_grad():
+        first = next(p for p in nets['G2'].parameters() if p.dim() == 4)
+        first.mul_(3e7)                                        # the stem's outputs now exceed 65 504
+    I.run_dask(tiles, nets=nets, opt=opt, output_tensor=True)
+    with pytest.raises(FloatingPointError, match="precision='bf16'"):
+        I.run_dask(tiles, nets=nets, opt=opt, output_tensor=True)          # the check of the previous batch, before anything new is launched
+    I._FP16_NAN.clear()
+    for net in nets.values():
+        net.set_precision('bf16')
+    res = I.run_dask(tiles, nets=nets, opt=opt, output_tensor=True)
+    assert all(torch.isfinite(v).all() for v in res.values())
