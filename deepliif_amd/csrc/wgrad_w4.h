@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(256) wgrad_w4_kernel(const WgradW4Args a, cons
             set_row(r);
             step();
         }
+        // the last sub-step prefetched fragments nobody consumes: they must have LANDED before the epilogue re-uses their registers (the compiler does not
+        // know that the inline-asm reads complete asynchronously; tests/test_isa_checks.py holds both halves of this contract on the generated code)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
     // ---- epilogue: acc[i][k][e] = dW[ca = ta*128 + 32 i + 8 (e >> 2) + 4 lh + (e & 3)][kh][kw = k][cb = tb*128 + 32 wave + lr]
