@@ -203,7 +203,12 @@ template <> __device__ __forceinline__ void store1<bf16_t>(bf16_t *p, float v) {
 
 __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {
+#ifdef DL_H16_FP16
+        case DL_ACT_RELU: return v < 0.f ? 0.f : v;      // same values, but NaN stays NaN: a half overflow (inf in a conv output -> NaN statistics) must reach the
+                                                         // network's output, where deepliif_amd/inference.py looks for it, instead of being clamped to 0 here
+#else
         case DL_ACT_RELU: return v > 0.f ? v : 0.f;
+#endif
         case DL_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
         case DL_ACT_TANH: return tanhf(v);
         case DL_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));

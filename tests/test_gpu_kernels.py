@@ -330,9 +330,9 @@ def test_pack_weights_batch_matches_single_packs():
                 single = ops.PackedWeights(plan, DEV, with_lo)
                 be.pack_weights(single, w)
                 batched = ops.PackedWeights(plan, DEV, with_lo)
-                batched.hi.fill_(float('nan'))
+                batched.hi.fill_(0x7fc0)               # (a bf16 NaN pattern: anything the pack does not overwrite shows up)
                 if with_lo:
-                    batched.lo.fill_(float('nan'))
+                    batched.lo.fill_(0x7fc0)
                 jobs.append((batched, w))
                 refs.append(single)
     table = be.pack_batch_build(jobs)
@@ -354,7 +354,7 @@ def test_pack_weights_batch_matches_single_packs():
         L.load().dl_switches_reload()
     assert not ((chunk_table[1][0::2] & (1 << 30)) != 0).any()
     for batched, _ in jobs:
-        batched.hi.fill_(float('nan'))
+        batched.hi.fill_(0x7fc0)               # (a bf16 NaN pattern: anything the pack does not overwrite shows up)
     be.pack_batch_run(chunk_table, len(jobs))
     sync()
     for (batched, _), single in zip(jobs, refs):
