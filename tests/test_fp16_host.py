@@ -92,3 +92,30 @@ def test_fp16_overflow_is_reported_not_returned():
     I.fp16_check()                                   # consumed
     I._fp16_note({'G1': E.Act(torch.full((1, 4, 4, 8), float('nan'), dtype=torch.bfloat16), 3)})      # other policies are not looked at
     assert not I._FP16_NAN
+
+
+def test_region_inference_on_the_fp16_policy():
+    """infer_region (crop + is_empty + generator DAG + stitch) with the nets on 'fp16': float16 tiles from the gather to the paste, the stitched 8-bit images
+    within one level of the strict policy's"""
+    import types
+    import numpy as np
+    from deepliif_amd import inference as I
+    from golden_util import synth_image
+    torch.manual_seed(0)
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=1, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_32', input_no=1, scale_size=64,
+                                modalities_names=['input1', 'mod1'], background_colors=[(201, 211, 208)], gpu_ids=[])
+    nets = I.build_generators(opt, torch.device('cpu'), 'fp32')
+    img = synth_image(150, 230, 13)
+    img[:64] = 250                               # an empty first tile row
+    img = torch.from_numpy(img)
+    out = {}
+    for p in ('fp32', 'fp16'):
+        for net in nets.values():
+            net.set_precision(p)
+        out[p], band = I.infer_region([img], 64, 4, nets, opt, seg_weights=[0.5, 0.5], batch_size=3)
+        assert band == (0, img.shape[0])
+    assert set(out['fp16']) == set(out['fp32'])
+    for k, ref in out['fp32'].items():
+        d = (out['fp16'][k].to(torch.int32) - ref.to(torch.int32)).abs()
+        assert int(d.max()) <= 2 and float((d > 1).float().mean()) < 1e-3, (k, int(d.max()))
