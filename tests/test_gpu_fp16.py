@@ -288,3 +288,32 @@ def test_half_overflow_inside_a_net_raises():
         net.set_precision('bf16')
     res = I.run_dask(tiles, nets=nets, opt=opt, output_tensor=True)
     assert all(torch.isfinite(v).all() for v in res.values())
+
+
+def test_reference_run_dask_fixture_on_the_fp16_policy():
+    """tests/golden/inference_small.npz holds what the REFERENCE's run_dask returned for three tiles (one call per tile): the same nets served on 'fp16' in ONE batch
+    (per-sample statistics) against those outputs, next to the bf16 policy"""
+    if DRY:
+        pytest.skip('GPU policy comparison')
+    import numpy as np
+    from deepliif_amd import inference as I
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'inference_small.npz'))
+    opt = types.SimpleNamespace(model='DeepLIIF', modalities_no=4, seg_gen=True, mod_id_seg='S', input_id=0, input_nc=3, output_nc=3, ngf=8,
+                                norm='batch', padding='zero', net_g='resnet_9blocks', net_gs='unet_64', input_no=1,
+                                modalities_names=['IHC', 'Hema', 'DAPI', 'Lap2', 'Marker'], gpu_ids=[0])
+    tiles = seeded_uniform((3, 3, 64, 64), 32)
+    worst = {}
+    for p in ('fp16', 'bf16'):
+        nets = I.build_generators(opt, torch.device('cuda', 0), p)
+        for name, seed in zip(z['net_names'], z['net_seeds']):
+            name = str(name)
+            seg = len(name) > 2
+            sd = O.random_state_dict('unet_64' if seg else 'resnet_9blocks', 3, 3, 8, 'batch', 'reflect' if seg else 'zero',
+                                     generator=torch.Generator().manual_seed(int(seed)))
+            nets[name].load_state_dict(sd)
+        res = I.run_dask(tiles.to(DEV), nets=nets, opt=opt, seg_weights=[float(w) for w in z['seg_weights']], output_tensor=True)
+        I.fp16_check()
+        assert list(res.keys()) == [str(k) for k in z['keys']]
+        worst[p] = max(rel(res[k][t:t + 1], torch.from_numpy(z[f'tile{t}/{k}'])) for t in range(3) for k in res)
+        ERRLOG[f'reference_fixture/inference_small/{p}'] = worst[p]
+    assert worst['fp16'] < 1.5e-2 and worst['fp16'] < 0.4 * worst['bf16'], worst          # measured 8.8e-3 vs 6.7e-2 (the strict policy on this fixture: < 1e-3, test_gpu_networks)
