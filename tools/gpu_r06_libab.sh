@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of the training step between the shipped library and variant builds: tools/gpu_r06_libab.sh <tag> <variant .so name> [<variant> ...]
+# KSHOW=substr,substr: also list these kernels when they are not among the first 14
 # (variants live next to the shipped library, e.g. deepliif_amd/libdeepliif_hip_w4nt.so; selected through DEEPLIIF_AMD_LIB)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -17,8 +18,11 @@ import csv
 rows = list(csv.DictReader(open('gpurun_out/prof_ab/bench_kernel_stats.csv')))
 tot = sum(float(r['TotalDurationNs']) for r in rows if 'probe_mfma' not in r['Name'])
 print('total kernel ms / step %.2f' % (tot / 4e6))
-for r in rows[:14]:
-    print('  %-70s %5s calls %8.1f us avg' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3))
+import os
+show = [t for t in os.environ.get('KSHOW', '').split(',') if t]
+for i, r in enumerate(rows):
+    if i < 14 or any(t in r['Name'] for t in show):
+        print('  %-70s %5s calls %8.1f us avg' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cpu-baseline-n8 --no-strict --no-timer-check --no-other-workloads 2>/dev/null | tail -1 > gpurun_out/libab_bench.json
   python -c "
