@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) norm_partial_kernel(const T *y, int y_ps,
 //   FUSE 1 (forward) : mean, rstd, scale, shift           FUSE 2 (backward): c1 = S1/HW, c2 = S2/HW
 template <int FUSE>
 __global__ void __launch_bounds__(1024) norm_chunk_sum_kernel(const float *part, NormGeom g, float *sums, float eps, float *o0, float *o1,
-                                                              float *o2, float *o3) {
+                                                              float *o2, float *o3, const float *gamma, const float *beta) {
     // block = 32 channels x 32 chunk lanes: every thread owns at most nchunks/32 partials and loads them with independent
     // accumulators (the 8-lane version was a chain of 8-16 dependent L2 round trips: 11 us for < 2 MB)
     constexpr int KL = 32;
@@ -166,13 +166,23 @@ __global__ void __launch_bounds__(1024) norm_chunk_sum_kernel(const float *part,
         for (int r = 0; r < KL; ++r) { a1 += (double)red[0][r][cl]; a2 += (double)red[1][r][cl]; }
         sums[((size_t)n * 2) * g.Cp + c] = (float)a1;
         sums[((size_t)n * 2 + 1) * g.Cp + c] = (float)a2;
-        if (FUSE == 1) {           // InstanceNorm2d: no affine (networks.py:36-37)
-            const double mu = a1 / g.HW;
-            double var = a2 / g.HW - mu * mu;
+        if (FUSE == 1) {           // per-(n, c) statistics: InstanceNorm2d (no affine, networks.py:36-37), or BatchNorm2d's affine on the statistics of ONE tile
+                                   // (batched inference with per-sample normalisation) -- same formulas as norm_fwd_finalize_kernel
+            // with an affine the sums go through their fp32 rounding first, as norm_fwd_finalize_kernel reads them: a tile normalised on its own statistics must come
+            // out bit-identical whether it was served as one of a batch (this path) or alone in train() mode (batch scope, N = 1: the finalize kernel)
+            const bool affine = gamma != nullptr || beta != nullptr;
+            const double m1 = affine ? (double)(float)a1 : a1, m2 = affine ? (double)(float)a2 : a2;
+            const double mu = m1 / g.HW;
+            double var = m2 / g.HW - mu * mu;
             if (var < 0.0) var = 0.0;
             const float rs = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = c < g.C ? rs : 0.f;
-            o0[n * g.Cp + c] = (float)mu; o1[n * g.Cp + c] = rs; o2[n * g.Cp + c] = sc; o3[n * g.Cp + c] = -(float)mu * sc;
+            float sc = 0.f, sh = 0.f;
+            if (c < g.C) {
+                const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+                sc = ga * rs;
+                sh = be - (float)mu * sc;
+            }
+            o0[n * g.Cp + c] = (float)mu; o1[n * g.Cp + c] = rs; o2[n * g.Cp + c] = sc; o3[n * g.Cp + c] = sh;
         } else if (FUSE == 2) {
             o0[n * g.Cp + c] = (float)(a1 / g.HW); o1[n * g.Cp + c] = (float)(a2 / g.HW);
         }
@@ -471,11 +481,12 @@ extern "C" int dl_norm_forward(const dl_norm_desc *d, const void *y, const float
                            (const bf16_t *)nullptr, 0, g, nullptr, nullptr, nullptr, nullptr, ws);
     DL_CHECK_LAUNCH("dl_norm_forward(stats)");
     float *sums = ws + (size_t)g.N * g.nchunks * 2 * g.Cp;
-    if (d->scope == DL_NORM_INSTANCE && !gamma && !beta) {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<1>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, mean, rstd, scale, shift);
+    if (d->scope == DL_NORM_INSTANCE) {
+        // (r06: also with an affine -- the 9-generator inference batch ran 185 norm_fwd_finalize launches of 4.7 us per step next to as many chunk sums)
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<1>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, mean, rstd, scale, shift, gamma, beta);
         DL_CHECK_LAUNCH("dl_norm_forward(chunk sums + finalize)");
     } else {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, ws, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_forward(chunk sums)");
         const int ftotal = (d->scope == DL_NORM_BATCH) ? g.Cp : g.N * g.Cp;
         hipLaunchKernelGGL(norm_fwd_finalize_kernel, dim3((ftotal + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, d->eps, gamma, beta,
@@ -521,10 +532,10 @@ extern "C" int dl_norm_backward(const dl_norm_desc *d, const void *dz, const voi
     else { DL_NORM_ACT_SWITCH(d->act, DL_LAUNCH_BRED_BF16) }
     DL_CHECK_LAUNCH("dl_norm_backward(reduce)");
     if (d->scope == DL_NORM_INSTANCE && !dgamma) {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<2>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, c1, c2, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<2>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, c1, c2, nullptr, nullptr, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_backward(chunk sums + finalize)");
     } else {
-        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(norm_chunk_sum_kernel<0>, dim3((g.Cp + 31) / 32, g.N), dim3(1024), 0, stream, part, g, sums, d->eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         DL_CHECK_LAUNCH("dl_norm_backward(chunk sums)");
         hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((g.Cp + 255) / 256), dim3(256), 0, stream, sums, g, d->scope, c1, c2, dgamma, dbeta,
                            accumulate_affine);
