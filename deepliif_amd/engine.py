@@ -196,6 +196,8 @@ def new_act(n, h, w, c, prec: Precision, device, zero=False) -> Act:
 
 # A/B switch (DL_CONV_PREACT=0 disables): apply a conv's input activation in a separate pass so the conv can take the direct-to-LDS path
 _PREACT = os.environ.get('DL_CONV_PREACT', '1') != '0'
+# A/B switch (DL_WGRAD_PREACT=0 disables): the activation materialised by DL_CONV_PREACT is kept for the layer's weight gradient, which then takes the direct-to-LDS kernel too
+_WGRAD_PREACT = os.environ.get('DL_WGRAD_PREACT', '1') != '0'
 # A/B switch (DL_CONVT4=0 disables): narrow-Cout ConvTranspose2d(4, 2, 1) at inference as one 1x1 GEMM + a 2x2 gather-sum (conv() below)
 _CONVT4 = os.environ.get('DL_CONVT4', '1') != '0'
 
@@ -361,6 +363,7 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
     spec = layer.spec
     n, hi, wi, _ = x.t.shape
     ho, wo = spec.out_hw(hi, wi)
+    x_pre = None            # in_act(x) materialised by the forward pass and kept for the weight gradient (below)
     w_needs = layer.weight.requires_grad and ctx.tape is not None
     x_needs = x.needs_grad and ctx.tape is not None
     layer.ensure_packed(ctx.prec, need_dgrad=x_needs)
@@ -405,6 +408,10 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
             xin = empty_like_act(x.t)
             be.act_forward(in_act, x.t, xin)
             fwd_in_act = L.ACT_NONE
+            if w_needs and _WGRAD_PREACT:
+                # ... and the weight gradient has the same problem (an operand with a staged activation goes to the register-staged wgrad_kernel: 105 us per UNet
+                # layer, 7 % of the 18-network step): keep in_act(x) for it -- one more activation-sized tensor per UNet conv, alive until its backward
+                x_pre = xin
         x_split = x.split is not None and fwd_in_act == L.ACT_NONE and xin is x.t and getattr(be, 'supports_split', False) and \
             be.conv_takes_split(x.t, ctx.prec.prec, fwd_in_act, spec.pad_mode)
         assert x.values_stored or x_split, 'a split-only activation reached a convolution that needs its fp32 values'
@@ -479,13 +486,15 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
                 be.conv_wgrad(D, x.t, layer.weight.grad, spec.k, 1, spec.pad, L.PAD_ZERO, L.ACT_NONE, in_act, ctx.prec.prec, True, stack_kw=spec.k)
                 del D
             elif spec.kind == 'conv':
+                xw, xw_act = (x_pre, L.ACT_NONE) if x_pre is not None else (x.t, in_act)       # (x_pre: bf16 policy only, so no split copies are in play)
                 sp = (gs is not None or xs is not None) and be.wgrad_takes_split(g, x.t, layer.weight.grad, spec.k, spec.pad_mode, ctx.prec.prec)
-                be.conv_wgrad(gs if (sp and gs is not None) else g, xs if (sp and xs is not None) else x.t, layer.weight.grad, spec.k, spec.stride, spec.pad,
-                              spec.pad_mode, L.ACT_NONE, in_act, ctx.prec.prec, True, **({'p_split': gs is not None, 'q_split': xs is not None} if sp else {}))
+                be.conv_wgrad(gs if (sp and gs is not None) else g, xs if (sp and xs is not None) else xw, layer.weight.grad, spec.k, spec.stride, spec.pad,
+                              spec.pad_mode, L.ACT_NONE, xw_act, ctx.prec.prec, True, **({'p_split': gs is not None, 'q_split': xs is not None} if sp else {}))
             else:
+                xw, xw_act = (x_pre, L.ACT_NONE) if x_pre is not None else (x.t, in_act)
                 sp = (gs is not None or xs is not None) and be.wgrad_takes_split(x.t, g, layer.weight.grad, spec.k, L.PAD_ZERO, ctx.prec.prec)
-                be.conv_wgrad(xs if (sp and xs is not None) else x.t, gs if (sp and gs is not None) else g, layer.weight.grad, spec.k, spec.stride, spec.pad,
-                              L.PAD_ZERO, in_act, L.ACT_NONE, ctx.prec.prec, True, **({'p_split': xs is not None, 'q_split': gs is not None} if sp else {}))
+                be.conv_wgrad(xs if (sp and xs is not None) else xw, gs if (sp and gs is not None) else g, layer.weight.grad, spec.k, spec.stride, spec.pad,
+                              L.PAD_ZERO, xw_act, L.ACT_NONE, ctx.prec.prec, True, **({'p_split': xs is not None, 'q_split': gs is not None} if sp else {}))
             if layer.bias is not None and layer.bias.requires_grad and not y.bias_done:
                 be.channel_sum(g, spec.cout, layer.bias.grad, True)
         if x_needs and spec.kind == 'conv' and spec.pad_mode == L.PAD_REFLECT:
