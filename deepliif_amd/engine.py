@@ -200,6 +200,8 @@ _PREACT = os.environ.get('DL_CONV_PREACT', '1') != '0'
 _WGRAD_PREACT = os.environ.get('DL_WGRAD_PREACT', '1') != '0'
 # A/B switch (DL_CONVT4=0 disables): narrow-Cout ConvTranspose2d(4, 2, 1) at inference as one 1x1 GEMM + a 2x2 gather-sum (conv() below)
 _CONVT4 = os.environ.get('DL_CONVT4', '1') != '0'
+# A/B switch (DL_CONVT4_TRAIN=0): that route only without a tape, as in rounds 4-5 (the training forward of the layer then runs the 4-phase gather GEMM: 337 us per UNet)
+_CONVT4_TRAIN = os.environ.get('DL_CONVT4_TRAIN', '1') != '0'
 
 
 def empty_like_act(a: torch.Tensor) -> torch.Tensor:
@@ -378,15 +380,17 @@ def conv(ctx: Ctx, x: Act, layer: ConvLayer, act: int = L.ACT_NONE, in_act: int 
         # one kernel: every input row staged once, all kernel rows at once, kernel-column sum from LDS (conv_small.hip)
         be.conv_narrow_forward(layer.packed_fwd, x.t, out, spec.cout, spec.k, spec.pad, layer.bias.detach() if layer.bias is not None else None, act)
         nch = 0
-    elif (_CONVT4 and spec.kind == 'convT' and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and spec.cout <= 4 and not (x_needs or w_needs)
+    elif (_CONVT4 and spec.kind == 'convT' and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and spec.cout <= 4 and (_CONVT4_TRAIN or not (x_needs or w_needs))
           and ctx.prec.prec == L.PREC_BF16 and ctx.prec.is16 and x.t.dtype == ctx.prec.dtype and getattr(be, 'convt4_gather', None) is not None):
-        # UnetGenerator's outermost up-convolution to 3 channels (networks.py:573-576), inference: one 1x1 GEMM over the input with a row per
+        # UnetGenerator's outermost up-convolution to 3 channels (networks.py:573-576), inference and (r06) the training forward: one 1x1 GEMM over the input with a row per
         # (ky, kx, co), then the 2x2 gather-sum + bias + tanh (dl_convt4_gather).  The 4-phase gather GEMM stages every input pixel 16 times for
         # 3 useful columns: 327 us at 8 x 256^2 x 128, 5.9 % of the inference batch.
         xin = x.t
         if in_act != L.ACT_NONE:
             xin = empty_like_act(x.t)
             be.act_forward(in_act, x.t, xin)
+            if w_needs and _WGRAD_PREACT:
+                x_pre = xin                    # kept for the weight gradient (see the general branch below)
         T = torch.empty((n, hi, wi, cpad(16 * spec.cout)), dtype=torch.float32, device=x.t.device)
         be.conv_forward(layer.ensure_packed_taps(ctx.prec), xin, T, hi, wi, None, L.ACT_NONE, L.ACT_NONE, ctx.prec.prec, raw_out=True)
         be.convt4_gather(T, spec.cout, layer.bias.detach() if layer.bias is not None else None, act, out)
