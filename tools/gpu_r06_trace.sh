@@ -1,11 +1,11 @@
 #!/bin/bash
 # per-dispatch view of the one-stream training step: rocprofv3 --kernel-trace, dispatches grouped by (kernel, grid, workgroup) -> launches, mean / min duration.
-# Tells apart the SHAPES a kernel template runs on (the --stats table averages over them).  tools/gpu_r06_trace.sh <tag> [substring ...]
+# WL=<workload> selects another bench workload (default train).  Tells apart the SHAPES a kernel template runs on (the --stats table averages over them).  tools/gpu_r06_trace.sh <tag> [substring ...]
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 TAG=${1:-a}; shift
 rm -rf gpurun_out/prof_tr
-(cd /tmp && DL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_tr -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cpu-baseline-n8 --no-strict --no-graph --no-timer-check --no-other-workloads > /dev/null 2>&1)
+(cd /tmp && DL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_tr -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-train} --steps 2 --warmup 1 --no-cpu-baseline --no-cpu-baseline-n8 --no-strict --no-graph --no-timer-check --no-other-workloads > /dev/null 2>&1)
 python - "$@" > gpurun_out/trace_$TAG.txt <<'PY'
 import csv, sys, collections
 subs = sys.argv[1:] or ['norm_']
