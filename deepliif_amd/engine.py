@@ -690,12 +690,16 @@ def dropout(ctx: Ctx, x: Act, p: float, in_place: bool = False) -> Act:
     return z
 
 
-def concat_channels(ctx: Ctx, parts: List[Act]) -> Act:
-    """torch.cat(parts, 1) for small channel counts (D inputs: cat(cond, image), DeepLIIF_model.py:223)."""
+def concat_channels(ctx: Ctx, parts: List[Act], out: Optional[torch.Tensor] = None) -> Act:
+    """torch.cat(parts, 1) for small channel counts (D inputs: cat(cond, image), DeepLIIF_model.py:223).
+    out: an already ZEROED [n, h, w, cpad(sum C)] tensor to fill instead of a new one (a batch slice of a larger buffer: pair_batch below)"""
     be = ops.impl()
     ctot = sum(p.C for p in parts)
     n, h, w, _ = parts[0].t.shape
-    out = torch.zeros((n, h, w, cpad(ctot)), dtype=parts[0].t.dtype, device=parts[0].t.device)
+    if out is None:
+        out = torch.zeros((n, h, w, cpad(ctot)), dtype=parts[0].t.dtype, device=parts[0].t.device)
+    else:
+        assert tuple(out.shape) == (n, h, w, cpad(ctot)) and out.dtype == parts[0].t.dtype
     c0 = 0
     for p in parts:
         be.copy_channels(p.t, 0, out, c0, p.C)
@@ -818,6 +822,24 @@ def loss_op(ctx: Ctx, kind: int, x: Act, target: Optional[Act], target_const: fl
     needs = ctx.tape is not None and x.needs_grad
     grad = empty_like_act(x.t) if needs else None
     be.loss(kind, x.t, target.t if target is not None else None, target_const, x.C, loss_out, grad, weight, out_scale, accumulate)
+    if needs:
+        def backward():
+            x.add_grad(grad)
+        ctx.tape.record(backward)
+
+
+def loss_op_halves(ctx: Ctx, kind: int, x: Act, consts, weight: float, loss_outs) -> None:
+    """Two loss_op calls on the two batch halves of x -- x[:n/2] against consts[0] into loss_outs[0], x[n/2:] against consts[1] into loss_outs[1] -- with ONE
+    gradient tensor for x: the discriminator pass over cat(fake batch, real batch) (models.DeepLIIFModel.backward_D).  Each half is a mean over its own
+    elements, exactly what two separate passes compute."""
+    be = ops.impl()
+    n = x.t.shape[0]
+    assert n % 2 == 0
+    needs = ctx.tape is not None and x.needs_grad
+    grad = empty_like_act(x.t) if needs else None
+    for half, (c, lo) in enumerate(zip(consts, loss_outs)):
+        sl = slice(half * (n // 2), (half + 1) * (n // 2))
+        be.loss(kind, x.t[sl], None, c, x.C, lo, grad[sl] if needs else None, weight, 1.0, False)
     if needs:
         def backward():
             x.add_grad(grad)

@@ -77,6 +77,10 @@ def pick_gpu(gpu_ids, is_train: bool, env=None) -> int:
                               'then takes gpu_ids[LOCAL_RANK] and the gradients are averaged over RCCL, deepliif_amd.distributed)')
 
 
+# A/B switch (DL_D_PAIR_BATCH=0): the discriminators see the fake pairs and the real pairs in two calls, as in rounds 1-5 (DeepLIIFModel.backward_D)
+_D_PAIR_BATCH = os.environ.get('DL_D_PAIR_BATCH', '1') != '0'
+
+
 class StepGraph:
     """optimize_parameters() captured ONCE in a hipGraph and replayed per step: a training step is ~2 400 kernel launches issued
     by ~55 ms of Python for ~100 ms of GPU time; a replay is one launch.  The shapes are static, the losses stay on the device, the tape is
@@ -633,25 +637,57 @@ class DeepLIIFModel(BaseModel):
         wD = self.loss_D_weights
         cg, cs = self.criterionGAN_mod, self.criterionGAN_seg
         self._fork()                             # (the gradients were zeroed on the main stream)
+        # A discriminator that normalises every sample on its own statistics (InstanceNorm, or no norm layer) sees the fake pairs and the real pairs as ONE batch of
+        # 2N: sample by sample the same arithmetic as the reference's two calls (DeepLIIF_model.py:222-236), but every launch has twice the tiles -- the PatchGAN's
+        # GEMM-shaped layers are the under-filled kernels of this step (64-128 tiles of 256 x 256 on 256 CUs at batch 8) -- and there are half as many launches.
+        # BatchNorm discriminators keep the two calls (their statistics are per call).
+        paired = _D_PAIR_BATCH and all(getattr(getattr(self, 'net' + n), 'norm_kind', 'batch') != 'batch' for n in self.model_names_d)
+        real_mod_done = False
         for i, n in enumerate(self.model_names_d):
             with self._branch(i):
                 # every discriminator runs twice below (fake, real): mark before the first use -- on the stream of its branch: the marker's all-reduce is
                 # ordered behind THAT stream
                 self._mark_net(tape, getattr(self, 'net' + n))
+                if paired:
+                    nb, h, w, _ = self._A.t.shape
+                    both = torch.zeros((2 * nb, h, w, E.cpad(self._A.C + self._fake[i].C)), dtype=self._A.t.dtype, device=self._A.t.device)
+                    E.concat_channels(ctx, [self._A, self._fake[i].detach()], out=both[:nb])
+                    E.concat_channels(ctx, [self._A, self._B[i]], out=both[nb:])
+                    pred = getattr(self, 'net' + n).run(ctx, E.Act(both, self._A.C + self._fake[i].C))
+                    E.loss_op_halves(ctx, cg.kind, pred, (cg.target(False), cg.target(True)), 0.5 * wD[i],
+                                     (getattr(self, f'loss_D_fake_{i + 1}').view(1), getattr(self, f'loss_D_real_{i + 1}').view(1)))
+                    continue
                 pair = E.concat_channels(ctx, [self._A, self._fake[i].detach()])
                 pred = getattr(self, 'net' + n).run(ctx, pair)
                 E.loss_op(ctx, cg.kind, pred, None, cg.target(False), 0.5 * wD[i], getattr(self, f'loss_D_fake_{i + 1}').view(1))
+        real_mod_done = paired
         for n in self.model_names_ds:
             self._mark_net(tape, getattr(self, 'net' + n))
-        if self.seg_gen:
+        paired_seg = self.seg_gen and _D_PAIR_BATCH and all(getattr(getattr(self, 'net' + n), 'norm_kind', 'batch') != 'batch' for n in self.model_names_ds)
+        if paired_seg:
+            # the five segmentation discriminators, each on cat(fake pairs, real pairs); weighted BEFORE the loss as in _seg_pred (:258-262)
+            preds = []
+            nb, h, w, _ = self._A.t.shape
+            for i, n in enumerate(self.model_names_ds):
+                cond = self._A if i == 0 else self._B[i - 1]
+                both = torch.zeros((2 * nb, h, w, E.cpad(cond.C + self._fake_seg.C)), dtype=cond.t.dtype, device=cond.t.device)
+                E.concat_channels(ctx, [cond, self._fake_seg.detach()], out=both[:nb])
+                E.concat_channels(ctx, [cond, self._Bseg], out=both[nb:])
+                preds.append(getattr(self, 'net' + n).run(ctx, E.Act(both, cond.C + self._fake_seg.C)))
+            pred = E.weighted_sum(ctx, preds, self.seg_weights[:M + 1])
+            E.loss_op_halves(ctx, cs.kind, pred, (cs.target(False), cs.target(True)), 0.5 * wD[M],
+                             (getattr(self, f'loss_D_fake_{S}').view(1), getattr(self, f'loss_D_real_{S}').view(1)))
+        elif self.seg_gen:
             pred = self._seg_pred(ctx, self._fake_seg.detach())
             E.loss_op(ctx, cs.kind, pred, None, cs.target(False), 0.5 * wD[M], getattr(self, f'loss_D_fake_{S}').view(1))
-        real_mod, real_seg = self._pairs_real(ctx)
+        real_mod, real_seg = self._pairs_real(ctx) if ((self.seg_gen and not paired_seg) or not real_mod_done) else (None, None)
         for i, n in enumerate(self.model_names_d):
+            if real_mod_done:
+                break
             with self._branch(i):
                 pred = getattr(self, 'net' + n).run(ctx, real_mod[i])
                 E.loss_op(ctx, cg.kind, pred, None, cg.target(True), 0.5 * wD[i], getattr(self, f'loss_D_real_{i + 1}').view(1))
-        if self.seg_gen:
+        if self.seg_gen and not paired_seg:
             preds = [getattr(self, 'net' + n).run(ctx, real_seg[i]) for i, n in enumerate(self.model_names_ds)]
             pred = E.weighted_sum(ctx, preds, self.seg_weights[:M + 1])
             E.loss_op(ctx, cs.kind, pred, None, cs.target(True), 0.5 * wD[M], getattr(self, f'loss_D_real_{S}').view(1))
@@ -883,6 +919,30 @@ class DeepLIIFExtModel(BaseModel):
         cg, cs, M = self.criterionGAN_mod, self.criterionGAN_seg, self.mod_gen_no
         rc = self._cat_real(ctx)                     # (main stream, before the fork)
         self._fork()                                 # (the gradients were zeroed on the main stream)
+        if _D_PAIR_BATCH and all(getattr(d, 'norm_kind', 'batch') != 'batch' for d in list(self.netD[:M]) + [d for d in self.netDS if d is not None]):
+            # per-sample-normalised discriminators: the fake and the real inputs of each as ONE batch of 2N (see DeepLIIFModel.backward_D)
+            def both_halves(parts_fake, parts_real):
+                nb, h, w, _ = parts_fake[0].t.shape
+                c = sum(p.C for p in parts_fake)
+                both = torch.zeros((2 * nb, h, w, E.cpad(c)), dtype=parts_fake[0].t.dtype, device=parts_fake[0].t.device)
+                E.concat_channels(ctx, parts_fake, out=both[:nb])
+                E.concat_channels(ctx, parts_real, out=both[nb:])
+                return E.Act(both, c)
+            for i in range(M):
+                with self._branch(i):
+                    self._mark_net(tape, self.netD[i])
+                    pred = self.netD[i].run(ctx, both_halves([self._A, self._fake[i].detach()], [self._A, self._B[i]]))
+                    E.loss_op_halves(ctx, cg.kind, pred, (cg.target(False), cg.target(True)), 0.5 * self.loss_D_weights[i],
+                                     (self._slot(f'D_fake_{i + 1}'), self._slot(f'D_real_{i + 1}')))
+            for i in range(len(self._fake_s)):
+                with self._branch(i):
+                    self._mark_net(tape, self.netDS[i])
+                    pred = self.netDS[i].run(ctx, both_halves([rc[i], self._fake_s[i].detach()], [rc[i], self._BS[i]]))
+                    E.loss_op_halves(ctx, cs.kind, pred, (cs.target(False), cs.target(True)), 0.5 * self.loss_DS_weights[i],
+                                     (self._slot(f'DS_fake_{i + 1}'), self._slot(f'DS_real_{i + 1}')))
+            tape.backward()
+            self._join()
+            return
         for i in range(M):
             with self._branch(i):
                 # every discriminator runs twice below (fake, real): mark before the first use, on the stream of its branch (the marker's all-reduce is

@@ -313,3 +313,44 @@ def test_lambda_feat_without_weights_is_an_error_not_a_silent_change_of_objectiv
         CpuModel(opt)
     opt.allow_no_vgg = True
     assert CpuModel(opt).criterionVGG is None
+
+
+def test_paired_discriminator_batch_equals_the_two_calls(monkeypatch):
+    """DeepLIIFModel.backward_D with DL_D_PAIR_BATCH (InstanceNorm discriminators see cat(fake pairs, real pairs) as one batch of 2N) against the reference's
+    two calls per discriminator: the same four loss kinds and the same discriminator gradients (the emulation computes in fp32: differences are summation order)"""
+    res = {}
+    for paired in (False, True):
+        monkeypatch.setattr(M, '_D_PAIR_BATCH', paired)
+        torch.manual_seed(0)
+        opt = make_opt(2, True, 'instance')
+        model = CpuModel(opt)
+        model.setup(opt)
+        A = seeded_uniform((2, 3, 64, 64), 22)
+        B = [seeded_uniform((2, 3, 64, 64), 23 + i) for i in range(3)]
+        model.set_input({'A': A, 'B': B, 'A_paths': ['x']})
+        model.forward()
+        for o in model.optimizers:
+            o.zero_grad()
+        model.backward_D()
+        losses = {k: float(v) for k, v in model.get_current_losses().items() if k.startswith('D_')}
+        grads = torch.cat([p.grad.reshape(-1) for n in model.model_names if n.startswith('D') for p in getattr(model, 'net' + n).parameters()])
+        res[paired] = (losses, grads.clone())
+    assert res[False][0].keys() == res[True][0].keys() and len(res[True][0]) == 6
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 1e-6 * max(1.0, abs(v)), (k, v, res[True][0][k])
+    g0, g1 = res[False][1], res[True][1]
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-5 and float(g0.norm()) > 0
+    # BatchNorm discriminators keep the two calls (their statistics are per call): the switch must not change anything there
+    monkeypatch.setattr(M, '_D_PAIR_BATCH', True)
+    torch.manual_seed(0)
+    opt = make_opt(1, False, 'batch')
+    model = CpuModel(opt)
+    model.setup(opt)
+    calls = []
+    d = model.netD1
+    orig = d.run
+    d.run = lambda ctx, x: (calls.append(x.t.shape[0]), orig(ctx, x))[1]
+    model.set_input({'A': seeded_uniform((2, 3, 64, 64), 22), 'B': [seeded_uniform((2, 3, 64, 64), 23)], 'A_paths': ['x']})
+    model.forward()
+    model.backward_D()
+    assert calls == [2, 2]
