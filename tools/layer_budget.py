@@ -152,21 +152,30 @@ if __name__ == '__main__':
     out.append(conv_case('G up1 convT3x3s2 256->128 @128->256', 'convT', 256, 128, 3, 2, 1, N, S // 4, S // 4, prec, NG, NG, NG, op=1))
     out.append(conv_case('G up2 convT3x3s2 128->64 @256->512', 'convT', 128, 64, 3, 2, 1, N, S // 2, S // 2, prec, NG, NG, NG, op=1))
     out.append(conv_case('G head 7x7 64->3 @512', 'conv', 64, 3, 7, 1, 3, N, S, S, prec, NG, NG, NG, act=TH))
-    # ---- NLayerD(n=4) (x ND): backward_D = 2 fwd + 2 bwd (no data gradient into the detached input pair), backward_G = 1 fwd + dgrad only
-    out.append(conv_case('D c1 4x4s2 6->64 @512->256', 'conv', 6, 64, 4, 2, 1, N, S, S, prec, 3 * ND, ND, 2 * ND, act=LR))
-    out.append(conv_case('D c2 4x4s2 64->128 @256->128', 'conv', 64, 128, 4, 2, 1, N, S // 2, S // 2, prec, 3 * ND, 3 * ND, 2 * ND))
-    out.append(conv_case('D c3 4x4s2 128->256 @128->64', 'conv', 128, 256, 4, 2, 1, N, S // 4, S // 4, prec, 3 * ND, 3 * ND, 2 * ND))
-    out.append(conv_case('D c4 4x4s2 256->512 @64->32', 'conv', 256, 512, 4, 2, 1, N, S // 8, S // 8, prec, 3 * ND, 3 * ND, 2 * ND))
-    out.append(conv_case('D c5 4x4s1 512->512 @32->31', 'conv', 512, 512, 4, 1, 1, N, S // 16, S // 16, prec, 3 * ND, 3 * ND, 2 * ND))
-    out.append(conv_case('D c6 4x4s1 512->1 @31->30', 'conv', 512, 1, 4, 1, 1, N, S // 16 - 1, S // 16 - 1, prec, 3 * ND, 3 * ND, 2 * ND))
+    # ---- NLayerD(n=4) (x ND).  r06: backward_D runs every discriminator ONCE on cat(fake pairs, real pairs) -- batch 2N: 1 fwd + 1 bwd (no data gradient into the
+    # detached input pair) -- and backward_G once on batch N (fwd + data gradient only).  LB_D_PAIR=0: the two calls per discriminator of rounds 1-5.
+    pair = os.environ.get('LB_D_PAIR', '1') != '0'
+    dcases = [('D c1 4x4s2 6->64 @512->256', 6, 64, 2, S, LR), ('D c2 4x4s2 64->128 @256->128', 64, 128, 2, S // 2, L.ACT_NONE), ('D c3 4x4s2 128->256 @128->64', 128, 256, 2, S // 4, L.ACT_NONE),
+              ('D c4 4x4s2 256->512 @64->32', 256, 512, 2, S // 8, L.ACT_NONE), ('D c5 4x4s1 512->512 @32->31', 512, 512, 1, S // 16, L.ACT_NONE),
+              ('D c6 4x4s1 512->1 @31->30', 512, 1, 1, S // 16 - 1, L.ACT_NONE)]
+    for name, ci, co, st, hw, act in dcases:
+        first = ci == 6
+        if pair:
+            out.append(conv_case(name + ' x2N (D step)', 'conv', ci, co, 4, st, 1, 2 * N, hw, hw, prec, ND, 0 if first else ND, ND, act=act))
+            out.append(conv_case(name + ' (G step)', 'conv', ci, co, 4, st, 1, N, hw, hw, prec, ND, ND, 0, act=act))
+        else:
+            out.append(conv_case(name, 'conv', ci, co, 4, st, 1, N, hw, hw, prec, 3 * ND, ND if first else 3 * ND, 2 * ND, act=act))
     # ---- norms (instance): G 23 per net (fwd + bwd), D 4 per net (3 fwd, 3 bwd)
     out.append(norm_case('norm 64 @512 relu', N, S, S, 64, prec, R, 2 * NG, 2 * NG))
     out.append(norm_case('norm 128 @256 relu', N, S // 2, S // 2, 128, prec, R, 2 * NG, 2 * NG))
     out.append(norm_case('norm 256 @128 relu', N, S // 4, S // 4, 256, prec, R, 10 * NG, 10 * NG))
     out.append(norm_case('norm 256 @128 +res', N, S // 4, S // 4, 256, prec, L.ACT_NONE, 9 * NG, 9 * NG, residual=True))
-    out.append(norm_case('norm 128 @128 lrelu (D)', N, S // 4, S // 4, 128, prec, LR, 3 * ND, 3 * ND))
-    out.append(norm_case('norm 256 @64 lrelu (D)', N, S // 8, S // 8, 256, prec, LR, 3 * ND, 3 * ND))
-    out.append(norm_case('norm 512 @32 lrelu (D)', N, S // 16, S // 16, 512, prec, LR, 3 * ND, 3 * ND))
+    for name, hw, c in (('norm 128 @128 lrelu (D)', S // 4, 128), ('norm 256 @64 lrelu (D)', S // 8, 256), ('norm 512 @32 lrelu (D)', S // 16, 512)):
+        if pair:
+            out.append(norm_case(name + ' x2N', 2 * N, hw, hw, c, prec, LR, ND, ND))
+            out.append(norm_case(name, N, hw, hw, c, prec, LR, ND, ND))
+        else:
+            out.append(norm_case(name, N, hw, hw, c, prec, LR, 3 * ND, 3 * ND))
     tot = sum(r['step_ms'] for r in out)
     print('sum of isolated launches per step: %.1f ms' % tot)
     os.makedirs('gpurun_out', exist_ok=True)
